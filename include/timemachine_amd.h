@@ -1,0 +1,190 @@
+/* timemachine_amd.h -- C ABI of the MI355X-native timemachine hot path (libtimemachine_amd.so).
+ *
+ * This is the drop-in boundary.  Every entry point is the plain-C door onto one method that the reference binds
+ * with pybind11 in timemachine/cpp/src/wrap_kernels.cpp (the `timemachine.lib.custom_ops` module); the citation
+ * next to each declaration is the reference interface it replaces (paths relative to the reference checkout).
+ * Host arrays in, host arrays out, exactly like the pybind layer: coordinates / parameters / boxes are C-contiguous
+ * f64, index arrays are int32 (uint32 where the reference uses uint32), forces and parameter derivatives come
+ * back as the raw 64-bit fixed-point accumulators (scale 2^36; see tm_fixed_to_float / tm_potential_du_dp_fixed_to_float),
+ * energies as signed 128-bit fixed point (tm_int128; "overflowed" means |u| reaches the int64 range => NaN).
+ *
+ * Conventions
+ *   - every function returns TM_OK (0) or an error code; tm_last_error() returns the message of the last failure
+ *     on the calling thread.  Messages are the reference's std::runtime_error texts verbatim.
+ *   - handles are opaque and reference counted internally: a BoundPotential keeps its Potential alive, a
+ *     Summed/Fanout potential keeps its children alive, a Context keeps integrator and potentials alive
+ *     (reference: all bound classes are held by std::shared_ptr).  Destroy every handle you were given exactly once.
+ *   - objects are stateful and NOT thread-safe (reference: cpp/src/potential.hpp:7).
+ *   - "precision" selects the arithmetic type of the kernels (the reference's *_f32 / *_f64 classes); storage of
+ *     coordinates, velocities, box and parameters is always f64.
+ */
+#ifndef TIMEMACHINE_AMD_H
+#define TIMEMACHINE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_OK 0
+#define TM_ERR_RUNTIME 1          /* -> Python RuntimeError (reference: std::runtime_error) */
+#define TM_ERR_INVALID_HARDWARE 2 /* -> custom_ops.InvalidHardware (reference: cpp/src/exceptions.hpp, gpu_utils.cuh:27-53) */
+
+#define TM_F32 0
+#define TM_F64 1
+
+#define TM_FIXED_EXPONENT_VALUE 0x1000000000ULL /* custom_ops.FIXED_EXPONENT, wrap_kernels.cpp:2144; fixed_point.hpp:5 */
+
+typedef struct tm_int128 { /* little-endian two's-complement, layout-identical to __int128 */
+    uint64_t lo;
+    int64_t hi;
+} tm_int128;
+
+typedef struct tm_potential_s *tm_potential_t;
+typedef struct tm_bound_potential_s *tm_bound_potential_t;
+typedef struct tm_integrator_s *tm_integrator_t;
+typedef struct tm_context_s *tm_context_t;
+typedef struct tm_neighborlist_s *tm_neighborlist_t;
+typedef struct tm_hilbert_sort_s *tm_hilbert_sort_t;
+
+/* ---- library / device ------------------------------------------------------------------------------------- */
+const char *tm_last_error(void);
+const char *tm_version(void);
+int tm_device_count(int *count);
+int tm_set_device(int device);     /* one process per GPU: call with LOCAL_RANK before creating objects */
+int tm_device_synchronize(void);
+int tm_device_reset(void);         /* custom_ops.cuda_device_reset(), wrap_kernels.cpp:2222-2225 */
+int tm_device_name(char *buf, size_t cap);
+
+/* fixed point helpers (host).  cpp/src/fixed_point.hpp:13-34, wrap_kernels.cpp:83-89 */
+double tm_fixed_to_float(uint64_t v);
+int tm_energy_overflowed(const tm_int128 *u);            /* fixed_point_overflow */
+double tm_energy_to_float(const tm_int128 *u);           /* convert_energy_to_fp: NaN when overflowed */
+
+/* ---- potentials: construction ----------------------------------------------------------------------------- */
+/* HarmonicBond_f32/_f64(bond_idxs int32[B,2])                      wrap_kernels.cpp:1311-1322; cpp/src/harmonic_bond.cu:11-34 */
+int tm_harmonic_bond_create(int precision, const int32_t *bond_idxs, int num_bonds, tm_potential_t *out);
+/* HarmonicAngle_*(angle_idxs int32[A,3])                            wrap_kernels.cpp:1396-1408; harmonic_angle.cu:11-36 */
+int tm_harmonic_angle_create(int precision, const int32_t *angle_idxs, int num_angles, tm_potential_t *out);
+/* PeriodicTorsion_*(angle_idxs int32[T,4])                          wrap_kernels.cpp:1432-1444; periodic_torsion.cu:11-38 */
+int tm_periodic_torsion_create(int precision, const int32_t *torsion_idxs, int num_torsions, tm_potential_t *out);
+/* NonbondedAllPairs_*(num_atoms, beta, cutoff, atom_idxs_i=None, disable_hilbert_sort=False, nblist_padding=0.1)
+ *                                                                    wrap_kernels.cpp:1446-1478; nonbonded_all_pairs.cu:21-86
+ * atom_idxs == NULL means "all atoms"; duplicates are removed as the binding does (unique_idxs). */
+int tm_nonbonded_all_pairs_create(int precision, int num_atoms, double beta, double cutoff, const int32_t *atom_idxs,
+                                  int num_atom_idxs, int disable_hilbert_sort, double nblist_padding, tm_potential_t *out);
+/* NonbondedPairList_* (negated=0) / NonbondedExclusions_* (negated=1)(pair_idxs_i int32[M,2], scales_i f64[M,2], beta, cutoff)
+ *                                                                    wrap_kernels.cpp:1563-1589; nonbonded_pair_list.cu:12-50 */
+int tm_nonbonded_pair_list_create(int precision, int negated, const int32_t *pair_idxs, int num_pairs, const double *scales,
+                                  int num_scales, double beta, double cutoff, tm_potential_t *out);
+/* SummedPotential(potentials, params_sizes, parallel=True)          wrap_kernels.cpp:1661-1676; summed_potential.cu:13-26 */
+int tm_summed_potential_create(const tm_potential_t *potentials, int num_potentials, const int32_t *params_sizes,
+                               int num_params_sizes, int parallel, tm_potential_t *out);
+/* FanoutSummedPotential(potentials, parallel=True)                  wrap_kernels.cpp:1678-1691; fanout_summed_potential.cu:9-16 */
+int tm_fanout_summed_potential_create(const tm_potential_t *potentials, int num_potentials, int parallel, tm_potential_t *out);
+int tm_potential_destroy(tm_potential_t pot);
+
+/* .get_potentials() of Summed / Fanout: fills up to cap NEW handles (destroy each); *count = number of children */
+int tm_potential_get_children(tm_potential_t pot, tm_potential_t *out, int cap, int *count);
+/* NonbondedAllPairs.set_atom_idxs / get_atom_idxs / get_num_atom_idxs   wrap_kernels.cpp:1452-1454 */
+int tm_nonbonded_all_pairs_set_atom_idxs(tm_potential_t pot, const int32_t *atom_idxs, int num_atom_idxs);
+int tm_nonbonded_all_pairs_get_num_atom_idxs(tm_potential_t pot, int *count);
+int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int cap);
+/* tiles (32 rows x 32 columns) in the current interaction list; diagnostic used by bench.py */
+int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count);
+
+/* ---- potentials: evaluation --------------------------------------------------------------------------------
+ * Potential.execute(coords[N,3], params[P], box[3,3], compute_du_dx, compute_du_dp, compute_u)
+ *                                                                    wrap_kernels.cpp:1039-1105; potential.cu:224-292
+ * Pass NULL for an output that is not requested.  du_dx: uint64[N*3]; du_dp: uint64[P]; u: tm_int128[1]. */
+int tm_potential_execute(tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box,
+                         uint64_t *du_dx, uint64_t *du_dp, tm_int128 *u);
+/* Potential.execute_batch(coords[C,N,3], params[Pb,P], boxes[C,3,3], ...) -> du_dx[C,Pb,N,3], du_dp[C,Pb,P], u[C,Pb]
+ *                                                                    wrap_kernels.cpp:731-862; potential.cu:70-145 */
+int tm_potential_execute_batch(tm_potential_t pot, int coord_batch_size, int N, int param_batch_size, int P,
+                               const double *coords, const double *params, const double *boxes, uint64_t *du_dx,
+                               uint64_t *du_dp, tm_int128 *u);
+/* Potential.execute_batch_sparse(coords, params, boxes, coords_batch_idxs u32[B], params_batch_idxs u32[B], ...)
+ *                                                                    wrap_kernels.cpp:863-1038; potential.cu:147-222 */
+int tm_potential_execute_batch_sparse(tm_potential_t pot, int coords_size, int N, int params_size, int P, int batch_size,
+                                      const uint32_t *coords_batch_idxs, const uint32_t *params_batch_idxs,
+                                      const double *coords, const double *params, const double *boxes, uint64_t *du_dx,
+                                      uint64_t *du_dp, tm_int128 *u);
+/* virtual Potential::du_dp_fixed_to_float (per-column exponents for nonbonded terms, slices for Summed)
+ *                                                                    potential.cu:322-326; nonbonded_all_pairs.cu:292-308 */
+int tm_potential_du_dp_fixed_to_float(tm_potential_t pot, int N, int P, const uint64_t *du_dp, double *out);
+/* Potential::execute_device: everything already resident in HBM (device pointers, hipStream_t as void*).
+ * Accumulates into d_du_dx / d_du_dp, overwrites d_u.             cpp/src/potential.hpp:87-96 */
+int tm_potential_execute_device(tm_potential_t pot, int N, int P, const double *d_x, const double *d_p, const double *d_box,
+                                uint64_t *d_du_dx, uint64_t *d_du_dp, tm_int128 *d_u, void *hip_stream);
+
+/* ---- BoundPotential(potential, params)                            wrap_kernels.cpp:1133-1309; bound_potential.cu ---- */
+int tm_bound_potential_create(tm_potential_t pot, const double *params, int P, tm_bound_potential_t *out);
+int tm_bound_potential_destroy(tm_bound_potential_t bp);
+int tm_bound_potential_set_params(tm_bound_potential_t bp, const double *params, int P); /* size must match: RuntimeError */
+int tm_bound_potential_size(tm_bound_potential_t bp, int *size);
+int tm_bound_potential_get_potential(tm_bound_potential_t bp, tm_potential_t *out); /* NEW handle */
+int tm_bound_potential_execute(tm_bound_potential_t bp, int N, const double *coords, const double *box, uint64_t *du_dx, tm_int128 *u);
+int tm_bound_potential_execute_batch(tm_bound_potential_t bp, int coord_batch_size, int N, const double *coords,
+                                     const double *boxes, uint64_t *du_dx, tm_int128 *u);
+
+/* ---- LangevinIntegrator(masses f64[N], temperature, dt, friction, seed)   wrap_kernels.cpp:691-715; langevin_integrator.cu:14-43
+ * Bound as <float> only, like the reference (wrap_kernels.cpp:700). */
+int tm_langevin_integrator_create(const double *masses, int N, double temperature, double dt, double friction, int seed,
+                                  tm_integrator_t *out);
+int tm_integrator_destroy(tm_integrator_t intg);
+
+/* ---- Context(x0, v0, box, integrator, bps, movers=None)           wrap_kernels.cpp:296-689; context.cu ---------- */
+int tm_context_create(const double *x0, const double *v0, const double *box, int N, tm_integrator_t intg,
+                      const tm_bound_potential_t *bps, int num_bps, tm_context_t *out);
+int tm_context_destroy(tm_context_t ctxt);
+int tm_context_num_atoms(tm_context_t ctxt, int *N);
+int tm_context_step(tm_context_t ctxt);
+int tm_context_initialize(tm_context_t ctxt);
+int tm_context_finalize(tm_context_t ctxt);
+/* multiple_steps(n_steps, store_x_interval): the caller computes n_samples = n_steps / (store_x_interval or n_steps)
+ * exactly as the binding does (wrap_kernels.cpp:347-369) and passes xs[n_samples,N,3], boxes[n_samples,3,3]. */
+int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, double *xs, double *boxes);
+int tm_context_get_x_t(tm_context_t ctxt, double *out);
+int tm_context_get_v_t(tm_context_t ctxt, double *out);
+int tm_context_get_box(tm_context_t ctxt, double *out);
+int tm_context_set_x_t(tm_context_t ctxt, const double *in);
+int tm_context_set_v_t(tm_context_t ctxt, const double *in);
+int tm_context_set_box(tm_context_t ctxt, const double *in);
+
+/* ---- Neighborlist_f32/_f64(N)                                     wrap_kernels.cpp:113-172; neighborlist.cu ------- */
+int tm_neighborlist_create(int precision, int N, tm_neighborlist_t *out);
+int tm_neighborlist_destroy(tm_neighborlist_t nb);
+/* get_nblist(coords, box, cutoff) -> list per 32-row block.  Builds, then reports sizes; fetch with ..._copy_nblist:
+ * offsets int32[num_row_blocks+1], atoms int32[offsets[num_row_blocks]]. */
+int tm_neighborlist_get_nblist(tm_neighborlist_t nb, int N, const double *coords, const double *box, double cutoff,
+                               int *num_row_blocks, int *total_atoms);
+int tm_neighborlist_copy_nblist(tm_neighborlist_t nb, int32_t *offsets, int32_t *atoms);
+/* compute_block_bounds(coords, box, block_size) -> (ctrs[B,3], exts[B,3]); block_size must be 32 (wrap_kernels.cpp:125-128) */
+int tm_neighborlist_compute_block_bounds(tm_neighborlist_t nb, int N, const double *coords, const double *box, int block_size,
+                                         double *ctrs, double *exts);
+int tm_neighborlist_set_row_idxs(tm_neighborlist_t nb, const uint32_t *idxs, int count);
+int tm_neighborlist_reset_row_idxs(tm_neighborlist_t nb);
+int tm_neighborlist_resize(tm_neighborlist_t nb, int size);
+int tm_neighborlist_get_tile_ixn_count(tm_neighborlist_t nb, unsigned int *count);
+int tm_neighborlist_get_max_ixn_count(tm_neighborlist_t nb, int *count);
+int tm_neighborlist_get_num_row_idxs(tm_neighborlist_t nb, int *count);
+
+/* ---- HilbertSort(size).sort(coords, box) -> uint32[N]             wrap_kernels.cpp:174-194; hilbert_sort.cu ------- */
+int tm_hilbert_sort_create(int size, tm_hilbert_sort_t *out);
+int tm_hilbert_sort_destroy(tm_hilbert_sort_t hs);
+int tm_hilbert_sort_sort(tm_hilbert_sort_t hs, int N, const double *coords, const double *box, uint32_t *perm);
+/* host-only: the 128^3 bin -> curve-index table the sort uses (hilbert_sort.cu:18-31); out uint32[128*128*128] */
+int tm_hilbert_lut(uint32_t *out);
+
+/* ---- kernel timing (HIP events on the launch stream of the tile kernel; used by bench.py's roofline leg) ---- */
+int tm_profile_set_enabled(int enabled);
+int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
+int tm_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMEMACHINE_AMD_H */

@@ -1,0 +1,118 @@
+"""CPU tests of the drop-in boundary: the shared library loads without a GPU, exports every symbol that
+include/timemachine_amd.h declares, and the host-only entry points (validation, LUT, fixed-point helpers) behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "timemachine_amd.h")
+LIB = os.path.join(REPO, "timemachine_amd", "csrc", "libtimemachine_amd.so")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "build the extension first: python -m timemachine_amd.csrc.build"
+    lib = ctypes.CDLL(LIB)
+    syms = declared_symbols()
+    assert len(syms) > 60
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_header_cites_reference_interfaces():
+    text = open(HEADER).read()
+    assert text.count("wrap_kernels.cpp") >= 20  # every entry point names the binding it replaces
+
+
+def test_host_only_entry_points():
+    from timemachine_amd.lib import custom_ops
+
+    assert custom_ops.FIXED_EXPONENT == 0x1000000000
+    assert custom_ops._lib.tm_fixed_to_float(ctypes.c_uint64(1 << 36)) == 1.0
+    assert custom_ops._lib.tm_fixed_to_float(ctypes.c_uint64((1 << 64) - (1 << 35))) == -0.5
+    rec = np.zeros(1, dtype=custom_ops._I128)
+    rec["lo"], rec["hi"] = (1 << 63) - 1, 0  # == LLONG_MAX -> overflowed -> NaN
+    assert custom_ops._lib.tm_energy_overflowed(rec.ctypes.data_as(ctypes.c_void_p)) == 1
+    assert np.isnan(custom_ops._lib.tm_energy_to_float(rec.ctypes.data_as(ctypes.c_void_p)))
+    rec["lo"], rec["hi"] = 3 << 35, 0
+    assert custom_ops._lib.tm_energy_to_float(rec.ctypes.data_as(ctypes.c_void_p)) == 1.5
+    # 128-bit negative value
+    rec["lo"], rec["hi"] = (1 << 64) - (1 << 36), -1
+    assert custom_ops._lib.tm_energy_to_float(rec.ctypes.data_as(ctypes.c_void_p)) == -1.0
+
+
+def test_hilbert_lut_of_the_library_is_bit_exact():
+    from oracle import hilbert as ohilbert
+    from timemachine_amd.lib import custom_ops
+
+    np.testing.assert_array_equal(custom_ops.hilbert_lut(), ohilbert.lut())
+
+
+def test_constructor_validation_messages_match_reference():
+    """Messages are part of the contract (reference tests regex-match them); all raised before any GPU work."""
+    from timemachine_amd.lib import custom_ops
+
+    with pytest.raises(RuntimeError, match="Neighborlist N must be at least 1"):  # tests/test_nblist.py:22-25
+        custom_ops.Neighborlist_f32(0)
+    with pytest.raises(RuntimeError, match="src == dst"):
+        custom_ops.HarmonicBond_f64(np.array([[3, 3]], dtype=np.int32))
+    with pytest.raises(RuntimeError, match="angle triplets must be unique"):
+        custom_ops.HarmonicAngle_f32(np.array([[0, 1, 0]], dtype=np.int32))
+    with pytest.raises(RuntimeError, match="torsion quads must be unique"):
+        custom_ops.PeriodicTorsion_f32(np.array([[0, 1, 2, 0]], dtype=np.int32))
+    with pytest.raises(RuntimeError, match="illegal pair with src == dst: 1, 1"):
+        custom_ops.NonbondedExclusions_f32(np.array([[1, 1]], dtype=np.int32), np.ones((1, 2)), 2.0, 1.2)
+    with pytest.raises(RuntimeError, match="expected same number of pairs and scale tuples, but got 1 != 2"):
+        custom_ops.NonbondedPairList_f64(np.array([[0, 1]], dtype=np.int32), np.ones((2, 2)), 2.0, 1.2)
+    with pytest.raises(RuntimeError, match="number of potentials != number of parameter sizes"):
+        custom_ops.SummedPotential([], [3])
+    with pytest.raises(TypeError):  # unsafe cast, as pybind's py::array_t<int, c_style> overload resolution
+        custom_ops.HarmonicBond_f32(np.array([[0.5, 1.5]]))
+    with pytest.raises(TypeError):
+        custom_ops.Potential()
+    with pytest.raises(NotImplementedError):
+        custom_ops.MonteCarloBarostat()
+
+
+def test_dataclass_field_order_is_constructor_order():
+    """to_gpu() calls custom_ops.<Name>_<prec>(*astuple(self)) (reference potentials/potential.py:28-37)."""
+    from dataclasses import fields
+
+    from timemachine_amd import potentials as P
+    from timemachine_amd.lib import LangevinIntegrator
+
+    assert [f.name for f in fields(P.Nonbonded)] == ["num_atoms", "exclusion_idxs", "scale_factors", "beta", "cutoff", "atom_idxs", "disable_hilbert_sort", "nblist_padding"]
+    assert [f.name for f in fields(P.NonbondedAllPairs)] == ["num_atoms", "beta", "cutoff", "atom_idxs", "disable_hilbert_sort", "nblist_padding"]
+    assert [f.name for f in fields(P.NonbondedExclusions)] == ["idxs", "rescale_mask", "beta", "cutoff"]
+    assert [f.name for f in fields(P.NonbondedPairList)] == ["idxs", "rescale_mask", "beta", "cutoff"]
+    assert [f.name for f in fields(P.HarmonicBond)] == ["idxs"]
+    assert [f.name for f in fields(P.SummedPotential)] == ["potentials", "params_init", "parallel"]
+    assert [f.name for f in fields(LangevinIntegrator)] == ["temperature", "dt", "friction", "masses", "seed"]
+    assert P.HarmonicBond._custom_ops_class_name(np.float32) == "HarmonicBond_f32"
+    assert P.NonbondedExclusions._custom_ops_class_name(np.float64) == "NonbondedExclusions_f64"
+    with pytest.raises(ValueError, match="invalid precision"):
+        P.HarmonicBond._custom_ops_class_name(np.float16)
+
+
+def test_filter_exclusions_matches_oracle():
+    from oracle import ref_potentials as rp
+    from timemachine_amd.potentials import filter_exclusions
+
+    rng = np.random.default_rng(1)
+    excl = np.stack([rng.permutation(50)[:2] for _ in range(40)]).astype(np.int32)
+    scales = rng.uniform(size=(40, 2))
+    atom_idxs = np.sort(rng.choice(50, 30, replace=False)).astype(np.int32)
+    a, b = filter_exclusions(atom_idxs, excl, scales)
+    c, d = rp.filter_exclusions(atom_idxs, excl, scales)
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(b, d)
+    e, f = filter_exclusions(np.array([0], dtype=np.int32), excl, scales)
+    assert e.shape == (0, 2) and f.shape == (0, 2)

@@ -1,0 +1,640 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X).  Every call goes Python -> ctypes -> C ABI -> HIP kernels.
+
+Bars (from the reference's own tests):
+  * integer / index work (fixed-point conversion, Hilbert permutation, neighbor-list sets, exclusion cancellation,
+    repeatability): BIT-EXACT
+  * f64 kernels vs the reference potentials: energy rtol 1e-8, forces 1e-8 of the per-atom force norm (floor 1.0), du_dp
+    rtol/atol 1e-7 -- the reference's tolerances (tests/nonbonded/test_nonbonded.py:123,161-163); BASELINE's bar is 1e-6
+  * f32 kernels: rtol 1e-4 / atol 5e-4 (tests/nonbonded/test_nonbonded.py:194)
+Expected values come from tests/golden/*.npz (energies computed by the reference's own Python; see
+tests/golden/generate_golden.py) and, for inputs built on the fly, from the oracle/ package.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def co():
+    from timemachine_amd.lib import custom_ops
+
+    assert custom_ops.device_count() >= 1, "no GPU visible: the product path has no CPU fallback"
+    return custom_ops
+
+
+@pytest.fixture(scope="module")
+def P():
+    from timemachine_amd import potentials
+
+    return potentials
+
+
+def assert_equal_vectors(truth, test, rtol):
+    """OpenMM convention used by the reference (tests/common.py:250-273): error relative to the force norm, floor 1."""
+    assert np.all(np.isfinite(truth)) and np.all(np.isfinite(test))
+    norms = np.linalg.norm(truth, axis=-1, keepdims=True)
+    norms = np.where(norms < 1.0, 1.0, norms)
+    err = np.abs((truth - test) / norms)
+    assert err.max() <= rtol, f"max relative force error {err.max():.3e} > {rtol:.1e}"
+    return err.max()
+
+
+TOL = {np.float64: dict(rtol=1e-8, atol=1e-8, prtol=1e-7, patol=1e-7), np.float32: dict(rtol=1e-4, atol=5e-4, prtol=1e-3, patol=5e-3)}
+
+
+def compare_forces(impl, x, params, box, ref_u, ref_du_dx, ref_du_dp, precision):
+    """The reference's GradientTest.compare_forces (tests/common.py:275-334): all 8 flag combinations, each executed
+    twice and compared bitwise."""
+    t = TOL[precision]
+    for compute_du_dx, compute_du_dp, compute_u in itertools.product([False, True], repeat=3):
+        du_dx, du_dp, u = impl.execute(x, params, box, compute_du_dx, compute_du_dp, compute_u)
+        if compute_u:
+            np.testing.assert_allclose(u, ref_u, rtol=t["rtol"], atol=t["atol"])
+        else:
+            assert u is None
+        if compute_du_dx:
+            assert_equal_vectors(ref_du_dx, du_dx, t["rtol"])
+        else:
+            assert du_dx is None
+        if compute_du_dp:
+            np.testing.assert_allclose(du_dp, ref_du_dp, rtol=t["prtol"], atol=t["patol"])
+        else:
+            assert du_dp is None
+        du_dx2, du_dp2, u2 = impl.execute(x, params, box, compute_du_dx, compute_du_dp, compute_u)
+        np.testing.assert_array_equal(du_dx, du_dx2)
+        np.testing.assert_array_equal(du_dp, du_dp2)
+        assert u == u2
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Nonbonded vs golden vectors
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("name", ["nb_small_w0", "nb_small_wrand", "nb_small_whalf"])
+def test_nonbonded_golden(co, P, name, precision):
+    g = load(name + ".npz")
+    beta, cutoff = float(g["beta"]), float(g["cutoff"])
+    x, p, box = g["x"], g["params"], g["box"]
+    N = x.shape[0]
+    impl = P.Nonbonded(N, g["exclusion_idxs"], g["scale_factors"], beta, cutoff).to_gpu(precision).unbound_impl
+    compare_forces(impl, x, p, box, float(g["u"]), g["du_dx"], g["du_dp"], precision)
+    ap = P.NonbondedAllPairs(N, beta, cutoff).to_gpu(precision).unbound_impl
+    compare_forces(ap, x, p, box, float(g["u_all_pairs"]), g["du_dx_all_pairs"], g["du_dp_all_pairs"], precision)
+    pl = P.NonbondedPairList(g["exclusion_idxs"], g["scale_factors"], beta, cutoff).to_gpu(precision).unbound_impl
+    compare_forces(pl, x, p, box, float(g["u_pair_list"]), g["du_dx_pair_list"], g["du_dp_pair_list"], precision)
+    ex = P.NonbondedExclusions(g["exclusion_idxs"], g["scale_factors"], beta, cutoff).to_gpu(precision).unbound_impl
+    compare_forces(ex, x, p, box, -float(g["u_pair_list"]), -g["du_dx_pair_list"], -g["du_dp_pair_list"], precision)
+    sub = P.Nonbonded(N, g["exclusion_idxs"], g["scale_factors"], beta, cutoff, atom_idxs=g["atom_idxs"]).to_gpu(precision).unbound_impl
+    compare_forces(sub, x, p, box, float(g["u_subset"]), g["du_dx_subset"], g["du_dp_subset"], precision)
+    # atoms outside atom_idxs get exactly zero force (Appendix B.10)
+    du_dx, _, _ = sub.execute(x, p, box)
+    outside = np.setdiff1d(np.arange(N), g["atom_idxs"])
+    assert np.all(du_dx[outside] == 0.0)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("lamb", ["0.0", "0.3", "1.0"])
+def test_config2_all_terms(co, P, lamb, precision):
+    """BASELINE config 2: ~2 300-atom solvated ligand, every term + du/dp vs the reference potentials."""
+    from timemachine_amd import testsystems as ts
+
+    g = load(f"config2_lambda{lamb}.npz")
+    s = ts.small_solvated_ligand(lamb=float(lamb))
+    x, box = g["x"], s.box
+    nb = P.Nonbonded(s.num_atoms, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(precision).unbound_impl
+    compare_forces(nb, x, g["nb_params"], box, float(g["u_nonbonded"]), g["du_dx_nonbonded"], g["du_dp_nonbonded"], precision)
+    t = TOL[precision]
+    terms = [
+        (P.HarmonicBond(s.bond_idxs), s.bond_params, "bond"),
+        (P.HarmonicAngle(s.angle_idxs), s.angle_params, "angle"),
+        (P.PeriodicTorsion(s.torsion_idxs), s.torsion_params, "torsion"),
+    ]
+    for pot, prm, key in terms:
+        impl = pot.to_gpu(precision).unbound_impl
+        du_dx, du_dp, u = impl.execute(x, prm, box)
+        brt = 1e-7 if precision == np.float64 else 2e-5  # tests/test_bonded.py:29,101,146
+        np.testing.assert_allclose(u, float(g[f"u_{key}"]), rtol=brt, atol=brt * 10)
+        assert_equal_vectors(g[f"du_dx_{key}"], du_dx, brt)
+        np.testing.assert_allclose(du_dp, g[f"du_dp_{key}"], rtol=brt * 10, atol=brt * 100)
+    # the whole state as one SummedPotential (how fe.free_energy.get_context packs it)
+    pots = [pot for pot, _, _ in terms] + [P.Nonbonded(s.num_atoms, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff)]
+    prms = [prm for _, prm, _ in terms] + [g["nb_params"]]
+    summed = P.SummedPotential(pots, prms).to_gpu(precision)
+    flat = np.concatenate([np.asarray(q).reshape(-1) for q in prms])
+    du_dx, du_dp, u = summed.unbound_impl.execute(x, flat, box)
+    ref_u = sum(float(g[f"u_{k}"]) for k in ("bond", "angle", "torsion", "nonbonded"))
+    ref_dx = sum(g[f"du_dx_{k}"] for k in ("bond", "angle", "torsion", "nonbonded"))
+    np.testing.assert_allclose(u, ref_u, rtol=t["rtol"] * 10, atol=t["atol"] * 10)
+    assert_equal_vectors(ref_dx, du_dx, t["rtol"] * 10)
+    assert du_dp.shape == flat.shape
+    np.testing.assert_allclose(du_dp[-s.num_atoms * 4 :].reshape(-1, 4), g["du_dp_nonbonded"], rtol=t["prtol"], atol=t["patol"])
+    # serial children give the same bits as parallel children (integer accumulation)
+    serial = P.SummedPotential(pots, prms, parallel=False).to_gpu(precision)
+    du_dx_s, du_dp_s, u_s = serial.unbound_impl.execute(x, flat, box)
+    np.testing.assert_array_equal(du_dx, du_dx_s)
+    np.testing.assert_array_equal(du_dp, du_dp_s)
+    assert u == u_s
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Bitwise invariances (integer accumulation => reordering must not change one bit)
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_bitwise_invariances(co, P, precision):
+    from timemachine_amd import testsystems as ts
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    x, p, box = s.coords, s.nb_params, s.box
+    N = s.num_atoms
+
+    def raw(pot, xx=x, pp=p):
+        return pot.to_gpu(precision).unbound_impl.execute_raw(xx, pp, box)
+
+    base = raw(P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff))
+    # Hilbert sort on/off (tests/nonbonded/test_nonbonded.py:18-60)
+    nohilb = raw(P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, disable_hilbert_sort=True))
+    # padding 0.0 vs 0.1 (test_nblist_rebuild)
+    nopad = raw(P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, nblist_padding=0.0))
+    # atom_idxs=None vs arange(N)
+    arange = raw(P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, atom_idxs=np.arange(N, dtype=np.int32)))
+    for other in (nohilb, nopad, arange):
+        np.testing.assert_array_equal(base[0], other[0])
+        np.testing.assert_array_equal(base[1], other[1])
+        assert base[2] == other[2]
+    # random relabelling of the atoms permutes the output, bit for bit
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(N)
+    inv = np.argsort(perm)
+    excl_perm = inv[s.exclusion_idxs].astype(np.int32)
+    permuted = raw(P.Nonbonded(N, excl_perm, s.scale_factors, s.beta, s.cutoff), x[perm], p[perm])
+    np.testing.assert_array_equal(base[0][perm], permuted[0])
+    np.testing.assert_array_equal(base[1].reshape(N, 4)[perm].reshape(-1), permuted[1])
+    assert base[2] == permuted[2]
+    # Newton's third law in fixed point: sum of all force accumulators wraps to exactly zero
+    with np.errstate(over="ignore"):
+        assert np.all(base[0].sum(axis=0, dtype=np.uint64) == 0)
+    # decomposition: AllPairs + Exclusions == Nonbonded, bitwise (tests/nonbonded/test_consistency.py)
+    ap = raw(P.NonbondedAllPairs(N, s.beta, s.cutoff))
+    ex = raw(P.NonbondedExclusions(s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff))
+    with np.errstate(over="ignore"):
+        np.testing.assert_array_equal(ap[0] + ex[0], base[0])
+        np.testing.assert_array_equal(ap[1] + ex[1], base[1])
+    assert ap[2] + ex[2] == base[2]
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_exclusions_cancel_exactly_with_clashing_atoms(co, P, precision):
+    """10 mutually excluded atoms within 1e-3 nm of each other: the all-pairs terms are astronomically large and must
+    cancel bit-for-bit against the exclusion kernel (tests/nonbonded/test_nonbonded.py:208-251)."""
+    from oracle import ref_potentials as rp
+
+    rng = np.random.default_rng(11)
+    N, L, beta, cutoff = 96, 3.0, 2.0, 1.2
+    x = rng.uniform(0, L, (N, 3))
+    x[:10] = x[0] + rng.uniform(-1e-3, 1e-3, (10, 3))
+    params = np.stack([(rng.uniform(size=N) - 0.5) * 11.0, rng.uniform(0.05, 0.1, N), np.sqrt(rng.uniform(size=N)), np.zeros(N)], 1)
+    x = x.astype(np.float32).astype(np.float64)
+    params = params.astype(np.float32).astype(np.float64)
+    excl = np.array([(i, j) for i in range(10) for j in range(i + 1, 10)], dtype=np.int32)
+    scales = np.ones((len(excl), 2))
+    box = np.eye(3) * L
+    ref_u, ref_dx, ref_dp = rp.nonbonded(x, params, box, excl, scales, beta, cutoff)
+    impl = P.Nonbonded(N, excl, scales, beta, cutoff).to_gpu(precision).unbound_impl
+    du_dx, du_dp, u = impl.execute(x, params, box)
+    t = TOL[precision]
+    np.testing.assert_allclose(u, ref_u, rtol=t["rtol"], atol=t["atol"])
+    assert_equal_vectors(ref_dx, du_dx, t["rtol"])
+    np.testing.assert_allclose(du_dp, ref_dp, rtol=t["prtol"], atol=t["patol"])
+    # without the exclusions the same configuration must overflow the energy (and only the energy) -> NaN
+    ap = P.NonbondedAllPairs(N, beta, cutoff).to_gpu(precision).unbound_impl
+    _, _, u_ap = ap.execute(x, params, box, False, False, True)
+    assert np.isnan(u_ap) or abs(u_ap) > 1e6
+
+
+def test_energy_overflow_semantics(co, P):
+    """Overlapping atoms: NaN from execute, LLONG_MAX from execute_fixed (tests/test_energy_overflows.py:21-63)."""
+    N, L = 8, 4.0
+    x = np.zeros((N, 3)) + np.arange(N)[:, None] * 0.3
+    x[1] = x[0] + 1e-12
+    params = np.tile([3.0, 0.15, 1.0, 0.0], (N, 1))
+    box = np.eye(3) * L
+    for precision in (np.float32, np.float64):
+        ap = P.NonbondedAllPairs(N, 2.0, 1.2).to_gpu(precision)
+        _, _, u = ap.unbound_impl.execute(x, params, box, False, False, True)
+        assert np.isnan(u)
+        fixed = ap.bind(params).bound_impl.execute_fixed(x, box)
+        assert fixed.dtype == np.uint64 and int(fixed[0]) == (1 << 63) - 1
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Bonded
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_bonded_golden_and_symmetry(co, P, precision):
+    g = load("bonded.npz")
+    x, box = g["x"], g["box"]
+    rt = 1e-7 if precision == np.float64 else 2e-5
+    for cls, key, width in ((P.HarmonicBond, "bond", 2), (P.HarmonicAngle, "angle", 3), (P.PeriodicTorsion, "torsion", 4)):
+        idxs, prm = g[f"{key}_idxs"], g[f"{key}_params"]
+        impl = cls(idxs).to_gpu(precision).unbound_impl
+        for cx, cp, cu in itertools.product([False, True], repeat=3):
+            du_dx, du_dp, u = impl.execute(x, prm, box, cx, cp, cu)
+            if cu:
+                np.testing.assert_allclose(u, float(g[f"u_{key}"]), rtol=rt, atol=rt * 10)
+            if cx:
+                assert_equal_vectors(g[f"du_dx_{key}"], du_dx, rt)
+            if cp:
+                np.testing.assert_allclose(du_dp, g[f"du_dp_{key}"], rtol=rt * 10, atol=rt * 100)
+            again = impl.execute(x, prm, box, cx, cp, cu)
+            np.testing.assert_array_equal(du_dx, again[0])
+            np.testing.assert_array_equal(du_dp, again[1])
+        # reversing the index order of every term gives identical bits (tests/test_bonded.py:109-120, test_bonded_stable.py:37-56)
+        if key in ("bond", "angle"):
+            rev = cls(np.ascontiguousarray(idxs[:, ::-1])).to_gpu(precision).unbound_impl
+            a = impl.execute_raw(x, prm, box)
+            b = rev.execute_raw(x, prm, box)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            assert a[2] == b[2]
+    # wrong parameter count -> the reference's message
+    with pytest.raises(RuntimeError, match=r"HarmonicBond::execute_device\(\): expected P == 2\*B, got P=3, 2\*B=80"):
+        P.HarmonicBond(g["bond_idxs"]).to_gpu(precision).unbound_impl.execute(x, np.zeros(3), box)
+    # empty term lists are legal and contribute nothing
+    empty = P.HarmonicBond(np.zeros((0, 2), dtype=np.int32)).to_gpu(precision).unbound_impl
+    du_dx, du_dp, u = empty.execute(x, np.zeros((0, 2)), box)
+    assert np.all(du_dx == 0) and du_dp.shape == (0, 2) and u == 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Hilbert sort + neighbor list (integer / index work: exact)
+# ----------------------------------------------------------------------------------------------------------------
+def test_hilbert_sort_permutation_is_bit_exact(co):
+    g = load("hilbert.npz")
+    water = np.load(os.path.join(GOLDEN, "water.npy"))[:, :3]
+    perm = co.HilbertSort(water.shape[0]).sort(water, g["box"])
+    np.testing.assert_array_equal(perm, g["perm"])
+    # ties: many atoms in one bin must keep their input order (stable sort)
+    from oracle import hilbert as ohilbert
+
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 0.2, (5000, 3)) + np.array([1.0, 2.0, 3.0])
+    box = np.eye(3) * 6.0
+    perm2 = co.HilbertSort(5000).sort(x, box)
+    assert len(np.unique(ohilbert.keys(x, box))) < 200
+    np.testing.assert_array_equal(perm2, ohilbert.sort_perm(x, box))
+    with pytest.raises(RuntimeError, match="number of idxs to sort must be less than or equal to N"):
+        co.HilbertSort(10).sort(x, box)
+
+
+@pytest.mark.parametrize("size", [12, 128, 156, 298])
+def test_block_bounds(co, size):
+    from oracle import nblist as onblist
+
+    rng = np.random.default_rng(2020)
+    coords = rng.normal(size=(size, 3))
+    box = np.eye(3) * (rng.uniform(size=3) + 1)
+    for cls, real, tol in ((co.Neighborlist_f32, np.float32, 1e-6), (co.Neighborlist_f64, np.float64, 1e-7)):
+        ctr, ext = cls(size).compute_block_bounds(coords, box, 32)
+        rc, re = onblist.block_bounds(coords, box, real=real)
+        np.testing.assert_allclose(ctr, rc, atol=tol, rtol=tol)
+        np.testing.assert_allclose(ext, re, atol=tol, rtol=tol)
+        with pytest.raises(RuntimeError, match="Block size must be 32."):
+            cls(size).compute_block_bounds(coords, box, 64)
+
+
+@pytest.mark.parametrize("num_atoms", [35, 64, 129, 1025, 1259, 2029])
+def test_neighborlist_matches_brute_force(co, num_atoms):
+    """tests/test_nblist.py:236-265: per 32-row block, the reported column set equals brute force at the list cutoff."""
+    from oracle import hilbert as ohilbert
+    from oracle import nblist as onblist
+
+    water = np.load(os.path.join(GOLDEN, "water.npy")).astype(np.float32).astype(np.float64)[:, :3]
+    rng = np.random.default_rng(1234)
+    coords = water[rng.choice(num_atoms, num_atoms, replace=False)]
+    box = np.eye(3) * (coords.max(0) - coords.min(0) + 0.1)
+    coords = coords[ohilbert.sort_perm(coords, box)]
+    ref = onblist.brute_force_ixn_list(coords, box, 1.0)
+    for cls in (co.Neighborlist_f32, co.Neighborlist_f64):
+        nb = cls(num_atoms)
+        for _ in range(2):
+            test = nb.get_nblist(coords, box, 1.0)
+            assert len(test) == len(ref)
+            for a, b in zip(ref, test):
+                assert sorted(a) == sorted(b)
+        assert nb.get_tile_ixn_count() == onblist.tile_count(ref)
+        assert nb.get_num_row_idxs() == num_atoms
+        nblocks = (num_atoms + 31) // 32
+        assert nb.get_max_ixn_count() == nblocks * (nblocks + 1) // 2 * 32
+    # row subset vs complement columns (tests/test_nblist.py:188-233)
+    rows = rng.choice(num_atoms, num_atoms // 2, replace=False).astype(np.uint32)
+    ref_rows = onblist.brute_force_ixn_list_rows(coords, box, 1.0, rows)
+    nb = co.Neighborlist_f64(num_atoms)
+    nb.set_row_idxs(rows)
+    test = nb.get_nblist(coords, box, 1.0)
+    assert len(test) == len(ref_rows)
+    for a, b in zip(ref_rows, test):
+        assert sorted(a) == sorted(b)
+    nb.reset_row_idxs()
+    for a, b in zip(ref, nb.get_nblist(coords, box, 1.0)):
+        assert sorted(a) == sorted(b)
+
+
+def test_neighborlist_validation_messages(co):
+    nb = co.Neighborlist_f32(3)
+    with pytest.raises(RuntimeError, match="size is greater than max size: 4 > 3"):
+        nb.resize(4)
+    with pytest.raises(RuntimeError, match="size is must be at least 1"):
+        nb.resize(0)
+    with pytest.raises(RuntimeError, match="idxs can't be empty"):
+        nb.set_row_idxs(np.zeros(0, dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="atom indices must be unique"):
+        nb.set_row_idxs(np.array([1, 1], dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="number of idxs must be less than N"):
+        nb.set_row_idxs(np.array([0, 1, 2], dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="indices values must be less than N"):
+        nb.set_row_idxs(np.array([7], dtype=np.uint32))
+
+
+def test_all_pairs_validation_messages(co, P):
+    # tests/nonbonded/test_nonbonded_all_pairs.py:10-50
+    with pytest.raises(RuntimeError, match="indices can't be empty"):
+        co.NonbondedAllPairs_f32(3, 2.0, 1.1, np.zeros(0, dtype=np.int32))
+    with pytest.raises(RuntimeError, match=r"index values must be less than N\(3\)"):
+        co.NonbondedAllPairs_f32(3, 2.0, 1.1, np.array([0, 5], dtype=np.int32))
+    with pytest.raises(RuntimeError, match="index values must be greater or equal to zero"):
+        co.NonbondedAllPairs_f32(3, 2.0, 1.1, np.array([-1, 1], dtype=np.int32))
+    pot = co.NonbondedAllPairs_f32(1, 2.0, 1.1)
+    with pytest.raises(RuntimeError, match=r"NonbondedAllPairs::execute_device\(\): expected N == N_, got N=2, N_=1"):
+        pot.execute(np.zeros((2, 3)), np.zeros((2, 4)), np.eye(3) * 3)
+    with pytest.raises(RuntimeError, match=r"NonbondedAllPairs::execute_device\(\): expected P == N_\*4, got P=6, N_\*4=4"):
+        pot.execute(np.zeros((1, 3)), np.zeros((1, 6)), np.eye(3) * 3)
+    with pytest.raises(RuntimeError, match="box must be ortholinear"):
+        pot.execute(np.zeros((1, 3)), np.zeros((1, 4)), np.ones((3, 3)))
+    with pytest.raises(RuntimeError, match="coords dimensions must be 2"):
+        pot.execute(np.zeros((1, 1, 3)), np.zeros((1, 4)), np.eye(3))
+    # K == 1 -> exactly zero (test_nonbonded_all_pairs.py:74-90)
+    du_dx, du_dp, u = pot.execute(np.zeros((1, 3)), np.ones((1, 4)), np.eye(3) * 3)
+    assert np.all(du_dx == 0) and np.all(du_dp == 0) and u == 0
+    # set_atom_idxs == fresh object, bitwise
+    rng = np.random.default_rng(2)
+    N = 70
+    x = rng.uniform(0, 3, (N, 3))
+    p = np.stack([rng.normal(size=N), rng.uniform(0.05, 0.15, N), rng.uniform(0.2, 1, N), np.zeros(N)], 1)
+    box = np.eye(3) * 3
+    sub = np.sort(rng.choice(N, 30, replace=False)).astype(np.int32)
+    a = co.NonbondedAllPairs_f64(N, 2.0, 1.2)
+    a.execute(x, p, box)
+    a.set_atom_idxs(sub)
+    assert a.get_num_atom_idxs() == 30 and a.get_atom_idxs() == sub.tolist()
+    b = co.NonbondedAllPairs_f64(N, 2.0, 1.2, sub)
+    ra, rb = a.execute_raw(x, p, box), b.execute_raw(x, p, box)
+    np.testing.assert_array_equal(ra[0], rb[0])
+    np.testing.assert_array_equal(ra[1], rb[1])
+    assert ra[2] == rb[2]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Potential plumbing
+# ----------------------------------------------------------------------------------------------------------------
+def test_bound_potential_and_batches(co, P):
+    from timemachine_amd import testsystems as ts
+
+    s = ts.add_chain_ligand(ts.build_water_box(216, 2.7, seed=9), 12, lamb=0.2)
+    N = s.num_atoms
+    nb = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(np.float64)
+    bound = nb.bind(s.nb_params).bound_impl
+    assert bound.size() == N * 4 and bound.get_potential() is nb.unbound_impl
+    du_dx, u = bound.execute(s.coords, s.box)
+    ref = nb.unbound_impl.execute(s.coords, s.nb_params, s.box)
+    np.testing.assert_array_equal(du_dx, ref[0])
+    assert u == ref[2]
+    with pytest.raises(RuntimeError, match="parameter size is not equal to device buffer size"):
+        bound.set_params(np.zeros(3))
+    p2 = s.nb_params.copy()
+    p2[:, 0] *= 0.5
+    bound.set_params(p2)
+    assert bound.execute(s.coords, s.box)[1] == nb.unbound_impl.execute(s.coords, p2, s.box)[2]
+    # execute_batch: [C, Pb, ...] outer loop coords, inner loop params
+    rng = np.random.default_rng(0)
+    coords = np.stack([s.coords, s.coords + rng.normal(scale=0.002, size=s.coords.shape)])
+    boxes = np.stack([s.box, s.box])
+    params = np.stack([s.nb_params, p2, s.nb_params * np.array([1.0, 1.0, 0.5, 1.0])])
+    bx, bp, bu = nb.unbound_impl.execute_batch(coords, params, boxes, True, True, True)
+    assert bx.shape == (2, 3, N, 3) and bp.shape == (2, 3, N, 4) and bu.shape == (2, 3)
+    for i, j in itertools.product(range(2), range(3)):
+        e = nb.unbound_impl.execute(coords[i], params[j], boxes[i])
+        np.testing.assert_array_equal(bx[i, j], e[0])
+        np.testing.assert_array_equal(bp[i, j], e[1])
+        assert bu[i, j] == e[2]
+    assert nb.unbound_impl.execute_batch(coords, params, boxes, False, False, True)[:2] == (None, None)
+    ci = np.array([1, 0, 1], dtype=np.uint32)
+    pi = np.array([2, 0, 1], dtype=np.uint32)
+    sx, sp, su = nb.unbound_impl.execute_batch_sparse(coords, params, boxes, ci, pi, True, True, True)
+    for k in range(3):
+        np.testing.assert_array_equal(sx[k], bx[ci[k], pi[k]])
+        np.testing.assert_array_equal(sp[k], bp[ci[k], pi[k]])
+        assert su[k] == bu[ci[k], pi[k]]
+    with pytest.raises(RuntimeError, match="coords_batch_idxs contains an index that is out of bounds"):
+        nb.unbound_impl.execute_batch_sparse(coords, params, boxes, np.array([2], dtype=np.uint32), np.array([0], dtype=np.uint32), True, True, True)
+    cb_x, cb_u = bound.execute_batch(coords, boxes, True, True)
+    np.testing.assert_array_equal(cb_x[0], bx[0, 1])
+    assert cb_u[1] == bu[1, 1]
+    # the python front-ends (reference: potentials/potential.py) give the same energy
+    assert nb(s.coords, s.nb_params, s.box) == ref[2]
+    assert P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).bind(s.nb_params).to_gpu(np.float64)(s.coords, s.box) == ref[2]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Integrator + Context
+# ----------------------------------------------------------------------------------------------------------------
+def _md_system():
+    from timemachine_amd import testsystems as ts
+
+    return ts.add_chain_ligand(ts.build_water_box(300, 3.0, seed=4), 16, lamb=0.0)
+
+
+def test_context_deterministic_steps_match_oracle(co, P):
+    """friction = 0 => no noise: 12 steps of ctxt.step() against the oracle's model of the device arithmetic, with forces
+    taken from the GPU's own fixed-point output; and against the f64 python BAOAB with oracle forces (loose: the
+    bound integrator rounds velocities to float like the reference's, wrap_kernels.cpp:700).  tests/test_md.py:142-247."""
+    from oracle import integrator as oi
+    from oracle import ref_potentials as rp
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    N = s.num_atoms
+    rng = np.random.default_rng(2)
+    v0 = rng.normal(size=(N, 3)) * 0.2
+    dt, T = 1.0e-3, 300.0
+    bps64 = [bp.to_gpu(np.float64).bound_impl for bp in ts.bound_potentials(s)]
+    intg = LangevinIntegrator(T, dt, 0.0, s.masses, 2024).impl()
+    ctxt = co.Context(s.coords, v0, s.box, intg, bps64)
+    ca, cb, cc, dt_r = oi.device_coefficients(T, dt, 0.0, s.masses)
+    assert np.all(cc == 0)
+    x, v = s.coords.copy(), v0.copy()
+    xf, vf = s.coords.copy(), v0.copy()
+    caf, cbf, ccf = oi.langevin_coefficients(T, dt, 0.0, s.masses)
+    eval_bps = [bp.to_gpu(np.float64).bound_impl for bp in ts.bound_potentials(s)]
+    for step in range(12):
+        # forces at the model's current x from fresh evaluations (same kernels => same fixed-point values)
+        fixed = np.zeros((N, 3), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for bp in eval_bps:
+                dx, _ = bp.execute(x, s.box, True, False)
+                fixed += np.rint(dx * 2.0**36).astype(np.int64).view(np.uint64)
+        x, v = oi.baoab_step_device_model(x, v, fixed, np.zeros((N, 3)), ca, cb, cc, dt_r)
+        ctxt.step()
+        np.testing.assert_allclose(ctxt.get_x_t(), x, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ctxt.get_v_t(), v, rtol=0, atol=1e-7)
+        if step < 4:  # independent f64 path with oracle forces
+            f = np.zeros((N, 3))
+            f -= rp.nonbonded(xf, s.nb_params, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff)[1]
+            f -= rp.harmonic_bond(xf, s.bond_params, s.box, s.bond_idxs)[1]
+            f -= rp.harmonic_angle(xf, s.angle_params, s.box, s.angle_idxs)[1]
+            f -= rp.periodic_torsion(xf, s.torsion_params, s.box, s.torsion_idxs)[1]
+            xf, vf = oi.baoab_step(xf, vf, f, np.zeros((N, 3)), caf, cbf, ccf, dt)
+            np.testing.assert_allclose(ctxt.get_x_t(), xf, rtol=0, atol=5e-7)
+            np.testing.assert_allclose(ctxt.get_v_t(), vf, rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(ctxt.get_box(), s.box)
+
+
+def test_context_multiple_steps_semantics(co, P):
+    """store_x_interval semantics, setters/getters, validation errors (tests/test_md.py:24-140,895-1009)."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    N = s.num_atoms
+    v0 = np.zeros((N, 3))
+
+    def make(seed=2024, friction=1.0, dt=0.5e-3):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+        return co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, dt, friction, s.masses, seed).impl(), bps)
+
+    c1, c2 = make(), make()
+    xs, boxes = c1.multiple_steps(20, 5)
+    assert xs.shape == (4, N, 3) and boxes.shape == (4, 3, 3)
+    np.testing.assert_array_equal(xs[-1], c1.get_x_t())
+    # same seed => same trajectory, bit for bit (counter-based noise); stepping one at a time is the same thing
+    for k in range(20):
+        c2.step()
+        if (k + 1) % 5 == 0:
+            np.testing.assert_array_equal(c2.get_x_t(), xs[(k + 1) // 5 - 1])
+    np.testing.assert_array_equal(c1.get_v_t(), c2.get_v_t())
+    c3 = make(seed=7)
+    xs3, _ = c3.multiple_steps(20, 0)
+    assert xs3.shape == (1, N, 3) and not np.array_equal(xs3[0], xs[-1])
+    assert np.all(np.isfinite(xs3))
+    xs_none, boxes_none = make().multiple_steps(5, 10)  # interval > n_steps: no frames, no box check
+    assert xs_none.shape == (0, N, 3) and boxes_none.shape == (0, 3, 3)
+    with pytest.raises(RuntimeError, match="store_x_interval must be greater than or equal to zero"):
+        c1.multiple_steps(5, -1)
+    # setters / getters round trip
+    newx = s.coords + 0.001
+    c1.set_x_t(newx)
+    c1.set_v_t(v0 + 0.5)
+    np.testing.assert_array_equal(c1.get_x_t(), newx)
+    np.testing.assert_array_equal(c1.get_v_t(), v0 + 0.5)
+    with pytest.raises(RuntimeError, match="number of new coords disagree with current coords"):
+        c1.set_x_t(newx[:-1])
+    with pytest.raises(RuntimeError, match="box must be 3x3"):
+        c1.set_box(np.eye(4))
+    assert c1.get_integrator() is not None and len(c1.get_potentials()) == 4 and c1.get_movers() == [] and c1.get_barostat() is None
+    # box smaller than 2 * (cutoff + padding) is rejected when a frame is collected
+    small = make()
+    small.set_box(np.eye(3) * 2.5)
+    with pytest.raises(RuntimeError, match="cutoff with padding is more than half of the box width, neighborlist is no longer reliable"):
+        small.multiple_steps(2, 1)
+    # exploded coordinates are rejected
+    boom = make()
+    far = s.coords.copy()
+    far[0] += 1e4
+    boom.set_x_t(far)
+    with pytest.raises(RuntimeError, match="simulation unstable: dimensions of coordinates two orders of magnitude larger than max box dimension"):
+        boom.multiple_steps(1, 1)
+    with pytest.raises(RuntimeError, match="v0 N != x0 N"):
+        co.Context(s.coords, v0[:-1], s.box, LangevinIntegrator(300.0, 1e-3, 1.0, s.masses, 1).impl(), [])
+
+
+def test_langevin_thermostat_statistics(co, P):
+    """Statistical parity for the stochastic part (cuRAND streams cannot be matched): ideal gas (no potentials) with
+    friction reaches kT per degree of freedom; the noise has zero mean, unit variance and no lag-1 correlation."""
+    from timemachine_amd.lib import LangevinIntegrator
+
+    N = 20000
+    rng = np.random.default_rng(0)
+    masses = rng.uniform(1.0, 16.0, N)
+    x0 = rng.uniform(0, 5, (N, 3))
+    ctxt = co.Context(x0, np.zeros((N, 3)), np.eye(3) * 5, LangevinIntegrator(300.0, 2.5e-3, 50.0, masses, 99).impl(), [])
+    ctxt.multiple_steps(200, 0)
+    v = ctxt.get_v_t()
+    kT = 0.008314462618 * 300.0
+    ke_per_dof = (masses[:, None] * v * v).mean()
+    assert abs(ke_per_dof / kT - 1.0) < 0.02
+    z = v * np.sqrt(masses[:, None] / kT)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs(np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]) < 0.03 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.03
+    from scipy import stats
+
+    assert stats.kstest(z.reshape(-1)[:50000], "norm").pvalue > 1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Full size (BASELINE config 3): size-independent properties + a sampled comparison with the oracle
+# ----------------------------------------------------------------------------------------------------------------
+def test_dhfr_sized_box_properties(co, P):
+    from oracle import ref_potentials as rp
+    from timemachine_amd import testsystems as ts
+
+    s = ts.dhfr_sized_water_box()
+    N = s.num_atoms
+    assert N == 23559
+    x, p, box = s.coords, s.nb_params, s.box
+    nb = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(np.float64).unbound_impl
+    a = nb.execute_raw(x, p, box)
+    b = nb.execute_raw(x, p, box)
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[2] == b[2]
+    with np.errstate(over="ignore"):
+        assert np.all(a[0].sum(axis=0, dtype=np.uint64) == 0)  # Newton's third law, exactly
+    nohilb = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, disable_hilbert_sort=True).to_gpu(np.float64).unbound_impl
+    c = nohilb.execute_raw(x, p, box)
+    np.testing.assert_array_equal(a[0], c[0])
+    np.testing.assert_array_equal(a[1], c[1])
+    assert a[2] == c[2]
+    # oracle forces for a sample of atoms: F_i = sum_j dU_ij/dx_i over every j outside i's own (fully excluded) water
+    import torch
+
+    rng = np.random.default_rng(1)
+    sample = np.sort(rng.choice(N, 256, replace=False))
+    pt = torch.tensor(p)
+    bt = torch.tensor(np.diagonal(box).copy())
+    others = torch.arange(N)
+    du_dx = a[0].view(np.int64).astype(np.float64) / 2.0**36
+    ref = np.zeros((len(sample), 3))
+    xt2 = torch.tensor(x)
+    for k0 in range(0, len(sample), 64):
+        idx = sample[k0 : k0 + 64]
+        xi = torch.tensor(x[idx], requires_grad=True)
+        d3 = rp.delta_r(xi[:, None, :], xt2[None, :, :], bt)
+        d2 = (d3 * d3).sum(-1)
+        m = torch.tensor(idx)[:, None] != others[None, :]
+        ex_mask = torch.ones_like(m)
+        for r, i in enumerate(idx):
+            w0 = (i // 3) * 3
+            ex_mask[r, w0 : w0 + 3] = False  # same water molecule: excluded (scale 1) or self
+        d2 = torch.where(m & ex_mask, d2, torch.full_like(d2, 1e6))
+        lj, es = rp._pair_energies(torch.sqrt(d2), pt[idx, 0][:, None] * pt[None, :, 0], pt[idx, 1][:, None] + pt[None, :, 1], pt[idx, 2][:, None] * pt[None, :, 2], s.beta, s.cutoff)
+        ref[k0 : k0 + 64] = torch.autograd.grad((lj + es).sum(), xi)[0].numpy()
+    assert_equal_vectors(ref, du_dx[sample], 1e-8)

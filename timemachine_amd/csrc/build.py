@@ -1,0 +1,70 @@
+"""Builds libtimemachine_amd.so for gfx950 with hipcc (in-tree, next to the sources).
+
+    python -m timemachine_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so travels to the GPU box
+with the repo snapshot.  One object per translation unit, compiled in parallel, linked into one shared library.
+-ffp-contract=off: the per-pair math must compile to the same instruction sequence at every call site (exclusions are
+subtracted in fixed point and have to cancel bit-for-bit); every fused multiply-add we want is written explicitly.
+"""
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libtimemachine_amd.so")
+SOURCES = ["nonbonded.hip", "bonded.hip", "integrator.hip", "potential.hip", "c_api.cpp"]
+HEADERS = [
+    "common.hpp", "engine.hpp", "fixed_point.cuh", "nb_pair.cuh", "kernels_nonbonded.cuh", "kernels_nblist.cuh",
+    "profiler.hpp", "../../include/timemachine_amd.h",
+]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+]
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + ["build.py"]:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, obj, r.returncode, r.stdout + r.stderr
+
+
+def build(force=False, verbose=True):
+    stamp_file = os.path.join(HERE, ".build_stamp")
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    objs = []
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        for src, obj, rc, out in ex.map(_compile, SOURCES):
+            if verbose and out.strip():
+                print(f"--- {src} ---\n{out}", file=sys.stderr)
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {src}")
+            objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print(r.stdout + r.stderr, file=sys.stderr)
+        raise RuntimeError("link failed")
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,588 @@
+// extern "C" surface of libtimemachine_amd.so (declared in include/timemachine_amd.h).
+// Thin: argument marshalling + exception -> error-code translation.  No torch, no Python types.
+#include "../../include/timemachine_amd.h"
+#include "engine.hpp"
+#include "profiler.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <set>
+
+using namespace tmamd;
+
+struct tm_potential_s {
+    std::shared_ptr<Potential> p;
+};
+struct tm_bound_potential_s {
+    std::shared_ptr<BoundPotential> p;
+};
+struct tm_integrator_s {
+    std::shared_ptr<Integrator> p;
+};
+struct tm_context_s {
+    std::unique_ptr<Context> p;
+};
+struct tm_neighborlist_s {
+    int precision;
+    std::unique_ptr<Neighborlist<float>> f32;
+    std::unique_ptr<Neighborlist<double>> f64;
+    std::vector<std::vector<int>> last;
+};
+struct tm_hilbert_sort_s {
+    std::unique_ptr<HilbertSort> p;
+};
+
+static thread_local std::string g_last_error;
+
+#define TM_TRY try {
+#define TM_CATCH                                                                                                       \
+    }                                                                                                                  \
+    catch (const InvalidHardware &e) {                                                                                 \
+        g_last_error = e.what();                                                                                       \
+        return TM_ERR_INVALID_HARDWARE;                                                                                \
+    }                                                                                                                  \
+    catch (const std::exception &e) {                                                                                  \
+        g_last_error = e.what();                                                                                       \
+        return TM_ERR_RUNTIME;                                                                                         \
+    }                                                                                                                  \
+    catch (...) {                                                                                                      \
+        g_last_error = "unknown error";                                                                                \
+        return TM_ERR_RUNTIME;                                                                                         \
+    }                                                                                                                  \
+    return TM_OK;
+
+static void require(bool cond, const char *msg) {
+    if (!cond)
+        throw std::runtime_error(msg);
+}
+
+static i128 *as_i128(tm_int128 *u) { return reinterpret_cast<i128 *>(u); }
+static_assert(sizeof(tm_int128) == sizeof(i128), "tm_int128 must be layout compatible with __int128");
+
+template <template <typename> class Cls, typename... Args> static std::shared_ptr<Potential> make_by_precision(int precision, Args &&...args) {
+    if (precision == TM_F32)
+        return std::make_shared<Cls<float>>(std::forward<Args>(args)...);
+    if (precision == TM_F64)
+        return std::make_shared<Cls<double>>(std::forward<Args>(args)...);
+    throw std::runtime_error("invalid precision");
+}
+
+template <typename F> static void with_all_pairs(tm_potential_t pot, F f) {
+    if (auto a = std::dynamic_pointer_cast<NonbondedAllPairs<float>>(pot->p))
+        f(*a);
+    else if (auto b = std::dynamic_pointer_cast<NonbondedAllPairs<double>>(pot->p))
+        f(*b);
+    else
+        throw std::runtime_error("unable to cast potential to NonbondedAllPairs");
+}
+
+extern "C" {
+
+const char *tm_last_error(void) { return g_last_error.c_str(); }
+const char *tm_version(void) { return "timemachine_amd 0.1 (gfx950)"; }
+
+int tm_device_count(int *count) {
+    TM_TRY
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        n = 0;
+        (void)hipGetLastError();
+    }
+    *count = n;
+    TM_CATCH
+}
+
+int tm_set_device(int device) {
+    TM_TRY
+    HIP_CHECK(hipSetDevice(device));
+    TM_CATCH
+}
+
+int tm_device_synchronize(void) {
+    TM_TRY
+    HIP_CHECK(hipDeviceSynchronize());
+    TM_CATCH
+}
+
+int tm_device_reset(void) {
+    TM_TRY
+    HIP_CHECK(hipDeviceReset());
+    TM_CATCH
+}
+
+int tm_device_name(char *buf, size_t cap) {
+    TM_TRY
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    TM_CATCH
+}
+
+double tm_fixed_to_float(uint64_t v) { return static_cast<double>(static_cast<long long>(v)) / static_cast<double>(TM_FIXED_EXPONENT_VALUE); }
+
+int tm_energy_overflowed(const tm_int128 *u) {
+    const i128 v = *reinterpret_cast<const i128 *>(u);
+    return (v >= static_cast<i128>(LLONG_MAX) || v <= static_cast<i128>(LLONG_MIN)) ? 1 : 0;
+}
+
+double tm_energy_to_float(const tm_int128 *u) {
+    if (tm_energy_overflowed(u))
+        return std::numeric_limits<double>::quiet_NaN();
+    const i128 v = *reinterpret_cast<const i128 *>(u);
+    return static_cast<double>(static_cast<long long>(v)) / static_cast<double>(TM_FIXED_EXPONENT_VALUE);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_harmonic_bond_create(int precision, const int32_t *idxs, int n, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 2);
+    *out = new tm_potential_s{make_by_precision<HarmonicBond>(precision, v)};
+    TM_CATCH
+}
+
+int tm_harmonic_angle_create(int precision, const int32_t *idxs, int n, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 3);
+    *out = new tm_potential_s{make_by_precision<HarmonicAngle>(precision, v)};
+    TM_CATCH
+}
+
+int tm_periodic_torsion_create(int precision, const int32_t *idxs, int n, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 4);
+    *out = new tm_potential_s{make_by_precision<PeriodicTorsion>(precision, v)};
+    TM_CATCH
+}
+
+int tm_nonbonded_all_pairs_create(
+    int precision, int num_atoms, double beta, double cutoff, const int32_t *atom_idxs, int num_atom_idxs, int disable_hilbert_sort,
+    double nblist_padding, tm_potential_t *out) {
+    TM_TRY
+    std::optional<std::vector<int>> idxs;
+    if (atom_idxs != nullptr) {
+        idxs.emplace(atom_idxs, atom_idxs + num_atom_idxs);
+    }
+    *out = new tm_potential_s{make_by_precision<NonbondedAllPairs>(precision, num_atoms, beta, cutoff, idxs, disable_hilbert_sort != 0, nblist_padding)};
+    TM_CATCH
+}
+
+int tm_nonbonded_pair_list_create(
+    int precision, int negated, const int32_t *pair_idxs, int num_pairs, const double *scales, int num_scales, double beta, double cutoff,
+    tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> p(pair_idxs, pair_idxs + static_cast<size_t>(num_pairs) * 2);
+    std::vector<double> s(scales, scales + static_cast<size_t>(num_scales) * 2);
+    std::shared_ptr<Potential> pot;
+    if (precision == TM_F32) {
+        if (negated)
+            pot = std::make_shared<NonbondedPairList<float, true>>(p, s, beta, cutoff);
+        else
+            pot = std::make_shared<NonbondedPairList<float, false>>(p, s, beta, cutoff);
+    } else if (precision == TM_F64) {
+        if (negated)
+            pot = std::make_shared<NonbondedPairList<double, true>>(p, s, beta, cutoff);
+        else
+            pot = std::make_shared<NonbondedPairList<double, false>>(p, s, beta, cutoff);
+    } else {
+        throw std::runtime_error("invalid precision");
+    }
+    *out = new tm_potential_s{pot};
+    TM_CATCH
+}
+
+int tm_summed_potential_create(
+    const tm_potential_t *potentials, int n, const int32_t *params_sizes, int n_sizes, int parallel, tm_potential_t *out) {
+    TM_TRY
+    std::vector<std::shared_ptr<Potential>> pots;
+    for (int i = 0; i < n; i++)
+        pots.push_back(potentials[i]->p);
+    std::vector<int> sizes(params_sizes, params_sizes + n_sizes);
+    *out = new tm_potential_s{std::make_shared<SummedPotential>(pots, sizes, parallel != 0)};
+    TM_CATCH
+}
+
+int tm_fanout_summed_potential_create(const tm_potential_t *potentials, int n, int parallel, tm_potential_t *out) {
+    TM_TRY
+    std::vector<std::shared_ptr<Potential>> pots;
+    for (int i = 0; i < n; i++)
+        pots.push_back(potentials[i]->p);
+    *out = new tm_potential_s{std::make_shared<FanoutSummedPotential>(pots, parallel != 0)};
+    TM_CATCH
+}
+
+int tm_potential_destroy(tm_potential_t pot) {
+    TM_TRY
+    delete pot;
+    TM_CATCH
+}
+
+int tm_potential_get_children(tm_potential_t pot, tm_potential_t *out, int cap, int *count) {
+    TM_TRY
+    const std::vector<std::shared_ptr<Potential>> *kids = nullptr;
+    if (auto s = std::dynamic_pointer_cast<SummedPotential>(pot->p))
+        kids = &s->get_potentials();
+    else if (auto f = std::dynamic_pointer_cast<FanoutSummedPotential>(pot->p))
+        kids = &f->get_potentials();
+    else
+        throw std::runtime_error("potential has no children");
+    *count = kids->size();
+    for (int i = 0; i < cap && i < static_cast<int>(kids->size()); i++)
+        out[i] = new tm_potential_s{(*kids)[i]};
+    TM_CATCH
+}
+
+int tm_nonbonded_all_pairs_set_atom_idxs(tm_potential_t pot, const int32_t *atom_idxs, int n) {
+    TM_TRY
+    std::vector<int> v(atom_idxs, atom_idxs + n);
+    with_all_pairs(pot, [&](auto &p) { p.set_atom_idxs(v); });
+    TM_CATCH
+}
+
+int tm_nonbonded_all_pairs_get_num_atom_idxs(tm_potential_t pot, int *count) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { *count = p.get_num_atom_idxs(); });
+    TM_CATCH
+}
+
+int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int cap) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) {
+        std::vector<int> v = p.get_atom_idxs();
+        for (int i = 0; i < cap && i < static_cast<int>(v.size()); i++)
+            out[i] = v[i];
+    });
+    TM_CATCH
+}
+
+int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { *count = p.num_tile_ixns(); });
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_potential_execute(
+    tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, uint64_t *du_dx, uint64_t *du_dp,
+    tm_int128 *u) {
+    TM_TRY
+    pot->p->execute_host(N, P, coords, params, box, reinterpret_cast<u64 *>(du_dx), reinterpret_cast<u64 *>(du_dp), as_i128(u));
+    TM_CATCH
+}
+
+int tm_potential_execute_batch(
+    tm_potential_t pot, int C, int N, int Pb, int P, const double *coords, const double *params, const double *boxes, uint64_t *du_dx,
+    uint64_t *du_dp, tm_int128 *u) {
+    TM_TRY
+    pot->p->execute_batch_host(C, N, Pb, P, coords, params, boxes, reinterpret_cast<u64 *>(du_dx), reinterpret_cast<u64 *>(du_dp), as_i128(u));
+    TM_CATCH
+}
+
+int tm_potential_execute_batch_sparse(
+    tm_potential_t pot, int coords_size, int N, int params_size, int P, int batch_size, const uint32_t *cidx, const uint32_t *pidx,
+    const double *coords, const double *params, const double *boxes, uint64_t *du_dx, uint64_t *du_dp, tm_int128 *u) {
+    TM_TRY
+    for (int i = 0; i < batch_size; i++) {
+        require(cidx[i] < static_cast<uint32_t>(coords_size), "coords_batch_idxs contains an index that is out of bounds");
+        require(pidx[i] < static_cast<uint32_t>(params_size), "params_batch_idxs contains an index that is out of bounds");
+    }
+    pot->p->execute_batch_sparse_host(
+        coords_size, N, params_size, P, batch_size, cidx, pidx, coords, params, boxes, reinterpret_cast<u64 *>(du_dx),
+        reinterpret_cast<u64 *>(du_dp), as_i128(u));
+    TM_CATCH
+}
+
+int tm_potential_du_dp_fixed_to_float(tm_potential_t pot, int N, int P, const uint64_t *du_dp, double *out) {
+    TM_TRY
+    pot->p->du_dp_fixed_to_float(N, P, reinterpret_cast<const u64 *>(du_dp), out);
+    TM_CATCH
+}
+
+int tm_potential_execute_device(
+    tm_potential_t pot, int N, int P, const double *d_x, const double *d_p, const double *d_box, uint64_t *d_du_dx, uint64_t *d_du_dp,
+    tm_int128 *d_u, void *hip_stream) {
+    TM_TRY
+    pot->p->execute_device(
+        N, P, d_x, d_p, d_box, reinterpret_cast<u64 *>(d_du_dx), reinterpret_cast<u64 *>(d_du_dp), as_i128(d_u),
+        static_cast<hipStream_t>(hip_stream));
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_bound_potential_create(tm_potential_t pot, const double *params, int P, tm_bound_potential_t *out) {
+    TM_TRY
+    std::vector<double> v(params, params + P);
+    *out = new tm_bound_potential_s{std::make_shared<BoundPotential>(pot->p, v)};
+    TM_CATCH
+}
+
+int tm_bound_potential_destroy(tm_bound_potential_t bp) {
+    TM_TRY
+    delete bp;
+    TM_CATCH
+}
+
+int tm_bound_potential_set_params(tm_bound_potential_t bp, const double *params, int P) {
+    TM_TRY
+    std::vector<double> v(params, params + P);
+    bp->p->set_params(v);
+    TM_CATCH
+}
+
+int tm_bound_potential_size(tm_bound_potential_t bp, int *size) {
+    TM_TRY
+    *size = bp->p->size;
+    TM_CATCH
+}
+
+int tm_bound_potential_get_potential(tm_bound_potential_t bp, tm_potential_t *out) {
+    TM_TRY
+    *out = new tm_potential_s{bp->p->potential};
+    TM_CATCH
+}
+
+int tm_bound_potential_execute(tm_bound_potential_t bp, int N, const double *coords, const double *box, uint64_t *du_dx, tm_int128 *u) {
+    TM_TRY
+    bp->p->execute_host(N, coords, box, reinterpret_cast<u64 *>(du_dx), as_i128(u));
+    TM_CATCH
+}
+
+int tm_bound_potential_execute_batch(
+    tm_bound_potential_t bp, int C, int N, const double *coords, const double *boxes, uint64_t *du_dx, tm_int128 *u) {
+    TM_TRY
+    bp->p->execute_batch_host(C, N, coords, boxes, reinterpret_cast<u64 *>(du_dx), as_i128(u));
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_langevin_integrator_create(
+    const double *masses, int N, double temperature, double dt, double friction, int seed, tm_integrator_t *out) {
+    TM_TRY
+    *out = new tm_integrator_s{std::make_shared<LangevinIntegrator<float>>(N, masses, temperature, dt, friction, seed)};
+    TM_CATCH
+}
+
+int tm_integrator_destroy(tm_integrator_t intg) {
+    TM_TRY
+    delete intg;
+    TM_CATCH
+}
+
+int tm_context_create(
+    const double *x0, const double *v0, const double *box, int N, tm_integrator_t intg, const tm_bound_potential_t *bps, int num_bps,
+    tm_context_t *out) {
+    TM_TRY
+    std::vector<std::shared_ptr<BoundPotential>> v;
+    for (int i = 0; i < num_bps; i++)
+        v.push_back(bps[i]->p);
+    std::vector<std::shared_ptr<Mover>> movers;
+    *out = new tm_context_s{std::make_unique<Context>(N, x0, v0, box, intg->p, v, movers)};
+    TM_CATCH
+}
+
+int tm_context_destroy(tm_context_t ctxt) {
+    TM_TRY
+    delete ctxt;
+    TM_CATCH
+}
+
+int tm_context_num_atoms(tm_context_t ctxt, int *N) {
+    TM_TRY
+    *N = ctxt->p->num_atoms();
+    TM_CATCH
+}
+
+int tm_context_step(tm_context_t ctxt) {
+    TM_TRY
+    ctxt->p->step();
+    TM_CATCH
+}
+int tm_context_initialize(tm_context_t ctxt) {
+    TM_TRY
+    ctxt->p->initialize();
+    TM_CATCH
+}
+int tm_context_finalize(tm_context_t ctxt) {
+    TM_TRY
+    ctxt->p->finalize();
+    TM_CATCH
+}
+int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, double *xs, double *boxes) {
+    TM_TRY
+    ctxt->p->multiple_steps(n_steps, n_samples, xs, boxes);
+    TM_CATCH
+}
+int tm_context_get_x_t(tm_context_t ctxt, double *out) {
+    TM_TRY
+    ctxt->p->get_x_t(out);
+    TM_CATCH
+}
+int tm_context_get_v_t(tm_context_t ctxt, double *out) {
+    TM_TRY
+    ctxt->p->get_v_t(out);
+    TM_CATCH
+}
+int tm_context_get_box(tm_context_t ctxt, double *out) {
+    TM_TRY
+    ctxt->p->get_box(out);
+    TM_CATCH
+}
+int tm_context_set_x_t(tm_context_t ctxt, const double *in) {
+    TM_TRY
+    ctxt->p->set_x_t(in);
+    TM_CATCH
+}
+int tm_context_set_v_t(tm_context_t ctxt, const double *in) {
+    TM_TRY
+    ctxt->p->set_v_t(in);
+    TM_CATCH
+}
+int tm_context_set_box(tm_context_t ctxt, const double *in) {
+    TM_TRY
+    ctxt->p->set_box(in);
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+#define NB_DISPATCH(nb, expr)                                                                                          \
+    do {                                                                                                               \
+        if ((nb)->precision == TM_F32) {                                                                               \
+            auto &L = *(nb)->f32;                                                                                      \
+            expr;                                                                                                      \
+        } else {                                                                                                       \
+            auto &L = *(nb)->f64;                                                                                      \
+            expr;                                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+int tm_neighborlist_create(int precision, int N, tm_neighborlist_t *out) {
+    TM_TRY
+    std::unique_ptr<tm_neighborlist_s> h(new tm_neighborlist_s());
+    h->precision = precision;
+    if (precision == TM_F32)
+        h->f32.reset(new Neighborlist<float>(N));
+    else if (precision == TM_F64)
+        h->f64.reset(new Neighborlist<double>(N));
+    else
+        throw std::runtime_error("invalid precision");
+    *out = h.release();
+    TM_CATCH
+}
+
+int tm_neighborlist_destroy(tm_neighborlist_t nb) {
+    TM_TRY
+    delete nb;
+    TM_CATCH
+}
+
+int tm_neighborlist_get_nblist(
+    tm_neighborlist_t nb, int N, const double *coords, const double *box, double cutoff, int *num_row_blocks, int *total_atoms) {
+    TM_TRY
+    NB_DISPATCH(nb, nb->last = L.get_nblist_host(N, coords, box, cutoff));
+    *num_row_blocks = nb->last.size();
+    int total = 0;
+    for (auto &l : nb->last)
+        total += l.size();
+    *total_atoms = total;
+    TM_CATCH
+}
+
+int tm_neighborlist_copy_nblist(tm_neighborlist_t nb, int32_t *offsets, int32_t *atoms) {
+    TM_TRY
+    int off = 0;
+    for (size_t r = 0; r < nb->last.size(); r++) {
+        offsets[r] = off;
+        for (int a : nb->last[r])
+            atoms[off++] = a;
+    }
+    offsets[nb->last.size()] = off;
+    TM_CATCH
+}
+
+int tm_neighborlist_compute_block_bounds(
+    tm_neighborlist_t nb, int N, const double *coords, const double *box, int block_size, double *ctrs, double *exts) {
+    TM_TRY
+    require(block_size == 32, "Block size must be 32.");
+    NB_DISPATCH(nb, L.compute_block_bounds_host(N, coords, box, ctrs, exts));
+    TM_CATCH
+}
+
+int tm_neighborlist_set_row_idxs(tm_neighborlist_t nb, const uint32_t *idxs, int count) {
+    TM_TRY
+    std::vector<unsigned int> v(idxs, idxs + count);
+    NB_DISPATCH(nb, L.set_row_idxs(v));
+    TM_CATCH
+}
+int tm_neighborlist_reset_row_idxs(tm_neighborlist_t nb) {
+    TM_TRY
+    NB_DISPATCH(nb, L.reset_row_idxs());
+    TM_CATCH
+}
+int tm_neighborlist_resize(tm_neighborlist_t nb, int size) {
+    TM_TRY
+    NB_DISPATCH(nb, L.resize(size));
+    TM_CATCH
+}
+int tm_neighborlist_get_tile_ixn_count(tm_neighborlist_t nb, unsigned int *count) {
+    TM_TRY
+    NB_DISPATCH(nb, *count = L.num_tile_ixns());
+    TM_CATCH
+}
+int tm_neighborlist_get_max_ixn_count(tm_neighborlist_t nb, int *count) {
+    TM_TRY
+    NB_DISPATCH(nb, *count = L.max_ixn_count());
+    TM_CATCH
+}
+int tm_neighborlist_get_num_row_idxs(tm_neighborlist_t nb, int *count) {
+    TM_TRY
+    NB_DISPATCH(nb, *count = L.get_num_row_idxs());
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_hilbert_sort_create(int size, tm_hilbert_sort_t *out) {
+    TM_TRY
+    *out = new tm_hilbert_sort_s{std::make_unique<HilbertSort>(size)};
+    TM_CATCH
+}
+int tm_hilbert_sort_destroy(tm_hilbert_sort_t hs) {
+    TM_TRY
+    delete hs;
+    TM_CATCH
+}
+int tm_hilbert_sort_sort(tm_hilbert_sort_t hs, int N, const double *coords, const double *box, uint32_t *perm) {
+    TM_TRY
+    std::vector<unsigned int> p = hs->p->sort_host(N, coords, box);
+    for (int i = 0; i < N; i++)
+        perm[i] = p[i];
+    TM_CATCH
+}
+int tm_hilbert_lut(uint32_t *out) {
+    TM_TRY
+    const std::vector<unsigned int> &t = HilbertSort::lut();
+    for (size_t i = 0; i < t.size(); i++)
+        out[i] = t[i];
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int tm_profile_set_enabled(int enabled) {
+    TM_TRY
+    Profiler::get().set_enabled(enabled != 0);
+    TM_CATCH
+}
+int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches) {
+    TM_TRY
+    Profiler::get().read(kernel_name, total_ms, launches);
+    TM_CATCH
+}
+int tm_profile_reset(void) {
+    TM_TRY
+    Profiler::get().reset();
+    TM_CATCH
+}
+
+} // extern "C"

@@ -1,0 +1,361 @@
+// Host-side object model of the hot path.  Mirrors the class surface the reference binds in
+// cpp/src/wrap_kernels.cpp (Potential / BoundPotential / Summed / Fanout / NonbondedAllPairs / NonbondedPairList /
+// HarmonicBond / HarmonicAngle / PeriodicTorsion / Neighborlist / HilbertSort / LangevinIntegrator / Context) so the
+// C ABI in include/timemachine_amd.h is a 1:1 door onto it.  Everything device-side is HIP for gfx950.
+#pragma once
+#include "common.hpp"
+
+#include <memory>
+#include <optional>
+
+namespace tmamd {
+
+// Sums n signed 128-bit values on `stream` into *d_out (overwrites).  Integer => order independent.
+void reduce_i128_device(const i128 *d_in, int n, i128 *d_out, hipStream_t stream);
+
+int device_cu_count();
+
+// ------------------------------------------------------------------------------------------------------------
+// reference: cpp/src/potential.hpp:7-96, cpp/src/potential.cu
+class Potential {
+public:
+    virtual ~Potential() {}
+    static const int D = 3;
+
+    // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
+    virtual void execute_device(
+        const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp,
+        i128 *d_u, hipStream_t stream) = 0;
+
+    virtual void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float);
+
+    void execute_host(
+        const int N, const int P, const double *h_x, const double *h_p, const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u);
+
+    void execute_batch_host(
+        const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *h_x, const double *h_p,
+        const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u);
+
+    void execute_batch_sparse_host(
+        const int coords_size, const int N, const int params_size, const int P, const int batch_size,
+        const unsigned int *coords_batch_idxs, const unsigned int *params_batch_idxs, const double *h_x, const double *h_p,
+        const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u);
+
+    void execute_batch_device(
+        const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *d_x, const double *d_p,
+        const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream);
+
+    void execute_batch_sparse_device(
+        const int N, const int P, const int batch_size, const unsigned int *coords_batch_idxs,
+        const unsigned int *params_batch_idxs, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx,
+        u64 *d_du_dp, i128 *d_u, hipStream_t stream);
+
+private:
+    // grow-only scratch for the host entry points (the reference mallocs and frees on every call)
+    DeviceBuffer<double> hs_x_, hs_p_, hs_box_;
+    DeviceBuffer<u64> hs_du_dx_, hs_du_dp_;
+    DeviceBuffer<i128> hs_u_;
+};
+
+// reference: cpp/src/bound_potential.{hpp,cu}
+class BoundPotential {
+public:
+    BoundPotential(std::shared_ptr<Potential> potential, const std::vector<double> &params);
+    int size;
+    DeviceBuffer<double> d_p;
+    std::shared_ptr<Potential> potential;
+
+    void set_params(const std::vector<double> &params);
+    void set_params_device(const int size, const double *d_p, hipStream_t stream);
+    void execute_device(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream);
+    void execute_host(const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
+    void execute_batch_host(const int coord_batch_size, const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
+
+private:
+    DeviceBuffer<double> hs_x_, hs_box_;
+    DeviceBuffer<u64> hs_du_dx_;
+    DeviceBuffer<i128> hs_u_;
+};
+
+// Lazily created side streams + events for running children concurrently (reference: stream_manager.cu:18-56).
+class StreamFork {
+public:
+    ~StreamFork();
+    hipStream_t stream(int i);
+    void fork_from(int i, hipStream_t parent); // side stream i waits for everything queued on parent
+    void join_to(int i, hipStream_t parent);   // parent waits for side stream i
+private:
+    std::vector<hipStream_t> streams_;
+    std::vector<hipEvent_t> events_;
+    void ensure(int i);
+};
+
+// reference: cpp/src/summed_potential.cu:33-97
+class SummedPotential : public Potential {
+public:
+    SummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel);
+    const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
+    const std::vector<int> &get_parameter_sizes() { return params_sizes_; }
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+    void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+
+private:
+    std::vector<std::shared_ptr<Potential>> potentials_;
+    std::vector<int> params_sizes_;
+    int P_;
+    bool parallel_;
+    DeviceBuffer<i128> d_u_buffer_;
+    StreamFork fork_;
+};
+
+// reference: cpp/src/fanout_summed_potential.cu:23-68
+class FanoutSummedPotential : public Potential {
+public:
+    FanoutSummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const bool parallel);
+    const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+    void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+
+private:
+    std::vector<std::shared_ptr<Potential>> potentials_;
+    bool parallel_;
+    DeviceBuffer<i128> d_u_buffer_;
+    StreamFork fork_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Bonded terms.  kind: 0 = HarmonicBond (2 idx, 2 params), 1 = HarmonicAngle (3, 3), 2 = PeriodicTorsion (4, 3)
+// reference: cpp/src/harmonic_bond.cu, harmonic_angle.cu, periodic_torsion.cu
+template <typename Real> class HarmonicBond : public Potential {
+public:
+    explicit HarmonicBond(const std::vector<int> &bond_idxs);
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int B_;
+    DeviceBuffer<int> d_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+};
+
+template <typename Real> class HarmonicAngle : public Potential {
+public:
+    explicit HarmonicAngle(const std::vector<int> &angle_idxs);
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int A_;
+    DeviceBuffer<int> d_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+};
+
+template <typename Real> class PeriodicTorsion : public Potential {
+public:
+    explicit PeriodicTorsion(const std::vector<int> &torsion_idxs);
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int T_;
+    DeviceBuffer<int> d_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// reference: cpp/src/hilbert_sort.{hpp,cu}
+class HilbertSort {
+public:
+    explicit HilbertSort(const int N);
+    ~HilbertSort();
+    void sort_device(const int N, const unsigned int *d_atom_idxs, const double *d_coords, const double *d_box, unsigned int *d_output_perm, hipStream_t stream);
+    std::vector<unsigned int> sort_host(const int N, const double *h_coords, const double *h_box);
+    static const std::vector<unsigned int> &lut(); // bin (i,j,k) -> Hilbert index, 128^3 entries
+private:
+    int N_;
+    DeviceBuffer<unsigned int> d_bin_to_idx_, d_keys_in_, d_keys_out_, d_vals_in_;
+    void *d_sort_storage_;
+    size_t sort_storage_bytes_;
+};
+
+// reference: cpp/src/neighborlist.{hpp,cu}
+template <typename Real> class Neighborlist {
+public:
+    explicit Neighborlist(const int N);
+    ~Neighborlist() {}
+
+    void set_row_idxs(std::vector<unsigned int> idxs);
+    void reset_row_idxs();
+    void resize(const int size);
+    void set_idxs_device(const int NC, const int NR, const unsigned int *d_col_idxs, const unsigned int *d_row_idxs, hipStream_t stream);
+
+    unsigned int num_tile_ixns();
+    std::vector<std::vector<int>> get_nblist_host(const int N, const double *h_coords, const double *h_box, const double cutoff);
+    void compute_block_bounds_host(const int N, const double *h_coords, const double *h_box, double *h_bb_ctrs, double *h_bb_exts);
+
+    // `d_gathered` holds Real[K][8] records (x, y, z, ...).  If d_flag != nullptr the kernels return immediately
+    // unless force != 0 or *d_flag != 0 (device-side rebuild decision: no host synchronisation).
+    // When d_snap_x != nullptr the n_snap doubles of d_x (and the box) are copied into the snapshot as part of the build.
+    void build_device(
+        const Real *d_gathered, const double *d_box, const double cutoff, const int *d_flag, const int force, const int n_snap,
+        const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream);
+
+    int get_num_row_idxs() const { return NR_; }
+    int num_row_blocks() const { return ceil_divide(NR_, TILE); }
+    int num_column_blocks() const { return ceil_divide(NC_, TILE); }
+    int max_ixn_count() const;
+    bool upper_triangular() const { return NR_ == N_ && NC_ == N_; }
+    int num_atoms() const { return N_; }
+
+    const unsigned int *row_idxs_or_null() const { return upper_triangular() ? nullptr : d_row_idxs_.data; }
+    const unsigned int *d_counters() const { return d_counters_.data; }
+    const int4 *d_items() const { return d_items_.data; }
+    const unsigned int *d_col_atoms() const { return d_col_atoms_.data; }
+
+private:
+    const int max_size_;
+    int N_, NC_, NR_;
+    DeviceBuffer<Real> d_col_ctr_, d_col_ext_, d_row_ctr_, d_row_ext_;
+    DeviceBuffer<unsigned int> d_row_idxs_, d_col_idxs_;
+    DeviceBuffer<unsigned int> d_counters_;  // [0] pool cursor, [1] work items, [2] 32-wide tile count
+    DeviceBuffer<unsigned int> d_col_atoms_; // CSR pool
+    DeviceBuffer<int4> d_items_;
+    DeviceBuffer<int2> d_row_segments_;
+    DeviceBuffer<Real> d_scratch_gathered_; // host entry points only
+    void gather_host_coords(const int N, const double *h_coords, const double *h_box, DeviceBuffer<double> &d_box);
+};
+
+void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
+
+// reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
+class NonbondedAllPairsBase : public Potential {
+public:
+    virtual double get_cutoff() const = 0;
+    virtual double get_nblist_padding() const = 0;
+};
+
+template <typename Real> class NonbondedAllPairs : public NonbondedAllPairsBase {
+public:
+    NonbondedAllPairs(const int N, const double beta, const double cutoff, const std::optional<std::vector<int>> &atom_idxs, const bool disable_hilbert_sort, const double nblist_padding);
+    ~NonbondedAllPairs() {}
+
+    void set_atom_idxs(const std::vector<int> &atom_idxs);
+    std::vector<int> get_atom_idxs();
+    int get_num_atom_idxs() const { return K_; }
+    double get_cutoff() const override { return cutoff_; }
+    double get_nblist_padding() const override { return nblist_padding_; }
+    unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
+
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+    void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+
+private:
+    const int N_;
+    int K_;
+    const double beta_, cutoff_, nblist_padding_;
+    const bool disable_hilbert_;
+    int calls_since_sort_;
+    int parity_;
+    bool force_rebuild_;
+    int grid_;
+    Neighborlist<Real> nblist_;
+    std::unique_ptr<HilbertSort> hilbert_;
+    DeviceBuffer<unsigned int> d_atom_idxs_, d_perm_;
+    DeviceBuffer<Real> d_gathered_;
+    DeviceBuffer<u64> d_g_du_dx_, d_g_du_dp_;
+    DeviceBuffer<double> d_snap_x_, d_snap_box_;
+    DeviceBuffer<int> d_flags_;
+    DeviceBuffer<i128> d_u_partials_;
+};
+
+void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);
+
+// reference: cpp/src/nonbonded_pair_list.{hpp,cu}; Negated == true is bound as NonbondedExclusions_*
+template <typename Real, bool Negated> class NonbondedPairList : public Potential {
+public:
+    NonbondedPairList(const std::vector<int> &pair_idxs, const std::vector<double> &scales, const double beta, const double cutoff);
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+    void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+private:
+    int M_;
+    double beta_, cutoff_;
+    DeviceBuffer<int> d_pair_idxs_;
+    DeviceBuffer<double> d_scales_;
+    DeviceBuffer<i128> d_u_partials_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// reference: cpp/src/integrator.hpp, cpp/src/langevin_integrator.{hpp,cu}
+class Integrator {
+public:
+    virtual ~Integrator() {}
+    virtual void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
+    virtual void initialize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
+    virtual void finalize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
+};
+
+template <typename Real> class LangevinIntegrator : public Integrator {
+public:
+    LangevinIntegrator(const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed);
+    double get_temperature() const { return temperature_; }
+    void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
+    void initialize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
+    void finalize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
+private:
+    const int N_;
+    const double temperature_;
+    const Real dt_;
+    const double friction_;
+    Real ca_;
+    unsigned long long seed_;
+    unsigned long long step_;
+    DeviceBuffer<Real> d_cbs_, d_ccs_;
+    DeviceBuffer<u64> d_du_dx_;
+};
+
+// reference: cpp/src/mover.hpp (interface only; no movers are implemented on this path yet)
+class Mover {
+public:
+    virtual ~Mover() {}
+    virtual void move(const int N, double *d_x, double *d_box, hipStream_t stream) = 0;
+    void set_interval(const int interval) { interval_ = interval; step_ = 0; }
+    int get_interval() const { return interval_; }
+    void set_step(const int step) { step_ = step; }
+protected:
+    int interval_ = 1;
+    int step_ = 0;
+};
+
+// reference: cpp/src/context.{hpp,cu}
+class Context {
+public:
+    Context(int N, const double *x_0, const double *v_0, const double *box_0, std::shared_ptr<Integrator> intg, std::vector<std::shared_ptr<BoundPotential>> &bps, std::vector<std::shared_ptr<Mover>> &movers);
+    ~Context();
+
+    void step();
+    void initialize();
+    void finalize();
+    void multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box);
+    int num_atoms() const { return N_; }
+    void set_x_t(const double *in);
+    void set_v_t(const double *in);
+    void set_box(const double *in);
+    void get_x_t(double *out) const;
+    void get_v_t(double *out) const;
+    void get_box(double *out) const;
+    std::shared_ptr<Integrator> get_integrator() const { return intg_; }
+    std::vector<std::shared_ptr<BoundPotential>> get_potentials() const { return bps_; }
+    std::vector<std::shared_ptr<Mover>> get_movers() const { return movers_; }
+    hipStream_t stream() const { return stream_; }
+
+private:
+    int N_;
+    std::vector<std::shared_ptr<Mover>> movers_;
+    int step_;
+    DeviceBuffer<double> d_x_t_, d_v_t_, d_box_t_;
+    std::shared_ptr<Integrator> intg_;
+    std::vector<std::shared_ptr<BoundPotential>> bps_;
+    std::vector<double> nb_cutoffs_with_padding_;
+    hipStream_t stream_;
+    void _step(hipStream_t stream);
+    void _verify_coords_and_box(const double *coords, const double *box, hipStream_t stream);
+};
+
+// recursive search used by Context for the box-size check (reference: cpp/src/nonbonded_common.cpp:77-124)
+void collect_nonbonded_cutoffs(const std::shared_ptr<Potential> &pot, std::vector<double> &out);
+
+} // namespace tmamd

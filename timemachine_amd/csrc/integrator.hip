@@ -1,0 +1,226 @@
+// LangevinIntegrator (BAOAB) and the MD Context loop for gfx950.
+// reference: cpp/src/langevin_integrator.cu:14-88, cpp/src/kernels/k_integrator.cuh:5-62, cpp/src/context.cu:28-303,
+//            timemachine/integrator.py:124-150 (python reference of the same step)
+//
+// Differences on purpose:
+//  * noise is generated INSIDE the update kernel with a counter-based Philox4x32-10 keyed on (seed; atom, step):
+//    no noise buffer, no separate RNG launch, no 12 B/atom/step of HBM traffic.  cuRAND's XORWOW stream cannot be
+//    reproduced by any independent implementation, so trajectories are comparable exactly at friction == 0
+//    (ccs == 0) and statistically otherwise -- same contract as the reference's own tests (tests/test_md.py:142-247).
+//  * BOLTZ is the C++ value (cpp/src/constants.hpp:5), not the python one (timemachine/constants.py:5-8).
+#include "engine.hpp"
+#include "fixed_point.cuh"
+
+#include <algorithm>
+#include <cmath>
+#include <iostream>
+
+namespace tmamd {
+
+static const double BOLTZ = 0.008314462618; // kJ/mol/K, cpp/src/constants.hpp:5
+
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0, unsigned int k1, unsigned int out[4]) {
+    const unsigned int M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = static_cast<unsigned long long>(M0) * c0;
+        const unsigned long long p1 = static_cast<unsigned long long>(M1) * c2;
+        const unsigned int n0 = static_cast<unsigned int>(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = static_cast<unsigned int>(p1);
+        const unsigned int n2 = static_cast<unsigned int>(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = static_cast<unsigned int>(p0);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += W0;
+        k1 += W1;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+// three N(0,1) variates for (atom, step) by Box-Muller on Philox output
+__device__ __forceinline__ void normal3(unsigned long long seed, unsigned long long step, unsigned int atom, float n[3]) {
+    unsigned int r[4];
+    philox4x32_10(atom, static_cast<unsigned int>(step), static_cast<unsigned int>(step >> 32), 0x54494d45u,
+                  static_cast<unsigned int>(seed), static_cast<unsigned int>(seed >> 32), r);
+    const float two_pow_m32 = 2.3283064365386963e-10f;
+    const float u0 = (static_cast<float>(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0,1), never 0
+    const float u1 = static_cast<float>(r[1]) * two_pow_m32;
+    const float u2 = (static_cast<float>(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = static_cast<float>(r[3]) * two_pow_m32;
+    const float two_pi = 6.2831853071795864769f;
+    const float ra = sqrtf(-2.0f * logf(u0));
+    const float rb = sqrtf(-2.0f * logf(u2));
+    float s, c;
+    sincosf(two_pi * u1, &s, &c);
+    n[0] = ra * c;
+    n[1] = ra * s;
+    n[2] = rb * cosf(two_pi * u3);
+}
+
+// reference: k_update_forward_baoab (k_integrator.cuh:5-62).  x, v stored f64; arithmetic in Real with the same
+// promotion points: v_mid = Real(v + cb*F); v' = ca*v_mid + cc*noise (Real); x += Real(0.5*dt) * (v_mid + v') in f64.
+template <typename Real>
+__global__ __launch_bounds__(256) void k_update_forward_baoab(
+    const int N, const Real ca, const unsigned int *__restrict__ idxs, const Real *__restrict__ cbs, const Real *__restrict__ ccs,
+    const unsigned long long seed, const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t,
+    u64 *__restrict__ du_dx, const Real dt) {
+    for (int kidx = blockIdx.x * blockDim.x + threadIdx.x; kidx < N; kidx += gridDim.x * blockDim.x) {
+        const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
+        if (atom < N) {
+            const Real cb = cbs[atom];
+            const Real cc = ccs[atom];
+            float nz[3] = {0.f, 0.f, 0.f};
+            if (cc != 0) {
+                normal3(seed, step, static_cast<unsigned int>(atom), nz);
+            }
+            const Real half_dt = static_cast<Real>(0.5) * dt;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const Real force = -fixed_to_float<Real>(du_dx[atom * 3 + d]);
+                const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
+                const Real v_new = ca * v_mid + cc * static_cast<Real>(nz[d]);
+                v_t[atom * 3 + d] = static_cast<double>(v_new);
+                x_t[atom * 3 + d] += static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
+                du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
+            }
+        } else if (idxs != nullptr) {
+            du_dx[kidx * 3 + 0] = 0;
+            du_dx[kidx * 3 + 1] = 0;
+            du_dx[kidx * 3 + 2] = 0;
+        }
+    }
+}
+
+template <typename Real>
+LangevinIntegrator<Real>::LangevinIntegrator(
+    const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed)
+    : N_(N), temperature_(temperature), dt_(static_cast<Real>(dt)), friction_(friction), seed_(static_cast<unsigned long long>(static_cast<long long>(seed))),
+      step_(0), d_cbs_(N), d_ccs_(N), d_du_dx_(static_cast<size_t>(N) * 3) {
+    ca_ = static_cast<Real>(std::exp(-friction * dt));
+    const double kT = BOLTZ * temperature;
+    const double ccs_adjustment = std::sqrt(1 - std::exp(-2 * friction * dt));
+    std::vector<Real> h_cbs(N_), h_ccs(N_);
+    for (int i = 0; i < N_; i++) {
+        h_cbs[i] = static_cast<Real>(dt_ / masses[i]);
+        h_ccs[i] = static_cast<Real>(ccs_adjustment * std::sqrt(kT / masses[i]));
+    }
+    d_cbs_.copy_from(h_cbs.data());
+    d_ccs_.copy_from(h_ccs.data());
+    HIP_CHECK(hipMemset(d_du_dx_.data, 0, d_du_dx_.size()));
+}
+
+template <typename Real>
+void LangevinIntegrator<Real>::step_fwd(
+    std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
+    hipStream_t stream) {
+    for (auto &bp : bps) {
+        bp->execute_device(N_, d_x_t, d_box_t, d_du_dx_.data, nullptr, nullptr, stream); // forces only
+    }
+    const int tpb = 256;
+    k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
+        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_);
+    HIP_CHECK(hipGetLastError());
+    step_++;
+}
+
+template class LangevinIntegrator<float>;
+template class LangevinIntegrator<double>;
+
+// ------------------------------------------------------------------------------------------------------------
+Context::Context(
+    int N, const double *x_0, const double *v_0, const double *box_0, std::shared_ptr<Integrator> intg,
+    std::vector<std::shared_ptr<BoundPotential>> &bps, std::vector<std::shared_ptr<Mover>> &movers)
+    : N_(N), movers_(movers), step_(0), d_x_t_(static_cast<size_t>(N) * 3), d_v_t_(static_cast<size_t>(N) * 3), d_box_t_(9), intg_(intg),
+      bps_(bps), stream_(0) {
+    d_x_t_.copy_from(x_0);
+    d_v_t_.copy_from(v_0);
+    d_box_t_.copy_from(box_0);
+    for (auto &bp : bps_) {
+        collect_nonbonded_cutoffs(bp->potential, nb_cutoffs_with_padding_);
+    }
+}
+
+Context::~Context() {}
+
+void Context::_verify_coords_and_box(const double *coords, const double *box, hipStream_t stream) {
+    // reference: context.cu:52-78 (messages are matched by tests/test_md.py:929,1007)
+    if (nb_cutoffs_with_padding_.empty()) {
+        return;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (double cutoff : nb_cutoffs_with_padding_) {
+        const double db_cutoff = 2 * cutoff;
+        for (int i = 0; i < 3; i++) {
+            if (box[i * 3 + i] < db_cutoff) {
+                throw std::runtime_error("cutoff with padding is more than half of the box width, neighborlist is no longer reliable");
+            }
+        }
+    }
+    const double max_box_dim = std::max(box[0], std::max(box[4], box[8]));
+    const auto mm = std::minmax_element(coords, coords + static_cast<size_t>(N_) * 3);
+    if (max_box_dim * 100.0 < *mm.second - *mm.first) {
+        throw std::runtime_error("simulation unstable: dimensions of coordinates two orders of magnitude larger than max box dimension");
+    }
+}
+
+void Context::_step(hipStream_t stream) {
+    intg_->step_fwd(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
+    for (auto &mover : movers_) {
+        mover->move(N_, d_x_t_.data, d_box_t_.data, stream);
+    }
+    step_ += 1;
+}
+
+void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box) {
+    if (n_samples < 0) {
+        throw std::runtime_error("n_samples < 0");
+    }
+    const int store_x_interval = n_samples > 0 ? n_steps / n_samples : n_steps + 1;
+    if (n_steps % store_x_interval != 0) {
+        std::cout << "warning:: n_steps modulo store_x_interval does not equal zero" << std::endl;
+    }
+    hipStream_t stream = stream_;
+    intg_->initialize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
+    for (int i = 1; i <= n_steps; i++) {
+        this->_step(stream);
+        if (i % store_x_interval == 0) {
+            double *box_ptr = h_box + static_cast<size_t>(i / store_x_interval - 1) * 9;
+            double *coord_ptr = h_x + static_cast<size_t>(i / store_x_interval - 1) * N_ * 3;
+            HIP_CHECK(hipMemcpyAsync(coord_ptr, d_x_t_.data, static_cast<size_t>(N_) * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(box_ptr, d_box_t_.data, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            this->_verify_coords_and_box(coord_ptr, box_ptr, stream);
+        }
+    }
+    intg_->finalize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void Context::step() {
+    this->_step(stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Context::initialize() {
+    intg_->initialize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Context::finalize() {
+    intg_->finalize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream_);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Context::set_x_t(const double *in) { d_x_t_.copy_from(in); }
+void Context::set_v_t(const double *in) { d_v_t_.copy_from(in); }
+void Context::set_box(const double *in) { d_box_t_.copy_from(in); }
+void Context::get_x_t(double *out) const { d_x_t_.copy_to(out); }
+void Context::get_v_t(double *out) const { d_v_t_.copy_to(out); }
+void Context::get_box(double *out) const { d_box_t_.copy_to(out); }
+
+} // namespace tmamd

@@ -1,0 +1,155 @@
+// The single per-pair nonbonded device function.  Both the tile kernel (all pairs) and the pair-list kernel
+// (exclusions, subtracted in fixed point) inline THIS function, so a fully excluded pair cancels bit-for-bit
+// (reference: the shared compute_electrostatics / compute_lj of cpp/src/kernels/k_nonbonded_common.cuh:180-246 and
+// the note at k_nonbonded_pair_list.cuh:3-6).  The translation units are compiled with -ffp-contract=off; every
+// fused multiply-add below is explicit, so the instruction sequence cannot differ between call sites.
+//
+// Math (k_nonbonded_common.cuh:16-94,184-246):
+//   inv = rsqrt(d2); d = d2*inv; inv2 = inv*inv
+//   S(d)  = cos^3(pi/2 (d/1.2)^8)           (0 for d >= 1.2; the 1.2 is hard-coded, independent of `cutoff`)
+//   damp  = erfc(beta d) S(d)
+//   es_prefactor = s_q q_i q_j inv [ (erfc S' + (-2 beta/sqrt(pi) e^{-(beta d)^2}) S) inv - damp inv2 ]
+//   u_es  = s_q q_i q_j inv damp
+//   LJ: eps_ij = e_i e_j, sig_ij = s_i + s_j, s6 = (sig_ij inv)^6
+//   lj_prefactor = s_lj eps_ij s6 inv2 (48 s6 - 24);  u_lj = s_lj 4 eps_ij (s6 - 1) s6
+//   prefactor = es_prefactor - lj_prefactor
+#pragma once
+#include "fixed_point.cuh"
+
+namespace tmamd {
+
+#define TM_PI 3.141592653589793115997963468544185161
+#define TM_TWO_OVER_SQRT_PI 1.128379167095512595889238330988549829708
+
+template <typename Real> struct PairOut {
+    Real prefactor; // dU/dr / r : force on i is prefactor * delta
+    Real u;         // pair energy
+    Real inv_dij;
+    Real ebd;       // erfc(beta d) * S(d)
+    Real sig_grad;  // dU/dsig_i (== dU/dsig_j)
+    Real eps_grad;  // dU/deps_i = eps_grad * eps_j ; dU/deps_j = eps_grad * eps_i
+    bool has_lj;
+};
+
+// ---------------- f64 ----------------
+__device__ __forceinline__ double switch_fn_and_deriv(double dij, double &dsdr) {
+    const double cutoff = 1.2;
+    if (dij >= cutoff) {
+        dsdr = 0.0;
+        return 0.0;
+    }
+    const double inv_cutoff = 1.0 / cutoff;
+    const double pi = static_cast<double>(TM_PI);
+    const double k2 = inv_cutoff * inv_cutoff;
+    const double k4 = k2 * k2;
+    const double k8 = k4 * k4;
+    double d2 = dij * dij;
+    double d4 = d2 * d2;
+    double d7 = d4 * d2 * dij;
+    double d8 = d4 * d4;
+    double arg = 0.5 * pi * (d8 * k8);
+    double s, c;
+    sincos(arg, &s, &c);
+    double c2 = c * c;
+    const double minus_12_pi_k8 = -12 * pi * k8;
+    dsdr = d7 * s * c2 * minus_12_pi_k8;
+    return c2 * c;
+}
+
+__device__ __forceinline__ double real_es_factor(double beta, double dij, double inv_dij, double inv_d2ij, double &damping) {
+    double bd = beta * dij;
+    double e = erfc(bd);
+    double dsdr;
+    double sr = switch_fn_and_deriv(dij, dsdr);
+    damping = e * sr;
+    double debd = -static_cast<double>(TM_TWO_OVER_SQRT_PI) * beta * exp(-bd * bd);
+    double damping_prime = (e * dsdr) + (debd * sr);
+    return damping_prime * inv_dij - damping * inv_d2ij;
+}
+
+// ---------------- f32 (what production MD runs; k_nonbonded_common.cuh:98-178) ----------------
+__device__ __forceinline__ float switch_fn_and_deriv(float dij, float &dsdr) {
+    const float cutoff = 1.2f;
+    if (dij >= cutoff) {
+        dsdr = 0.0f;
+        return 0.0f;
+    }
+    const float pi = static_cast<float>(TM_PI);
+    const float inv_cutoff = 1.0f / cutoff;
+    const float k2 = inv_cutoff * inv_cutoff;
+    const float k4 = k2 * k2;
+    const float k8 = k4 * k4;
+    float d2 = dij * dij;
+    float d4 = d2 * d2;
+    float d7 = d4 * d2 * dij;
+    float d8 = d4 * d4;
+    float arg = (0.5f * pi) * (d8 * k8);
+    float s, c;
+    __sincosf(arg, &s, &c);
+    float c2 = c * c;
+    const float minus_12_pi_k8 = -12 * pi * k8;
+    dsdr = minus_12_pi_k8 * d7 * s * c2;
+    return c2 * c;
+}
+
+__device__ __forceinline__ float real_es_factor(float beta, float dij, float inv_dij, float inv_d2ij, float &damping) {
+    float x = beta * dij;
+    float exp_x2 = __expf(-x * x);
+    // Abramowitz & Stegun 7.1.26 (|err| < 1.5e-7), same approximation the reference's f32 path uses
+    float t = 1.0f / (1.0f + 0.3275911f * x);
+    float ebd = (0.254829592f + (-0.284496736f + (1.421413741f + (-1.453152027f + 1.061405429f * t) * t) * t) * t) * t * exp_x2;
+    float debd = beta * (-static_cast<float>(TM_TWO_OVER_SQRT_PI) * exp_x2);
+    float dsdr;
+    float sr = switch_fn_and_deriv(dij, dsdr);
+    damping = ebd * sr;
+    float damping_prime = (ebd * dsdr) + (debd * sr);
+    return damping_prime * inv_dij - damping * inv_d2ij;
+}
+
+__device__ __forceinline__ double tm_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ float tm_rsqrt(float x) { return rsqrtf(x); }
+
+// d2ij must already satisfy d2ij < cutoff^2.
+template <typename Real>
+__device__ __forceinline__ void nb_pair(
+    Real charge_scale, Real lj_scale, Real qi, Real qj, Real sig_i, Real sig_j, Real eps_i, Real eps_j, Real d2ij, Real beta,
+    PairOut<Real> &o) {
+    Real inv_dij = tm_rsqrt(d2ij);
+    Real dij = d2ij * inv_dij;
+    Real inv_d2ij = inv_dij * inv_dij;
+    Real qij = qi * qj;
+    Real damping;
+    Real es_factor = real_es_factor(beta, dij, inv_dij, inv_d2ij, damping);
+    Real es_prefactor = charge_scale * qij * inv_dij * es_factor;
+    Real u = charge_scale * qij * inv_dij * damping;
+    Real prefactor = es_prefactor;
+    o.has_lj = (eps_i != 0 && eps_j != 0);
+    o.sig_grad = 0;
+    o.eps_grad = 0;
+    if (o.has_lj) {
+        Real eps_ij = eps_i * eps_j;
+        Real sig_ij = sig_i + sig_j;
+        Real sig_inv = sig_ij * inv_dij;
+        Real sig2 = sig_inv * sig_inv;
+        Real sig4 = sig2 * sig2;
+        Real sig6 = sig4 * sig2;
+        Real sig6_inv_d8 = sig6 * inv_d2ij;
+        Real sig5_inv_d6 = sig_ij * sig4 * inv_d2ij;
+        Real lj_prefactor = lj_scale * eps_ij * sig6_inv_d8 * (sig6 * 48 - 24);
+        u += lj_scale * 4 * eps_ij * (sig6 - 1) * sig6;
+        prefactor -= lj_prefactor;
+        o.sig_grad = lj_scale * 24 * eps_ij * sig5_inv_d6 * (2 * sig6 - 1);
+        o.eps_grad = lj_scale * 4 * (sig6 - 1) * sig6;
+    }
+    o.prefactor = prefactor;
+    o.u = u;
+    o.inv_dij = inv_dij;
+    o.ebd = damping;
+}
+
+// minimum-image displacement component: delta -= L * nearbyint(delta / L)   (round-half-even, Appendix B.2)
+template <typename Real> __device__ __forceinline__ Real min_image(Real delta, Real box, Real inv_box) {
+    return delta - box * nearbyint(delta * inv_box);
+}
+
+} // namespace tmamd

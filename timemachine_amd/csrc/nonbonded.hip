@@ -1,0 +1,579 @@
+// NonbondedAllPairs / NonbondedPairList / Neighborlist / HilbertSort host classes + kernel instantiations.
+// One translation unit on purpose: the tile kernel and the pair-list kernel must inline the same nb_pair() under
+// the same compiler flags (exact fixed-point cancellation of exclusions).
+#include "engine.hpp"
+#include "kernels_nblist.cuh"
+#include "profiler.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <numeric>
+#include <set>
+
+namespace tmamd {
+
+static const int STEPS_PER_SORT = 100; // reference: cpp/src/nonbonded_all_pairs.cu:16
+
+// =============================================================================================================
+// Hilbert sort
+// =============================================================================================================
+static const int HILBERT_GRID_DIM = 128; // reference: cpp/src/kernels/k_hilbert.cuh:6
+static const int HILBERT_N_BITS = 8;
+
+// Hilbert index of a 3-D integer point, `nbits` bits per axis (Butz's algorithm; bit-compatible with the
+// hilbert_c2i(3, nbits, ...) the reference uses to fill its LUT, cpp/src/hilbert_sort.cu:18-31 -- pinned by
+// tests/test_oracle_hilbert.py against that C code compiled into oracle/_ref).
+static unsigned int hilbert_index_3d(unsigned int c0, unsigned int c1, unsigned int c2, int nbits) {
+    unsigned long long index = 0;
+    unsigned int rot = 0, flip = 0, prev = 0;
+    for (int b = nbits - 1; b >= 0; b--) {
+        const unsigned int g = ((c0 >> b) & 1u) | (((c1 >> b) & 1u) << 1) | (((c2 >> b) & 1u) << 2);
+        const unsigned int t = g ^ prev ^ flip;
+        prev = g;
+        const unsigned int digit = ((t >> rot) | (t << (3 - rot))) & 7u;
+        index = (index << 3) | digit;
+        flip = 1u << rot;
+        const unsigned int low = digit & (0u - digit) & 3u;
+        rot = (rot + 1 + (low == 0 ? 0 : (low == 1 ? 1 : 2))) % 3;
+    }
+    unsigned long long pattern = 0;
+    for (int k = 0; k < nbits; k++) {
+        pattern |= 1ull << (3 * k);
+    }
+    index ^= pattern >> 1;
+    for (int d = 1; d < 3 * nbits; d *= 2) {
+        index ^= index >> d;
+    }
+    return static_cast<unsigned int>(index);
+}
+
+const std::vector<unsigned int> &HilbertSort::lut() {
+    static std::vector<unsigned int> table;
+    if (table.empty()) {
+        table.resize(HILBERT_GRID_DIM * HILBERT_GRID_DIM * HILBERT_GRID_DIM);
+        for (int i = 0; i < HILBERT_GRID_DIM; i++)
+            for (int j = 0; j < HILBERT_GRID_DIM; j++)
+                for (int k = 0; k < HILBERT_GRID_DIM; k++)
+                    table[(i * HILBERT_GRID_DIM + j) * HILBERT_GRID_DIM + k] = hilbert_index_3d(i, j, k, HILBERT_N_BITS);
+    }
+    return table;
+}
+
+// reference: k_coords_to_kv_gather (cpp/src/kernels/k_hilbert.cu:9-54).  f64 on purpose: imaging with floor in f32
+// can land outside the home box for large coordinates.
+__global__ void k_hilbert_keys(
+    const int N, const unsigned int *__restrict__ atom_idxs, const double *__restrict__ coords, const double *__restrict__ box,
+    const unsigned int *__restrict__ bin_to_idx, unsigned int *__restrict__ keys, unsigned int *__restrict__ vals) {
+    const double bx = box[0], by = box[4], bz = box[8];
+    const double inv_bx = 1 / bx, inv_by = 1 / by, inv_bz = 1 / bz;
+    const double inv_bin_width = min(min(inv_bx, inv_by), inv_bz) * (HILBERT_GRID_DIM - 1.0);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x) {
+        const unsigned int a = atom_idxs[idx];
+        double x = coords[a * 3 + 0], y = coords[a * 3 + 1], z = coords[a * 3 + 2];
+        x -= bx * floor(x * inv_bx);
+        y -= by * floor(y * inv_by);
+        z -= bz * floor(z * inv_bz);
+        const unsigned int ix = static_cast<unsigned int>(x * inv_bin_width);
+        const unsigned int iy = static_cast<unsigned int>(y * inv_bin_width);
+        const unsigned int iz = static_cast<unsigned int>(z * inv_bin_width);
+        keys[idx] = bin_to_idx[(ix * HILBERT_GRID_DIM + iy) * HILBERT_GRID_DIM + iz];
+        vals[idx] = a;
+    }
+}
+
+HilbertSort::HilbertSort(const int N)
+    : N_(N), d_bin_to_idx_(HILBERT_GRID_DIM * HILBERT_GRID_DIM * HILBERT_GRID_DIM), d_keys_in_(N), d_keys_out_(N), d_vals_in_(N),
+      d_sort_storage_(nullptr), sort_storage_bytes_(0) {
+    d_bin_to_idx_.copy_from(lut().data());
+    // stable LSD radix sort == the cub::DeviceRadixSort::SortPairs the reference calls (hilbert_sort.cu:69-80)
+    HIP_CHECK(rocprim::radix_sort_pairs(
+        nullptr, sort_storage_bytes_, d_keys_in_.data, d_keys_out_.data, d_vals_in_.data, d_keys_in_.data, static_cast<size_t>(N_), 0, 32));
+    HIP_CHECK(hipMalloc(&d_sort_storage_, sort_storage_bytes_ > 0 ? sort_storage_bytes_ : 1));
+}
+
+HilbertSort::~HilbertSort() {
+    if (d_sort_storage_)
+        (void)hipFree(d_sort_storage_);
+}
+
+void HilbertSort::sort_device(
+    const int N, const unsigned int *d_atom_idxs, const double *d_coords, const double *d_box, unsigned int *d_output_perm,
+    hipStream_t stream) {
+    if (N > N_) {
+        throw std::runtime_error("number of idxs to sort must be less than or equal to N");
+    }
+    const int tpb = DEFAULT_TPB;
+    k_hilbert_keys<<<ceil_divide(N, tpb), tpb, 0, stream>>>(
+        N, d_atom_idxs, d_coords, d_box, d_bin_to_idx_.data, d_keys_in_.data, d_vals_in_.data);
+    HIP_CHECK(hipGetLastError());
+    size_t bytes = sort_storage_bytes_;
+    HIP_CHECK(rocprim::radix_sort_pairs(
+        d_sort_storage_, bytes, d_keys_in_.data, d_keys_out_.data, d_vals_in_.data, d_output_perm, static_cast<size_t>(N), 0, 32, stream));
+}
+
+std::vector<unsigned int> HilbertSort::sort_host(const int N, const double *h_coords, const double *h_box) {
+    std::vector<unsigned int> h_idxs(N);
+    std::iota(h_idxs.begin(), h_idxs.end(), 0);
+    DeviceBuffer<double> d_coords(N * 3), d_box(9);
+    DeviceBuffer<unsigned int> d_idxs(N), d_perm(N);
+    d_coords.copy_from(h_coords);
+    d_box.copy_from(h_box);
+    d_idxs.copy_from(h_idxs.data());
+    hipStream_t stream = 0;
+    sort_device(N, d_idxs.data, d_coords.data, d_box.data, d_perm.data, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    d_perm.copy_to(h_idxs.data());
+    return h_idxs;
+}
+
+// =============================================================================================================
+// Neighborlist
+// =============================================================================================================
+__global__ void k_arange(const int n, unsigned int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = i;
+}
+
+// host-API helper: pack (x, y, z) into the Real[K][8] record layout the build kernels read
+template <typename Real> __global__ void k_pack_coords(const int n, const double *__restrict__ x, Real *__restrict__ gathered) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        for (int d = 0; d < 3; d++)
+            gathered[static_cast<size_t>(i) * 8 + d] = static_cast<Real>(x[i * 3 + d]);
+        for (int d = 3; d < 8; d++)
+            gathered[static_cast<size_t>(i) * 8 + d] = 0;
+    }
+}
+
+template <typename Real>
+Neighborlist<Real>::Neighborlist(const int N) : max_size_(N), N_(N), NC_(N), NR_(N) {
+    if (N == 0) {
+        throw std::runtime_error("Neighborlist N must be at least 1");
+    }
+    const int nb = ceil_divide(N, TILE);
+    d_col_ctr_.realloc(nb * 3);
+    d_col_ext_.realloc(nb * 3);
+    d_row_ctr_.realloc(nb * 3);
+    d_row_ext_.realloc(nb * 3);
+    d_row_idxs_.realloc(N);
+    d_col_idxs_.realloc(N);
+    d_counters_.realloc(4);
+    HIP_CHECK(hipMemset(d_counters_.data, 0, 4 * sizeof(unsigned int)));
+    // Pool sized for the worst case: every block pair interacting.  Row subsets need rows x cols <= (nb/2)^2 block
+    // pairs, always below the upper-triangular count used by the reference (neighborlist.cu:368-376).
+    const size_t max_block_pairs = static_cast<size_t>(nb) * (nb + 1) / 2;
+    d_col_atoms_.realloc(max_block_pairs * TILE);
+    d_items_.realloc(max_block_pairs * TILE / NB_CHUNK + nb + 1);
+    d_row_segments_.realloc(nb);
+    HIP_CHECK(hipMemset(d_row_segments_.data, 0, nb * sizeof(int2)));
+    this->reset_row_idxs();
+}
+
+template <typename Real> int Neighborlist<Real>::max_ixn_count() const {
+    const int nb = ceil_divide(max_size_, TILE);
+    return (nb * (nb + 1)) / 2 * TILE;
+}
+
+template <typename Real> void Neighborlist<Real>::reset_row_idxs() {
+    const int tpb = DEFAULT_TPB;
+    k_arange<<<ceil_divide(N_, tpb), tpb, 0, 0>>>(N_, d_col_idxs_.data);
+    k_arange<<<ceil_divide(N_, tpb), tpb, 0, 0>>>(N_, d_row_idxs_.data);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(0));
+    NR_ = N_;
+    NC_ = N_;
+}
+
+template <typename Real> void Neighborlist<Real>::resize(const int size) {
+    if (size <= 0) {
+        throw std::runtime_error("size is must be at least 1");
+    }
+    if (size > max_size_) {
+        throw std::runtime_error("size is greater than max size: " + std::to_string(size) + " > " + std::to_string(max_size_));
+    }
+    N_ = size;
+    this->reset_row_idxs();
+}
+
+template <typename Real> void Neighborlist<Real>::set_row_idxs(std::vector<unsigned int> row_idxs) {
+    if (row_idxs.size() == 0) {
+        throw std::runtime_error("idxs can't be empty");
+    }
+    std::set<unsigned int> unique_idxs(row_idxs.begin(), row_idxs.end());
+    if (unique_idxs.size() != row_idxs.size()) {
+        throw std::runtime_error("atom indices must be unique");
+    }
+    if (row_idxs.size() >= static_cast<size_t>(N_)) {
+        throw std::runtime_error("number of idxs must be less than N");
+    }
+    if (*std::max_element(row_idxs.begin(), row_idxs.end()) >= static_cast<unsigned int>(N_)) {
+        throw std::runtime_error("indices values must be less than N");
+    }
+    std::vector<unsigned int> col_idxs;
+    col_idxs.reserve(N_ - row_idxs.size());
+    for (unsigned int i = 0; i < static_cast<unsigned int>(N_); i++) {
+        if (!unique_idxs.count(i))
+            col_idxs.push_back(i);
+    }
+    DeviceBuffer<unsigned int> d_rows(row_idxs.size()), d_cols(col_idxs.size());
+    d_rows.copy_from(row_idxs.data());
+    d_cols.copy_from(col_idxs.data());
+    this->set_idxs_device(col_idxs.size(), row_idxs.size(), d_cols.data, d_rows.data, 0);
+    HIP_CHECK(hipStreamSynchronize(0));
+}
+
+template <typename Real>
+void Neighborlist<Real>::set_idxs_device(
+    const int NC, const int NR, const unsigned int *d_in_col, const unsigned int *d_in_row, hipStream_t stream) {
+    if (NC + NR != N_) {
+        throw std::runtime_error("Total of indices must equal N");
+    }
+    if (NC == 0 || NR == 0) {
+        throw std::runtime_error("Number of column and row indices must be non-zero");
+    }
+    HIP_CHECK(hipMemcpyAsync(d_col_idxs_.data, d_in_col, NC * sizeof(unsigned int), hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_row_idxs_.data, d_in_row, NR * sizeof(unsigned int), hipMemcpyDeviceToDevice, stream));
+    NR_ = NR;
+    NC_ = NC;
+}
+
+template <typename Real> unsigned int Neighborlist<Real>::num_tile_ixns() {
+    unsigned int h[4];
+    HIP_CHECK(hipMemcpy(h, d_counters_.data, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return h[2];
+}
+
+template <typename Real>
+void Neighborlist<Real>::build_device(
+    const Real *d_gathered, const double *d_box, const double cutoff, const int *d_flag, const int force, const int n_snap,
+    const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream) {
+    const bool ut = this->upper_triangular();
+    const int ncb = this->num_column_blocks();
+    const int nrb = this->num_row_blocks();
+    const int total_blocks = ncb + (ut ? 0 : nrb);
+    const int tpb = DEFAULT_TPB;
+    int work = std::max(total_blocks, d_snap_x ? n_snap : 0);
+    int grid = std::min(ceil_divide(work, tpb), 1024);
+    grid = std::max(grid, ceil_divide(total_blocks, tpb));
+    const int dummy_flag_force = d_flag ? force : 1;
+    k_block_bounds<Real><<<grid, tpb, 0, stream>>>(
+        ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
+        d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
+        d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+    HIP_CHECK(hipGetLastError());
+    const size_t lds = static_cast<size_t>(ceil_divide(ncb, 64)) * sizeof(u64);
+    if (ut) {
+        k_find_ixns<Real, true><<<nrb, 256, lds, stream>>>(
+            N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
+            cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+    } else {
+        k_find_ixns<Real, false><<<nrb, 256, lds, stream>>>(
+            N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
+            d_gathered, d_box, cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+template <typename Real>
+void Neighborlist<Real>::gather_host_coords(const int N, const double *h_coords, const double *h_box, DeviceBuffer<double> &d_box) {
+    DeviceBuffer<double> d_coords(N * 3);
+    d_coords.copy_from(h_coords);
+    d_box.copy_from(h_box);
+    d_scratch_gathered_.reserve(static_cast<size_t>(N) * 8);
+    k_pack_coords<Real><<<ceil_divide(N, DEFAULT_TPB), DEFAULT_TPB, 0, 0>>>(N, d_coords.data, d_scratch_gathered_.data);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(0));
+}
+
+template <typename Real>
+std::vector<std::vector<int>>
+Neighborlist<Real>::get_nblist_host(const int N, const double *h_coords, const double *h_box, const double cutoff) {
+    if (N != N_) {
+        throw std::runtime_error("N != N_");
+    }
+    DeviceBuffer<double> d_box(9);
+    this->gather_host_coords(N, h_coords, h_box, d_box);
+    this->build_device(d_scratch_gathered_.data, d_box.data, cutoff, nullptr, 1, 0, nullptr, nullptr, nullptr, 0);
+    HIP_CHECK(hipStreamSynchronize(0));
+    const int nrb = this->num_row_blocks();
+    std::vector<int2> segs(nrb);
+    HIP_CHECK(hipMemcpy(segs.data(), d_row_segments_.data, nrb * sizeof(int2), hipMemcpyDeviceToHost));
+    unsigned int counters[4];
+    HIP_CHECK(hipMemcpy(counters, d_counters_.data, sizeof(counters), hipMemcpyDeviceToHost));
+    std::vector<unsigned int> pool(counters[0]);
+    if (counters[0] > 0) {
+        HIP_CHECK(hipMemcpy(pool.data(), d_col_atoms_.data, counters[0] * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    }
+    std::vector<std::vector<int>> out(nrb);
+    for (int r = 0; r < nrb; r++) {
+        out[r].reserve(segs[r].y);
+        for (int k = 0; k < segs[r].y; k++) {
+            out[r].push_back(static_cast<int>(pool[segs[r].x + k]));
+        }
+        std::sort(out[r].begin(), out[r].end());
+    }
+    return out;
+}
+
+template <typename Real>
+void Neighborlist<Real>::compute_block_bounds_host(
+    const int N, const double *h_coords, const double *h_box, double *h_bb_ctrs, double *h_bb_exts) {
+    DeviceBuffer<double> d_box(9);
+    this->gather_host_coords(N, h_coords, h_box, d_box);
+    const bool ut = this->upper_triangular();
+    const int ncb = this->num_column_blocks();
+    const int nrb = this->num_row_blocks();
+    const int total_blocks = ncb + (ut ? 0 : nrb);
+    k_block_bounds<Real><<<ceil_divide(total_blocks, DEFAULT_TPB), DEFAULT_TPB, 0, 0>>>(
+        ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_scratch_gathered_.data,
+        d_box.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, 0, nullptr, nullptr, nullptr,
+        reinterpret_cast<const int *>(d_counters_.data), 1);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(0));
+    std::vector<Real> ctr(ncb * 3), ext(ncb * 3);
+    d_col_ctr_.copy_to(ctr.data(), ncb * 3);
+    d_col_ext_.copy_to(ext.data(), ncb * 3);
+    for (int i = 0; i < ncb * 3; i++) {
+        h_bb_ctrs[i] = ctr[i];
+        h_bb_exts[i] = ext[i];
+    }
+}
+
+template class Neighborlist<float>;
+template class Neighborlist<double>;
+
+// =============================================================================================================
+// NonbondedAllPairs
+// =============================================================================================================
+void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty) {
+    // reference: cpp/src/nonbonded_common.cpp:39-60 (messages are part of the contract)
+    if (atom_idxs.size() == 0) {
+        if (allow_empty)
+            return;
+        throw std::runtime_error("indices can't be empty");
+    }
+    std::set<int> unique_idxs(atom_idxs.begin(), atom_idxs.end());
+    if (unique_idxs.size() != atom_idxs.size()) {
+        throw std::runtime_error("atom indices must be unique");
+    }
+    if (*std::max_element(atom_idxs.begin(), atom_idxs.end()) >= N) {
+        throw std::runtime_error("index values must be less than N(" + std::to_string(N) + ")");
+    }
+    if (*std::min_element(atom_idxs.begin(), atom_idxs.end()) < 0) {
+        throw std::runtime_error("index values must be greater or equal to zero");
+    }
+}
+
+void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out) {
+    // per-column exponents, reference: cpp/src/nonbonded_all_pairs.cu:292-308
+    for (int i = 0; i < N; i++) {
+        out[i * 4 + 0] = static_cast<double>(static_cast<long long>(du_dp[i * 4 + 0])) / TM_FIXED_EXPONENT_DU_DCHARGE;
+        out[i * 4 + 1] = static_cast<double>(static_cast<long long>(du_dp[i * 4 + 1])) / TM_FIXED_EXPONENT_DU_DSIG;
+        out[i * 4 + 2] = static_cast<double>(static_cast<long long>(du_dp[i * 4 + 2])) / TM_FIXED_EXPONENT_DU_DEPS;
+        out[i * 4 + 3] = static_cast<double>(static_cast<long long>(du_dp[i * 4 + 3])) / TM_FIXED_EXPONENT_DU_DW;
+    }
+}
+
+template <typename Real>
+NonbondedAllPairs<Real>::NonbondedAllPairs(
+    const int N, const double beta, const double cutoff, const std::optional<std::vector<int>> &atom_idxs,
+    const bool disable_hilbert_sort, const double nblist_padding)
+    : N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding), disable_hilbert_(disable_hilbert_sort),
+      calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N) {
+    std::vector<int> idxs;
+    if (atom_idxs) {
+        idxs = *atom_idxs;
+        std::sort(idxs.begin(), idxs.end());
+        idxs.erase(std::unique(idxs.begin(), idxs.end()), idxs.end());
+    } else {
+        idxs.resize(N_);
+        std::iota(idxs.begin(), idxs.end(), 0);
+    }
+    verify_atom_idxs(N_, idxs);
+
+    d_atom_idxs_.realloc(N_);
+    d_perm_.realloc(N_);
+    d_gathered_.realloc(static_cast<size_t>(N_) * 8);
+    d_g_du_dx_.realloc(static_cast<size_t>(N_) * 3);
+    d_g_du_dp_.realloc(static_cast<size_t>(N_) * 4);
+    d_snap_x_.realloc(static_cast<size_t>(N_) * 3);
+    d_snap_box_.realloc(9);
+    HIP_CHECK(hipMemset(d_snap_x_.data, 0, d_snap_x_.size()));
+    HIP_CHECK(hipMemset(d_snap_box_.data, 0, d_snap_box_.size()));
+    d_flags_.realloc(2);
+    HIP_CHECK(hipMemset(d_flags_.data, 0, d_flags_.size()));
+    // persistent grid: one wave per workgroup, a few waves per SIMD on every CU
+    grid_ = device_cu_count() * 12;
+    d_u_partials_.realloc(grid_);
+    if (!disable_hilbert_) {
+        hilbert_.reset(new HilbertSort(N_));
+    }
+    this->set_atom_idxs(idxs);
+}
+
+template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::vector<int> &atom_idxs) {
+    verify_atom_idxs(N_, atom_idxs);
+    std::vector<unsigned int> u(atom_idxs.begin(), atom_idxs.end());
+    const int K = static_cast<int>(u.size());
+    HIP_CHECK(hipDeviceSynchronize());
+    d_atom_idxs_.copy_from(u.data(), K);
+    nblist_.resize(K);
+    K_ = K;
+    calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
+    force_rebuild_ = true;
+}
+
+template <typename Real> std::vector<int> NonbondedAllPairs<Real>::get_atom_idxs() {
+    std::vector<unsigned int> u(K_);
+    d_atom_idxs_.copy_to(u.data(), K_);
+    return std::vector<int>(u.begin(), u.end());
+}
+
+template <typename Real>
+void NonbondedAllPairs<Real>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    if (N != N_) {
+        throw std::runtime_error(
+            "NonbondedAllPairs::execute_device(): expected N == N_, got N=" + std::to_string(N) + ", N_=" + std::to_string(N_));
+    }
+    if (P != N_ * PARAMS_PER_ATOM) {
+        throw std::runtime_error(
+            "NonbondedAllPairs::execute_device(): expected P == N_*" + std::to_string(PARAMS_PER_ATOM) + ", got P=" +
+            std::to_string(P) + ", N_*" + std::to_string(PARAMS_PER_ATOM) + "=" + std::to_string(N_ * PARAMS_PER_ATOM));
+    }
+    const int tpb = DEFAULT_TPB;
+
+    // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
+    int force = force_rebuild_ ? 1 : 0;
+    if (calls_since_sort_ % STEPS_PER_SORT == 0) {
+        if (!disable_hilbert_) {
+            hilbert_->sort_device(K_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(d_perm_.data, d_atom_idxs_.data, K_ * sizeof(unsigned int), hipMemcpyDeviceToDevice, stream));
+        }
+        force = 1;
+    }
+
+    // (b) K1: displacement check against the last build's snapshot + gather into Hilbert order.  The rebuild flag
+    // lives on the device and is consumed on the device: the host never waits for it (the reference blocks on a
+    // pinned-memory flag every call, nonbonded_all_pairs.cu:217-236).
+    int *flag_now = d_flags_.data + parity_;
+    int *flag_next = d_flags_.data + (parity_ ^ 1);
+    k_check_gather<Real><<<ceil_divide(std::max(K_, 9), tpb), tpb, 0, stream>>>(
+        K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
+        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr);
+    HIP_CHECK(hipGetLastError());
+
+    // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
+    nblist_.build_device(
+        d_gathered_.data, d_box, cutoff_ + nblist_padding_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream);
+
+    // (d) K4: tile kernel
+    const unsigned int *d_counters = nblist_.d_counters();
+#define TM_LAUNCH_TILES(U, X, PP)                                                                                      \
+    k_nonbonded_tiles<Real, U, X, PP><<<grid_, 64, 0, stream>>>(                                                      \
+        K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(), d_counters + 1,\
+        nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, d_g_du_dx_.data,            \
+        d_g_du_dp_.data, d_u_partials_.data)
+    const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
+    const int prof = Profiler::get().begin("nonbonded_tiles", stream);
+    switch (sel) {
+    case 0: TM_LAUNCH_TILES(false, false, false); break;
+    case 1: TM_LAUNCH_TILES(false, false, true); break;
+    case 2: TM_LAUNCH_TILES(false, true, false); break;
+    case 3: TM_LAUNCH_TILES(false, true, true); break;
+    case 4: TM_LAUNCH_TILES(true, false, false); break;
+    case 5: TM_LAUNCH_TILES(true, false, true); break;
+    case 6: TM_LAUNCH_TILES(true, true, false); break;
+    case 7: TM_LAUNCH_TILES(true, true, true); break;
+    }
+#undef TM_LAUNCH_TILES
+    Profiler::get().end("nonbonded_tiles", prof, stream);
+    HIP_CHECK(hipGetLastError());
+
+    // (e) K5: back to the caller's atom order
+    if (d_du_dx) {
+        k_scatter_accum<3><<<ceil_divide(K_ * 3, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dx_.data, d_du_dx);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (d_du_dp) {
+        k_scatter_accum<4><<<ceil_divide(K_ * 4, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dp_.data, d_du_dp);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (d_u) {
+        reduce_i128_device(d_u_partials_.data, grid_, d_u, stream);
+    }
+    calls_since_sort_++;
+    parity_ ^= 1;
+    force_rebuild_ = false;
+}
+
+template <typename Real>
+void NonbondedAllPairs<Real>::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    nb_du_dp_fixed_to_float(N, du_dp, du_dp_float);
+}
+
+template class NonbondedAllPairs<float>;
+template class NonbondedAllPairs<double>;
+
+// =============================================================================================================
+// NonbondedPairList
+// =============================================================================================================
+template <typename Real, bool Negated>
+NonbondedPairList<Real, Negated>::NonbondedPairList(
+    const std::vector<int> &pair_idxs, const std::vector<double> &scales, const double beta, const double cutoff)
+    : M_(pair_idxs.size() / 2), beta_(beta), cutoff_(cutoff) {
+    if (pair_idxs.size() % 2 != 0) {
+        throw std::runtime_error("pair_idxs.size() must be even, but got " + std::to_string(pair_idxs.size()));
+    }
+    for (int i = 0; i < M_; i++) {
+        const int src = pair_idxs[i * 2 + 0], dst = pair_idxs[i * 2 + 1];
+        if (src == dst) {
+            throw std::runtime_error("illegal pair with src == dst: " + std::to_string(src) + ", " + std::to_string(dst));
+        }
+    }
+    if (static_cast<int>(scales.size() / 2) != M_) {
+        throw std::runtime_error(
+            "expected same number of pairs and scale tuples, but got " + std::to_string(M_) + " != " + std::to_string(scales.size() / 2));
+    }
+    d_pair_idxs_.realloc(M_ * 2);
+    d_scales_.realloc(M_ * 2);
+    if (M_ > 0) {
+        d_pair_idxs_.copy_from(pair_idxs.data());
+        d_scales_.copy_from(scales.data());
+    }
+    d_u_partials_.realloc(ceil_divide(M_, 256) * 4 + 1);
+}
+
+template <typename Real, bool Negated>
+void NonbondedPairList<Real, Negated>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    if (M_ > 0) {
+        const int tpb = 256;
+        const int blocks = ceil_divide(M_, tpb);
+        k_nonbonded_pair_list<Real, Negated><<<blocks, tpb, 0, stream>>>(
+            M_, d_x, d_p, d_box, d_pair_idxs_.data, d_scales_.data, beta_, cutoff_, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (d_u) {
+            reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+        }
+    }
+}
+
+template <typename Real, bool Negated>
+void NonbondedPairList<Real, Negated>::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    nb_du_dp_fixed_to_float(N, du_dp, du_dp_float);
+}
+
+template class NonbondedPairList<float, true>;
+template class NonbondedPairList<float, false>;
+template class NonbondedPairList<double, true>;
+template class NonbondedPairList<double, false>;
+
+} // namespace tmamd

@@ -1,0 +1,417 @@
+// Potential base-class host entry points, BoundPotential, Summed / Fanout composition, the signed-128 reduction.
+// reference: cpp/src/potential.cu, bound_potential.cu, summed_potential.cu, fanout_summed_potential.cu, stream_manager.cu
+#include "engine.hpp"
+#include "fixed_point.cuh"
+
+#include <numeric>
+
+namespace tmamd {
+
+int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// One workgroup: the inputs are a few hundred to a few thousand partials, so a single pass is launch-bound anyway.
+__global__ __launch_bounds__(256) void k_reduce_i128(const i128 *__restrict__ in, const int n, i128 *__restrict__ out) {
+    __shared__ i128 s_part[4];
+    i128 acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        acc += in[i];
+    }
+    acc = wave_sum_i128(acc);
+    if ((threadIdx.x & 63) == 0) {
+        s_part[threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+}
+
+void reduce_i128_device(const i128 *d_in, int n, i128 *d_out, hipStream_t stream) {
+    k_reduce_i128<<<1, 256, 0, stream>>>(d_in, n, d_out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+void Potential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    for (int i = 0; i < P; i++) {
+        du_dp_float[i] = fixed_to_float<double>(du_dp[i]);
+    }
+}
+
+void Potential::execute_batch_device(
+    const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *d_x, const double *d_p,
+    const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) {
+    // outer loop over coordinates, inner over parameters: stateful children (neighbor list) see each frame once
+    for (int i = 0; i < coord_batch_size; i++) {
+        for (int j = 0; j < param_batch_size; j++) {
+            const size_t k = static_cast<size_t>(i) * param_batch_size + j;
+            this->execute_device(
+                N, P, d_x + static_cast<size_t>(i) * N * D, P > 0 ? d_p + static_cast<size_t>(j) * P : nullptr, d_box + i * D * D,
+                d_du_dx ? d_du_dx + k * N * D : nullptr, d_du_dp ? d_du_dp + k * P : nullptr, d_u ? d_u + k : nullptr, stream);
+        }
+    }
+}
+
+void Potential::execute_batch_sparse_device(
+    const int N, const int P, const int batch_size, const unsigned int *coords_batch_idxs, const unsigned int *params_batch_idxs,
+    const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) {
+    for (int i = 0; i < batch_size; i++) {
+        const size_t ic = coords_batch_idxs[i], ip = params_batch_idxs[i];
+        this->execute_device(
+            N, P, d_x + ic * N * D, P > 0 ? d_p + ip * P : nullptr, d_box + ic * D * D,
+            d_du_dx ? d_du_dx + static_cast<size_t>(i) * N * D : nullptr, d_du_dp ? d_du_dp + static_cast<size_t>(i) * P : nullptr,
+            d_u ? d_u + i : nullptr, stream);
+    }
+}
+
+// Shared body of the three host entry points: stage inputs, zero the accumulators, run, copy back.
+struct HostStage {
+    DeviceBuffer<double> &x, &p, &box;
+    DeviceBuffer<u64> &du_dx, &du_dp;
+    DeviceBuffer<i128> &u;
+    void stage(size_t nx, const double *h_x, size_t np, const double *h_p, size_t nbox, const double *h_box, size_t n_du_dx,
+               size_t n_du_dp, size_t n_u, hipStream_t stream) {
+        x.reserve(nx);
+        box.reserve(nbox);
+        p.reserve(np);
+        HIP_CHECK(hipMemcpyAsync(x.data, h_x, nx * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(box.data, h_box, nbox * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (np > 0) {
+            HIP_CHECK(hipMemcpyAsync(p.data, h_p, np * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+        // the kernels accumulate: outputs must start from zero
+        if (n_du_dx) {
+            du_dx.reserve(n_du_dx);
+            du_dx.zero_async(stream, n_du_dx);
+        }
+        if (n_du_dp) {
+            du_dp.reserve(n_du_dp);
+            du_dp.zero_async(stream, n_du_dp);
+        }
+        if (n_u) {
+            u.reserve(n_u);
+            u.zero_async(stream, n_u);
+        }
+    }
+};
+
+void Potential::execute_host(
+    const int N, const int P, const double *h_x, const double *h_p, const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u) {
+    hipStream_t stream = 0;
+    HostStage st{hs_x_, hs_p_, hs_box_, hs_du_dx_, hs_du_dp_, hs_u_};
+    st.stage(static_cast<size_t>(N) * D, h_x, P, h_p, D * D, h_box, h_du_dx ? static_cast<size_t>(N) * D : 0, h_du_dp ? P : 0, h_u ? 1 : 0, stream);
+    this->execute_device(
+        N, P, hs_x_.data, P > 0 ? hs_p_.data : nullptr, hs_box_.data, h_du_dx ? hs_du_dx_.data : nullptr,
+        (h_du_dp && P > 0) ? hs_du_dp_.data : nullptr, h_u ? hs_u_.data : nullptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_du_dx)
+        hs_du_dx_.copy_to(h_du_dx, static_cast<size_t>(N) * D);
+    if (h_du_dp && P > 0)
+        hs_du_dp_.copy_to(h_du_dp, P);
+    if (h_u)
+        hs_u_.copy_to(h_u, 1);
+}
+
+void Potential::execute_batch_host(
+    const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *h_x, const double *h_p,
+    const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u) {
+    hipStream_t stream = 0;
+    const size_t total = static_cast<size_t>(coord_batch_size) * param_batch_size;
+    HostStage st{hs_x_, hs_p_, hs_box_, hs_du_dx_, hs_du_dp_, hs_u_};
+    st.stage(
+        static_cast<size_t>(coord_batch_size) * N * D, h_x, static_cast<size_t>(param_batch_size) * P, h_p,
+        static_cast<size_t>(coord_batch_size) * D * D, h_box, h_du_dx ? total * N * D : 0, h_du_dp ? total * P : 0, h_u ? total : 0, stream);
+    this->execute_batch_device(
+        coord_batch_size, N, param_batch_size, P, hs_x_.data, P > 0 ? hs_p_.data : nullptr, hs_box_.data,
+        h_du_dx ? hs_du_dx_.data : nullptr, (h_du_dp && P > 0) ? hs_du_dp_.data : nullptr, h_u ? hs_u_.data : nullptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_du_dx)
+        hs_du_dx_.copy_to(h_du_dx, total * N * D);
+    if (h_du_dp && P > 0)
+        hs_du_dp_.copy_to(h_du_dp, total * P);
+    if (h_u)
+        hs_u_.copy_to(h_u, total);
+}
+
+void Potential::execute_batch_sparse_host(
+    const int coords_size, const int N, const int params_size, const int P, const int batch_size,
+    const unsigned int *coords_batch_idxs, const unsigned int *params_batch_idxs, const double *h_x, const double *h_p,
+    const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u) {
+    hipStream_t stream = 0;
+    const size_t total = batch_size;
+    HostStage st{hs_x_, hs_p_, hs_box_, hs_du_dx_, hs_du_dp_, hs_u_};
+    st.stage(
+        static_cast<size_t>(coords_size) * N * D, h_x, static_cast<size_t>(params_size) * P, h_p, static_cast<size_t>(coords_size) * D * D,
+        h_box, h_du_dx ? total * N * D : 0, h_du_dp ? total * P : 0, h_u ? total : 0, stream);
+    this->execute_batch_sparse_device(
+        N, P, batch_size, coords_batch_idxs, params_batch_idxs, hs_x_.data, P > 0 ? hs_p_.data : nullptr, hs_box_.data,
+        h_du_dx ? hs_du_dx_.data : nullptr, (h_du_dp && P > 0) ? hs_du_dp_.data : nullptr, h_u ? hs_u_.data : nullptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_du_dx)
+        hs_du_dx_.copy_to(h_du_dx, total * N * D);
+    if (h_du_dp && P > 0)
+        hs_du_dp_.copy_to(h_du_dp, total * P);
+    if (h_u)
+        hs_u_.copy_to(h_u, total);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+BoundPotential::BoundPotential(std::shared_ptr<Potential> potential, const std::vector<double> &params)
+    : size(params.size()), d_p(params.size()), potential(potential) {
+    set_params(params);
+}
+
+void BoundPotential::set_params(const std::vector<double> &params) {
+    if (params.size() != d_p.length) {
+        throw std::runtime_error(
+            "parameter size is not equal to device buffer size: " + std::to_string(params.size()) + " != " + std::to_string(d_p.length));
+    }
+    if (params.size() > 0) {
+        d_p.copy_from(params.data());
+    }
+    this->size = params.size();
+}
+
+void BoundPotential::set_params_device(const int new_size, const double *d_new_params, hipStream_t stream) {
+    if (static_cast<size_t>(new_size) > d_p.length) {
+        throw std::runtime_error(
+            "parameter size is greater than device buffer size: " + std::to_string(new_size) + " > " + std::to_string(d_p.length));
+    }
+    HIP_CHECK(hipMemcpyAsync(d_p.data, d_new_params, new_size * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    this->size = new_size;
+}
+
+void BoundPotential::execute_device(
+    const int N, const double *d_x, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) {
+    this->potential->execute_device(N, this->size, d_x, this->size > 0 ? this->d_p.data : nullptr, d_box, d_du_dx, d_du_dp, d_u, stream);
+}
+
+void BoundPotential::execute_host(const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u) {
+    this->execute_batch_host(1, N, h_x, h_box, h_du_dx, h_u);
+}
+
+void BoundPotential::execute_batch_host(
+    const int coord_batch_size, const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u) {
+    const int D = 3;
+    hipStream_t stream = 0;
+    const size_t total = coord_batch_size;
+    hs_x_.reserve(total * N * D);
+    hs_box_.reserve(total * D * D);
+    HIP_CHECK(hipMemcpyAsync(hs_x_.data, h_x, total * N * D * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(hs_box_.data, h_box, total * D * D * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (h_du_dx) {
+        hs_du_dx_.reserve(total * N * D);
+        hs_du_dx_.zero_async(stream, total * N * D);
+    }
+    if (h_u) {
+        hs_u_.reserve(total);
+        hs_u_.zero_async(stream, total);
+    }
+    this->potential->execute_batch_device(
+        coord_batch_size, N, 1, this->size, hs_x_.data, this->size > 0 ? this->d_p.data : nullptr, hs_box_.data,
+        h_du_dx ? hs_du_dx_.data : nullptr, nullptr, h_u ? hs_u_.data : nullptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (h_du_dx)
+        hs_du_dx_.copy_to(h_du_dx, total * N * D);
+    if (h_u)
+        hs_u_.copy_to(h_u, total);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+StreamFork::~StreamFork() {
+    for (auto s : streams_)
+        (void)hipStreamDestroy(s);
+    for (auto e : events_)
+        (void)hipEventDestroy(e);
+}
+
+void StreamFork::ensure(int i) {
+    while (static_cast<int>(streams_.size()) <= i) {
+        hipStream_t s;
+        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        streams_.push_back(s);
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events_.push_back(e);
+    }
+}
+
+hipStream_t StreamFork::stream(int i) {
+    ensure(i);
+    return streams_[i];
+}
+
+void StreamFork::fork_from(int i, hipStream_t parent) {
+    ensure(i);
+    HIP_CHECK(hipEventRecord(events_[i], parent));
+    HIP_CHECK(hipStreamWaitEvent(streams_[i], events_[i], 0));
+}
+
+void StreamFork::join_to(int i, hipStream_t parent) {
+    ensure(i);
+    HIP_CHECK(hipEventRecord(events_[i], streams_[i]));
+    HIP_CHECK(hipStreamWaitEvent(parent, events_[i], 0));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+SummedPotential::SummedPotential(
+    const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel)
+    : potentials_(potentials), params_sizes_(params_sizes), P_(std::accumulate(params_sizes.begin(), params_sizes.end(), 0)),
+      parallel_(parallel) {
+    if (potentials_.size() != params_sizes_.size()) {
+        throw std::runtime_error("number of potentials != number of parameter sizes");
+    }
+    d_u_buffer_.realloc(potentials_.size());
+}
+
+void SummedPotential::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    if (P != P_) {
+        throw std::runtime_error(
+            "SummedPotential::execute_device(): expected " + std::to_string(P_) + " parameters, got " + std::to_string(P));
+    }
+    const int n = potentials_.size();
+    if (d_u) {
+        d_u_buffer_.zero_async(stream, n);
+    }
+    const bool par = parallel_ && n > 1;
+    if (par) {
+        for (int i = 0; i < n; i++)
+            fork_.fork_from(i, stream);
+    }
+    int offset = 0;
+    for (int i = 0; i < n; i++) {
+        hipStream_t s = par ? fork_.stream(i) : stream;
+        potentials_[i]->execute_device(
+            N, params_sizes_[i], d_x, d_p + offset, d_box, d_du_dx, d_du_dp == nullptr ? nullptr : d_du_dp + offset,
+            d_u == nullptr ? nullptr : d_u_buffer_.data + i, s);
+        offset += params_sizes_[i];
+        if (par)
+            fork_.join_to(i, stream);
+    }
+    if (d_u) {
+        reduce_i128_device(d_u_buffer_.data, n, d_u, stream);
+    }
+}
+
+void SummedPotential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    int offset = 0;
+    for (size_t i = 0; i < potentials_.size(); i++) {
+        potentials_[i]->du_dp_fixed_to_float(N, params_sizes_[i], du_dp + offset, du_dp_float + offset);
+        offset += params_sizes_[i];
+    }
+}
+
+FanoutSummedPotential::FanoutSummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const bool parallel)
+    : potentials_(potentials), parallel_(parallel), d_u_buffer_(potentials.size()) {}
+
+void FanoutSummedPotential::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    const int n = potentials_.size();
+    if (d_u) {
+        d_u_buffer_.zero_async(stream, n);
+    }
+    const bool par = parallel_ && n > 1;
+    if (par) {
+        for (int i = 0; i < n; i++)
+            fork_.fork_from(i, stream);
+    }
+    for (int i = 0; i < n; i++) {
+        hipStream_t s = par ? fork_.stream(i) : stream;
+        potentials_[i]->execute_device(N, P, d_x, d_p, d_box, d_du_dx, d_du_dp, d_u == nullptr ? nullptr : d_u_buffer_.data + i, s);
+        if (par)
+            fork_.join_to(i, stream);
+    }
+    if (d_u) {
+        reduce_i128_device(d_u_buffer_.data, n, d_u, stream);
+    }
+}
+
+void FanoutSummedPotential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    if (!potentials_.empty()) {
+        potentials_[0]->du_dp_fixed_to_float(N, P, du_dp, du_dp_float);
+    }
+}
+
+void collect_nonbonded_cutoffs(const std::shared_ptr<Potential> &pot, std::vector<double> &out) {
+    if (auto nb = std::dynamic_pointer_cast<NonbondedAllPairsBase>(pot)) {
+        out.push_back(nb->get_cutoff() + nb->get_nblist_padding());
+    } else if (auto f = std::dynamic_pointer_cast<FanoutSummedPotential>(pot)) {
+        for (auto &c : f->get_potentials())
+            collect_nonbonded_cutoffs(c, out);
+    } else if (auto s = std::dynamic_pointer_cast<SummedPotential>(pot)) {
+        for (auto &c : s->get_potentials())
+            collect_nonbonded_cutoffs(c, out);
+    }
+}
+
+} // namespace tmamd
+
+// ------------------------------------------------------------------------------------------------------------
+#include "profiler.hpp"
+namespace tmamd {
+
+Profiler &Profiler::get() {
+    static Profiler p;
+    return p;
+}
+
+int Profiler::begin(const char *name, hipStream_t stream) {
+    if (!enabled_)
+        return -1;
+    auto &v = events_[name];
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(a, stream));
+    v.emplace_back(a, b);
+    return static_cast<int>(v.size()) - 1;
+}
+
+void Profiler::end(const char *name, int idx, hipStream_t stream) {
+    if (idx < 0)
+        return;
+    HIP_CHECK(hipEventRecord(events_[name][idx].second, stream));
+}
+
+void Profiler::read(const char *name, double *total_ms, long long *launches) {
+    HIP_CHECK(hipDeviceSynchronize());
+    double total = 0;
+    long long n = 0;
+    auto it = events_.find(name);
+    if (it != events_.end()) {
+        for (auto &pr : it->second) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            total += ms;
+            n++;
+        }
+    }
+    *total_ms = total;
+    *launches = n;
+}
+
+void Profiler::reset() {
+    (void)hipDeviceSynchronize();
+    for (auto &kv : events_) {
+        for (auto &pr : kv.second) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    }
+    events_.clear();
+}
+
+} // namespace tmamd

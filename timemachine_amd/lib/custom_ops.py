@@ -1,0 +1,740 @@
+"""``timemachine_amd.lib.custom_ops`` -- the reference's ``timemachine.lib.custom_ops`` surface for the force-evaluation +
+Langevin-step hot path, served by ``libtimemachine_amd.so`` (hand-written HIP for gfx950) through its C ABI
+(``include/timemachine_amd.h``).
+
+Same class names, constructor argument order, method names, defaults, return shapes and error messages as the pybind11
+module the reference builds from ``timemachine/cpp/src/wrap_kernels.cpp`` (the lines are cited per class below), so
+reference-style callers (``potentials.*.to_gpu``, ``lib.LangevinIntegrator.impl``, ``Context(...).multiple_steps``)
+work by changing only the top-level import.  This module is deliberately thin: validation that the pybind lambdas do,
+ctypes marshalling, fixed-point -> float conversion of the returned accumulators.  There is NO CPU fallback: importing
+this module without the compiled library raises ImportError, and every method runs on the GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtimemachine_amd.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or python -m timemachine_amd.csrc.build). timemachine_amd has no CPU fallback."
+    )
+_lib = ctypes.CDLL(_LIB_PATH)
+
+FIXED_EXPONENT = 0x1000000000  # wrap_kernels.cpp:2144
+
+TM_OK, TM_ERR_RUNTIME, TM_ERR_INVALID_HARDWARE = 0, 1, 2
+_F32, _F64 = 0, 1
+
+
+class InvalidHardware(Exception):
+    """No usable GPU / driver (reference: custom_ops.InvalidHardware, wrap_kernels.cpp:2311)."""
+
+
+_lib.tm_last_error.restype = ctypes.c_char_p
+_lib.tm_version.restype = ctypes.c_char_p
+_lib.tm_fixed_to_float.restype = ctypes.c_double
+_lib.tm_fixed_to_float.argtypes = [ctypes.c_uint64]
+_lib.tm_energy_to_float.restype = ctypes.c_double
+
+_vp = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_double = ctypes.c_double
+
+
+def _check(code):
+    if code == TM_OK:
+        return
+    msg = _lib.tm_last_error().decode()
+    if code == TM_ERR_INVALID_HARDWARE:
+        raise InvalidHardware(msg)
+    raise RuntimeError(msg)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _as(a, dtype, what):
+    """py::array_t<T, c_style> semantics: safe casts are converted, unsafe ones are a TypeError."""
+    arr = np.asarray(a)
+    if arr.dtype != dtype and not np.can_cast(arr.dtype, dtype, "safe"):
+        raise TypeError(f"{what}: incompatible array dtype {arr.dtype}, expected {np.dtype(dtype)}")
+    return np.ascontiguousarray(arr, dtype=dtype)
+
+
+def _f64(a, what="array"):
+    return _as(a, np.float64, what)
+
+
+def _i32(a, what="index array"):
+    return _as(a, np.int32, what)
+
+
+def _u32(a, what="index array"):
+    return _as(a, np.uint32, what)
+
+
+def _verify_coords(coords):
+    # wrap_kernels.cpp:51-59
+    if coords.ndim != 2:
+        raise RuntimeError("coords dimensions must be 2")
+    if coords.shape[-1] != 3:
+        raise RuntimeError("coords must have a shape that is 3 dimensional")
+
+
+def _verify_coords_and_box(coords, box):
+    # wrap_kernels.cpp:62-78
+    _verify_coords(coords)
+    if box.ndim != 2 or box.shape[0] != 3 or box.shape[1] != 3:
+        raise RuntimeError("box must be 3x3")
+    flat = box.reshape(-1)
+    for i in range(9):
+        if i in (0, 4, 8):
+            if flat[i] <= 0.0:
+                raise RuntimeError("box must have positive values along diagonal")
+        elif flat[i] != 0.0:
+            raise RuntimeError("box must be ortholinear")
+
+
+def _fixed_to_float(u64_arr):
+    """FIXED_TO_FLOAT<double>, cpp/src/fixed_point.hpp:18-20."""
+    return u64_arr.view(np.int64).astype(np.float64) / float(FIXED_EXPONENT)
+
+
+_I128 = np.dtype([("lo", np.uint64), ("hi", np.int64)])
+
+
+def _i128_to_int(rec):
+    return (int(rec["hi"]) << 64) | int(rec["lo"])
+
+
+_LLONG_MAX = (1 << 63) - 1
+_LLONG_MIN = -(1 << 63)
+
+
+def _energy_to_float(rec):
+    """convert_energy_to_fp, wrap_kernels.cpp:83-89: NaN when the 128-bit sum left the int64 range."""
+    v = _i128_to_int(rec)
+    if v >= _LLONG_MAX or v <= _LLONG_MIN:
+        return float("nan")
+    return float(v) / float(FIXED_EXPONENT)
+
+
+def cuda_device_reset():
+    """wrap_kernels.cpp:2222-2225 (name kept for drop-in compatibility; resets the HIP device)."""
+    _check(_lib.tm_device_reset())
+
+
+def device_count():
+    n = _c_int(0)
+    _check(_lib.tm_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def set_device(idx):
+    _check(_lib.tm_set_device(int(idx)))
+
+
+def device_synchronize():
+    _check(_lib.tm_device_synchronize())
+
+
+def device_name():
+    buf = ctypes.create_string_buffer(256)
+    _check(_lib.tm_device_name(buf, ctypes.c_size_t(256)))
+    return buf.value.decode()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Potential:
+    """Base of every potential (wrap_kernels.cpp:731-1131).  Not constructible."""
+
+    _h = None
+    _keep = ()
+
+    def __init__(self, *a, **k):
+        raise TypeError("Potential: No constructor defined!")
+
+    @classmethod
+    def _wrap(cls, handle, keep=()):
+        obj = object.__new__(cls)
+        obj._h = handle
+        obj._keep = tuple(keep)
+        return obj
+
+    def __del__(self):
+        h, self._h = self._h, None
+        if h is not None and _lib is not None:
+            _lib.tm_potential_destroy(h)
+
+    def _du_dp_to_float(self, N, P, fixed, shape):
+        out = np.empty(shape, dtype=np.float64)
+        _check(_lib.tm_potential_du_dp_fixed_to_float(self._h, _c_int(N), _c_int(P), _ptr(fixed), _ptr(out)))
+        return out
+
+    def execute(self, coords, params, box, compute_du_dx=True, compute_du_dp=True, compute_u=True):
+        """-> (du_dx[N,3] | None, du_dp[params.shape] | None, u | None); wrap_kernels.cpp:1039-1105."""
+        coords, params, box = _f64(coords, "coords"), _f64(params, "params"), _f64(box, "box")
+        N, P = coords.shape[0], params.size
+        _verify_coords_and_box(coords, box)
+        du_dx = np.full(N * 3, 9999, dtype=np.uint64) if compute_du_dx else None
+        du_dp = np.full(P, 9999, dtype=np.uint64) if compute_du_dp else None
+        u = np.zeros(1, dtype=_I128) if compute_u else None
+        _check(_lib.tm_potential_execute(self._h, _c_int(N), _c_int(P), _ptr(coords), _ptr(params), _ptr(box), _ptr(du_dx), _ptr(du_dp), _ptr(u)))
+        r_dx = _fixed_to_float(du_dx).reshape(N, 3) if compute_du_dx else None
+        r_dp = self._du_dp_to_float(N, P, du_dp, params.shape) if compute_du_dp else None
+        r_u = _energy_to_float(u[0]) if compute_u else None
+        return r_dx, r_dp, r_u
+
+    def execute_raw(self, coords, params, box, compute_du_dx=True, compute_du_dp=True, compute_u=True):
+        """The un-converted accumulators: (uint64[N,3] | None, uint64[P] | None, python int | None).  Not part of the
+        reference surface; used by the parity tests for bit-exact (integer) comparisons."""
+        coords, params, box = _f64(coords, "coords"), _f64(params, "params"), _f64(box, "box")
+        N, P = coords.shape[0], params.size
+        _verify_coords_and_box(coords, box)
+        du_dx = np.zeros(N * 3, dtype=np.uint64) if compute_du_dx else None
+        du_dp = np.zeros(P, dtype=np.uint64) if compute_du_dp else None
+        u = np.zeros(1, dtype=_I128) if compute_u else None
+        _check(_lib.tm_potential_execute(self._h, _c_int(N), _c_int(P), _ptr(coords), _ptr(params), _ptr(box), _ptr(du_dx), _ptr(du_dp), _ptr(u)))
+        return (du_dx.reshape(N, 3) if compute_du_dx else None, du_dp, _i128_to_int(u[0]) if compute_u else None)
+
+    def execute_du_dx(self, coords, params, box):
+        """wrap_kernels.cpp:1106-1130."""
+        return self.execute(coords, params, box, True, False, False)[0]
+
+    def execute_batch(self, coords, params, boxes, compute_du_dx, compute_du_dp, compute_u):
+        """-> (du_dx[C,Pb,N,3], du_dp[C,Pb,*params.shape[1:]], u[C,Pb]); wrap_kernels.cpp:738-862."""
+        coords, params, boxes = _f64(coords, "coords"), _f64(params, "params"), _f64(boxes, "boxes")
+        if coords.ndim != 3 or boxes.ndim != 3:
+            raise RuntimeError("coords and boxes must have 3 dimensions")
+        if coords.shape[0] != boxes.shape[0]:
+            raise RuntimeError("number of batches of coords and boxes don't match")
+        if params.ndim < 2:
+            raise RuntimeError("parameters must have at least 2 dimensions")
+        C, N = coords.shape[0], coords.shape[1]
+        Pb = params.shape[0]
+        P = params.size // Pb if Pb else 0
+        total = C * Pb
+        du_dx = np.full(total * N * 3, 9999, dtype=np.uint64) if compute_du_dx else None
+        du_dp = np.full(total * P, 9999, dtype=np.uint64) if compute_du_dp else None
+        u = np.zeros(total, dtype=_I128) if compute_u else None
+        _check(_lib.tm_potential_execute_batch(
+            self._h, _c_int(C), _c_int(N), _c_int(Pb), _c_int(P), _ptr(coords), _ptr(params), _ptr(boxes), _ptr(du_dx), _ptr(du_dp), _ptr(u)))
+        r_dx = _fixed_to_float(du_dx).reshape(C, Pb, N, 3) if compute_du_dx else None
+        r_dp = None
+        if compute_du_dp:
+            r_dp = np.empty((C, Pb) + params.shape[1:], dtype=np.float64)
+            flat = r_dp.reshape(total, P)
+            for i in range(total):
+                flat[i] = self._du_dp_to_float(N, P, du_dp[i * P : (i + 1) * P], (P,))
+        r_u = np.array([_energy_to_float(x) for x in u], dtype=np.float64).reshape(C, Pb) if compute_u else None
+        return r_dx, r_dp, r_u
+
+    def execute_batch_sparse(self, coords, params, boxes, coords_batch_idxs, params_batch_idxs, compute_du_dx, compute_du_dp, compute_u):
+        """-> (du_dx[B,N,3], du_dp[B,*params.shape[1:]], u[B]); wrap_kernels.cpp:863-1038."""
+        coords, params, boxes = _f64(coords, "coords"), _f64(params, "params"), _f64(boxes, "boxes")
+        cidx, pidx = _u32(coords_batch_idxs, "coords_batch_idxs"), _u32(params_batch_idxs, "params_batch_idxs")
+        if coords.ndim != 3 or boxes.ndim != 3:
+            raise RuntimeError("coords and boxes must have 3 dimensions")
+        if coords.shape[0] != boxes.shape[0]:
+            raise RuntimeError("number of coord arrays and boxes don't match")
+        if params.ndim < 2:
+            raise RuntimeError("parameters must have at least 2 dimensions")
+        if cidx.ndim != 1 or pidx.ndim != 1:
+            raise RuntimeError("coords_batch_idxs and params_batch_idxs must be one-dimensional arrays")
+        if cidx.size != pidx.size:
+            raise RuntimeError("coords_batch_idxs and params_batch_idxs must have the same length")
+        B = cidx.size
+        if B and cidx.max() >= coords.shape[0]:
+            raise RuntimeError("coords_batch_idxs contains an index that is out of bounds")
+        if B and pidx.max() >= params.shape[0]:
+            raise RuntimeError("params_batch_idxs contains an index that is out of bounds")
+        Cs, N = coords.shape[0], coords.shape[1]
+        Ps = params.shape[0]
+        P = params.size // Ps if Ps else 0
+        du_dx = np.full(B * N * 3, 9999, dtype=np.uint64) if compute_du_dx else None
+        du_dp = np.full(B * P, 9999, dtype=np.uint64) if compute_du_dp else None
+        u = np.zeros(B, dtype=_I128) if compute_u else None
+        _check(_lib.tm_potential_execute_batch_sparse(
+            self._h, _c_int(Cs), _c_int(N), _c_int(Ps), _c_int(P), _c_int(B), _ptr(cidx), _ptr(pidx), _ptr(coords), _ptr(params),
+            _ptr(boxes), _ptr(du_dx), _ptr(du_dp), _ptr(u)))
+        r_dx = _fixed_to_float(du_dx).reshape(B, N, 3) if compute_du_dx else None
+        r_dp = None
+        if compute_du_dp:
+            r_dp = np.empty((B,) + params.shape[1:], dtype=np.float64)
+            flat = r_dp.reshape(B, P)
+            for i in range(B):
+                flat[i] = self._du_dp_to_float(N, P, du_dp[i * P : (i + 1) * P], (P,))
+        r_u = np.array([_energy_to_float(x) for x in u], dtype=np.float64) if compute_u else None
+        return r_dx, r_dp, r_u
+
+
+def _new_potential(cls, create_fn, *args, keep=()):
+    h = _vp()
+    _check(create_fn(*args, ctypes.byref(h)))
+    return cls._wrap(h, keep)
+
+
+def _declare_precision_classes(base_name, ctor):
+    """Creates <base_name>_f32 / _f64 (the reference declares each template twice, wrap_kernels.cpp:2186-2216)."""
+    out = []
+    for suffix, prec in (("f32", _F32), ("f64", _F64)):
+        def __new__(cls, *args, _prec=prec, **kwargs):
+            return ctor(cls, _prec, *args, **kwargs)
+
+        klass = type(f"{base_name}_{suffix}", (Potential,), {"__new__": __new__, "__init__": lambda self, *a, **k: None})
+        out.append(klass)
+    return out
+
+
+def _harmonic_bond_ctor(cls, prec, bond_idxs):
+    """HarmonicBond_*(bond_idxs int32[B,2]); wrap_kernels.cpp:1311-1322."""
+    idx = _i32(bond_idxs, "bond_idxs")
+    if idx.size % 2 != 0:
+        raise RuntimeError("bond_idxs.size() must be exactly 2*k!")
+    return _new_potential(cls, _lib.tm_harmonic_bond_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 2))
+
+
+def _harmonic_angle_ctor(cls, prec, angle_idxs):
+    """HarmonicAngle_*(angle_idxs int32[A,3]); wrap_kernels.cpp:1396-1408."""
+    idx = _i32(angle_idxs, "angle_idxs")
+    if idx.size % 3 != 0:
+        raise RuntimeError("angle_idxs.size() must be exactly 3*A")
+    return _new_potential(cls, _lib.tm_harmonic_angle_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 3))
+
+
+def _periodic_torsion_ctor(cls, prec, angle_idxs):
+    """PeriodicTorsion_*(angle_idxs int32[T,4]) -- the kwarg really is ``angle_idxs``; wrap_kernels.cpp:1432-1444."""
+    idx = _i32(angle_idxs, "angle_idxs")
+    if idx.size % 4 != 0:
+        raise RuntimeError("torsion_idxs.size() must be exactly 4*k")
+    return _new_potential(cls, _lib.tm_periodic_torsion_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 4))
+
+
+def _nonbonded_all_pairs_ctor(cls, prec, num_atoms, beta, cutoff, atom_idxs_i=None, disable_hilbert_sort=False, nblist_padding=0.1):
+    """NonbondedAllPairs_*(num_atoms, beta, cutoff, atom_idxs_i=None, disable_hilbert_sort=False, nblist_padding=0.1);
+    wrap_kernels.cpp:1446-1478."""
+    idx = None if atom_idxs_i is None else _i32(atom_idxs_i, "atom_idxs_i")
+    return _new_potential(
+        cls, _lib.tm_nonbonded_all_pairs_create, _c_int(prec), _c_int(int(num_atoms)), _c_double(beta), _c_double(cutoff), _ptr(idx),
+        _c_int(0 if idx is None else idx.size), _c_int(1 if disable_hilbert_sort else 0), _c_double(nblist_padding))
+
+
+def _pair_list_ctor(negated):
+    def ctor(cls, prec, pair_idxs_i, scales_i, beta, cutoff):
+        """NonbondedPairList_* / NonbondedExclusions_*(pair_idxs_i int32[M,2], scales_i f64[M,2], beta, cutoff);
+        wrap_kernels.cpp:1563-1589."""
+        idx = _i32(pair_idxs_i, "pair_idxs_i")
+        sc = _f64(scales_i, "scales_i")
+        if idx.size % 2 != 0:
+            raise RuntimeError(f"pair_idxs.size() must be even, but got {idx.size}")
+        return _new_potential(
+            cls, _lib.tm_nonbonded_pair_list_create, _c_int(prec), _c_int(negated), _ptr(idx), _c_int(idx.size // 2), _ptr(sc),
+            _c_int(sc.size // 2), _c_double(beta), _c_double(cutoff))
+
+    return ctor
+
+
+HarmonicBond_f32, HarmonicBond_f64 = _declare_precision_classes("HarmonicBond", _harmonic_bond_ctor)
+HarmonicAngle_f32, HarmonicAngle_f64 = _declare_precision_classes("HarmonicAngle", _harmonic_angle_ctor)
+PeriodicTorsion_f32, PeriodicTorsion_f64 = _declare_precision_classes("PeriodicTorsion", _periodic_torsion_ctor)
+NonbondedAllPairs_f32, NonbondedAllPairs_f64 = _declare_precision_classes("NonbondedAllPairs", _nonbonded_all_pairs_ctor)
+NonbondedPairList_f32, NonbondedPairList_f64 = _declare_precision_classes("NonbondedPairList", _pair_list_ctor(0))
+NonbondedExclusions_f32, NonbondedExclusions_f64 = _declare_precision_classes("NonbondedExclusions", _pair_list_ctor(1))
+
+
+def _all_pairs_set_atom_idxs(self, atom_idxs):
+    idx = _i32(np.asarray(atom_idxs, dtype=np.int32))
+    _check(_lib.tm_nonbonded_all_pairs_set_atom_idxs(self._h, _ptr(idx), _c_int(idx.size)))
+
+
+def _all_pairs_get_num_atom_idxs(self):
+    n = _c_int(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_num_atom_idxs(self._h, ctypes.byref(n)))
+    return n.value
+
+
+def _all_pairs_get_atom_idxs(self):
+    n = _all_pairs_get_num_atom_idxs(self)
+    out = np.zeros(n, dtype=np.int32)
+    _check(_lib.tm_nonbonded_all_pairs_get_atom_idxs(self._h, _ptr(out), _c_int(n)))
+    return out.tolist()
+
+
+def _all_pairs_get_tile_count(self):
+    n = ctypes.c_uint(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_tile_count(self._h, ctypes.byref(n)))
+    return n.value
+
+
+for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
+    _k.set_atom_idxs = _all_pairs_set_atom_idxs
+    _k.get_atom_idxs = _all_pairs_get_atom_idxs
+    _k.get_num_atom_idxs = _all_pairs_get_num_atom_idxs
+    _k.get_tile_ixn_count = _all_pairs_get_tile_count  # diagnostic (not in the reference surface)
+
+
+def _handles(potentials):
+    for p in potentials:
+        if not isinstance(p, Potential):
+            raise TypeError("potentials must be custom_ops.Potential instances")
+    arr = (_vp * len(potentials))(*[p._h.value for p in potentials])
+    return arr
+
+
+class SummedPotential(Potential):
+    """SummedPotential(potentials, params_sizes, parallel=True); wrap_kernels.cpp:1661-1676."""
+
+    def __new__(cls, potentials, params_sizes, parallel=True):
+        potentials = list(potentials)
+        sizes = np.ascontiguousarray(np.asarray(list(params_sizes), dtype=np.int32))
+        obj = _new_potential(
+            cls, _lib.tm_summed_potential_create, _handles(potentials), _c_int(len(potentials)), _ptr(sizes), _c_int(sizes.size),
+            _c_int(1 if parallel else 0), keep=potentials)
+        return obj
+
+    def __init__(self, *a, **k):
+        pass
+
+    def get_potentials(self):
+        return list(self._keep)
+
+
+class FanoutSummedPotential(Potential):
+    """FanoutSummedPotential(potentials, parallel=True); wrap_kernels.cpp:1678-1691."""
+
+    def __new__(cls, potentials, parallel=True):
+        potentials = list(potentials)
+        return _new_potential(
+            cls, _lib.tm_fanout_summed_potential_create, _handles(potentials), _c_int(len(potentials)), _c_int(1 if parallel else 0),
+            keep=potentials)
+
+    def __init__(self, *a, **k):
+        pass
+
+    def get_potentials(self):
+        return list(self._keep)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class BoundPotential:
+    """BoundPotential(potential, params); wrap_kernels.cpp:1133-1309."""
+
+    def __init__(self, potential, params):
+        if not isinstance(potential, Potential):
+            raise TypeError("potential must be a custom_ops.Potential")
+        p = _f64(params, "params")
+        self._potential = potential  # keeps the Potential alive (tests/test_potentials.py:36-48)
+        self._h = _vp()
+        _check(_lib.tm_bound_potential_create(potential._h, _ptr(p), _c_int(p.size), ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_bound_potential_destroy(h)
+
+    def get_potential(self):
+        return self._potential
+
+    def set_params(self, params):
+        p = _f64(params, "params")
+        _check(_lib.tm_bound_potential_set_params(self._h, _ptr(p), _c_int(p.size)))
+
+    def size(self):
+        n = _c_int(0)
+        _check(_lib.tm_bound_potential_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def execute(self, coords, box, compute_du_dx=True, compute_u=True):
+        """-> (du_dx | None, u | None); wrap_kernels.cpp:1149-1186."""
+        coords, box = _f64(coords, "coords"), _f64(box, "box")
+        N = coords.shape[0]
+        _verify_coords_and_box(coords, box)
+        du_dx = np.full(N * 3, 9999, dtype=np.uint64) if compute_du_dx else None
+        u = np.zeros(1, dtype=_I128) if compute_u else None
+        _check(_lib.tm_bound_potential_execute(self._h, _c_int(N), _ptr(coords), _ptr(box), _ptr(du_dx), _ptr(u)))
+        return (_fixed_to_float(du_dx).reshape(N, 3) if compute_du_dx else None, _energy_to_float(u[0]) if compute_u else None)
+
+    def execute_batch(self, coords, boxes, compute_du_dx, compute_u):
+        """-> (du_dx[C,N,3] | None, u[C] | None); wrap_kernels.cpp:1187-1274."""
+        coords, boxes = _f64(coords, "coords"), _f64(boxes, "boxes")
+        if coords.ndim != 3 and boxes.ndim != 3:
+            raise RuntimeError("coords and boxes must have 3 dimensions")
+        if coords.shape[0] != boxes.shape[0]:
+            raise RuntimeError("number of batches of coords and boxes don't match")
+        C, N = coords.shape[0], coords.shape[1]
+        du_dx = np.full(C * N * 3, 9999, dtype=np.uint64) if compute_du_dx else None
+        u = np.zeros(C, dtype=_I128) if compute_u else None
+        _check(_lib.tm_bound_potential_execute_batch(self._h, _c_int(C), _c_int(N), _ptr(coords), _ptr(boxes), _ptr(du_dx), _ptr(u)))
+        r_dx = _fixed_to_float(du_dx).reshape(C, N, 3) if compute_du_dx else None
+        r_u = np.array([_energy_to_float(x) for x in u], dtype=np.float64) if compute_u else None
+        return r_dx, r_u
+
+    def execute_fixed(self, coords, box):
+        """-> uint64[1]: raw fixed-point energy, LLONG_MAX when overflowed; wrap_kernels.cpp:1275-1308."""
+        coords, box = _f64(coords, "coords"), _f64(box, "box")
+        N = coords.shape[0]
+        _verify_coords_and_box(coords, box)
+        u = np.zeros(1, dtype=_I128)
+        _check(_lib.tm_bound_potential_execute(self._h, _c_int(N), _ptr(coords), _ptr(box), None, _ptr(u)))
+        v = _i128_to_int(u[0])
+        if v >= _LLONG_MAX or v <= _LLONG_MIN:
+            v = _LLONG_MAX
+        return np.array([v & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Integrator:
+    """Base class (wrap_kernels.cpp:691-697)."""
+
+    _h = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_integrator_destroy(h)
+
+
+class LangevinIntegrator(Integrator):
+    """LangevinIntegrator(masses f64[N], temperature, dt, friction, seed); wrap_kernels.cpp:699-715 (<float> arithmetic)."""
+
+    def __init__(self, masses, temperature, dt, friction, seed):
+        m = _f64(masses, "masses")
+        self._h = _vp()
+        _check(_lib.tm_langevin_integrator_create(
+            _ptr(m), _c_int(m.size), _c_double(temperature), _c_double(dt), _c_double(friction), _c_int(int(seed)), ctypes.byref(self._h)))
+
+
+class Mover:
+    """Interface placeholder (wrap_kernels.cpp:1591-1617); no movers are implemented on this path yet."""
+
+
+class Context:
+    """Context(x0, v0, box, integrator, bps, movers=None); wrap_kernels.cpp:296-689."""
+
+    def __init__(self, x0, v0, box, integrator, bps, movers=None):
+        x0, v0, box = _f64(x0, "x0"), _f64(v0, "v0"), _f64(box, "box")
+        _verify_coords_and_box(x0, box)
+        if x0.shape[0] != v0.shape[0]:
+            raise RuntimeError("v0 N != x0 N")
+        if v0.ndim != 2 or x0.shape[1] != v0.shape[1]:
+            raise RuntimeError("v0 D != x0 D")
+        if movers:
+            raise NotImplementedError("movers (barostat, exchange moves) are outside the MI355X hot path for now")
+        if not isinstance(integrator, Integrator):
+            raise TypeError("integrator must be a custom_ops.Integrator")
+        bps = list(bps)
+        for bp in bps:
+            if not isinstance(bp, BoundPotential):
+                raise TypeError("bps must be custom_ops.BoundPotential instances")
+        self._integrator, self._bps, self._movers = integrator, bps, []
+        self._N = x0.shape[0]
+        arr = (_vp * len(bps))(*[bp._h.value for bp in bps])
+        self._h = _vp()
+        _check(_lib.tm_context_create(_ptr(x0), _ptr(v0), _ptr(box), _c_int(self._N), integrator._h, arr, _c_int(len(bps)), ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_context_destroy(h)
+
+    def step(self):
+        _check(_lib.tm_context_step(self._h))
+
+    def initialize(self):
+        _check(_lib.tm_context_initialize(self._h))
+
+    def finalize(self):
+        _check(_lib.tm_context_finalize(self._h))
+
+    def multiple_steps(self, n_steps, store_x_interval=0):
+        """-> (xs[F,N,3], boxes[F,3,3]), F = n_steps // (store_x_interval or n_steps); wrap_kernels.cpp:347-369."""
+        if store_x_interval < 0:
+            raise RuntimeError("store_x_interval must be greater than or equal to zero")
+        n_steps = int(n_steps)
+        x_interval = n_steps if store_x_interval == 0 else int(store_x_interval)
+        n_samples = n_steps // x_interval if x_interval > 0 else 0
+        xs = np.empty((n_samples, self._N, 3), dtype=np.float64)
+        boxes = np.empty((n_samples, 3, 3), dtype=np.float64)
+        _check(_lib.tm_context_multiple_steps(self._h, _c_int(n_steps), _c_int(n_samples), _ptr(xs), _ptr(boxes)))
+        return xs, boxes
+
+    def set_x_t(self, coords):
+        c = _f64(coords, "coords")
+        if c.shape[0] != self._N:
+            raise RuntimeError("number of new coords disagree with current coords")
+        _check(_lib.tm_context_set_x_t(self._h, _ptr(c)))
+
+    def set_v_t(self, velocities):
+        v = _f64(velocities, "velocities")
+        if v.shape[0] != self._N:
+            raise RuntimeError("number of new velocities disagree with current coords")
+        _check(_lib.tm_context_set_v_t(self._h, _ptr(v)))
+
+    def set_box(self, box):
+        b = _f64(box, "box")
+        if b.size != 9 or b.shape[0] != 3:
+            raise RuntimeError("box must be 3x3")
+        _check(_lib.tm_context_set_box(self._h, _ptr(b)))
+
+    def get_x_t(self):
+        out = np.empty((self._N, 3), dtype=np.float64)
+        _check(_lib.tm_context_get_x_t(self._h, _ptr(out)))
+        return out
+
+    def get_v_t(self):
+        out = np.empty((self._N, 3), dtype=np.float64)
+        _check(_lib.tm_context_get_v_t(self._h, _ptr(out)))
+        return out
+
+    def get_box(self):
+        out = np.empty((3, 3), dtype=np.float64)
+        _check(_lib.tm_context_get_box(self._h, _ptr(out)))
+        return out
+
+    def get_integrator(self):
+        return self._integrator
+
+    def get_potentials(self):
+        return list(self._bps)
+
+    def get_movers(self):
+        return list(self._movers)
+
+    def get_barostat(self):
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _Neighborlist:
+    """Neighborlist_f32/_f64(N); wrap_kernels.cpp:113-172."""
+
+    _prec = None
+
+    def __init__(self, N):
+        self._h = _vp()
+        _check(_lib.tm_neighborlist_create(_c_int(self._prec), _c_int(int(N)), ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_neighborlist_destroy(h)
+
+    def compute_block_bounds(self, coords, box, block_size):
+        if block_size != 32:
+            raise RuntimeError("Block size must be 32.")
+        coords, box = _f64(coords, "coords"), _f64(box, "box")
+        _verify_coords_and_box(coords, box)
+        N = coords.shape[0]
+        B = (N + block_size - 1) // block_size
+        ctrs, exts = np.empty((B, 3)), np.empty((B, 3))
+        _check(_lib.tm_neighborlist_compute_block_bounds(self._h, _c_int(N), _ptr(coords), _ptr(box), _c_int(block_size), _ptr(ctrs), _ptr(exts)))
+        return ctrs, exts
+
+    def get_nblist(self, coords, box, cutoff):
+        coords, box = _f64(coords, "coords"), _f64(box, "box")
+        _verify_coords_and_box(coords, box)
+        nrb, total = _c_int(0), _c_int(0)
+        _check(_lib.tm_neighborlist_get_nblist(self._h, _c_int(coords.shape[0]), _ptr(coords), _ptr(box), _c_double(cutoff), ctypes.byref(nrb), ctypes.byref(total)))
+        offsets = np.zeros(nrb.value + 1, dtype=np.int32)
+        atoms = np.zeros(max(total.value, 1), dtype=np.int32)
+        _check(_lib.tm_neighborlist_copy_nblist(self._h, _ptr(offsets), _ptr(atoms)))
+        return [atoms[offsets[r] : offsets[r + 1]].tolist() for r in range(nrb.value)]
+
+    def set_row_idxs(self, idxs):
+        i = _u32(idxs, "idxs")
+        _check(_lib.tm_neighborlist_set_row_idxs(self._h, _ptr(i), _c_int(i.size)))
+
+    def reset_row_idxs(self):
+        _check(_lib.tm_neighborlist_reset_row_idxs(self._h))
+
+    def resize(self, size):
+        _check(_lib.tm_neighborlist_resize(self._h, _c_int(int(size))))
+
+    def get_tile_ixn_count(self):
+        n = ctypes.c_uint(0)
+        _check(_lib.tm_neighborlist_get_tile_ixn_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def get_max_ixn_count(self):
+        n = _c_int(0)
+        _check(_lib.tm_neighborlist_get_max_ixn_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def get_num_row_idxs(self):
+        n = _c_int(0)
+        _check(_lib.tm_neighborlist_get_num_row_idxs(self._h, ctypes.byref(n)))
+        return n.value
+
+
+class Neighborlist_f32(_Neighborlist):
+    _prec = _F32
+
+
+class Neighborlist_f64(_Neighborlist):
+    _prec = _F64
+
+
+class HilbertSort:
+    """HilbertSort(size).sort(coords, box) -> uint32[N]; wrap_kernels.cpp:174-194."""
+
+    def __init__(self, size):
+        self._h = _vp()
+        _check(_lib.tm_hilbert_sort_create(_c_int(int(size)), ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_hilbert_sort_destroy(h)
+
+    def sort(self, coords, box):
+        coords, box = _f64(coords, "coords"), _f64(box, "box")
+        _verify_coords_and_box(coords, box)
+        perm = np.zeros(coords.shape[0], dtype=np.uint32)
+        _check(_lib.tm_hilbert_sort_sort(self._h, _c_int(coords.shape[0]), _ptr(coords), _ptr(box), _ptr(perm)))
+        return perm
+
+
+def hilbert_lut():
+    """Host-only: the 128^3 bin -> Hilbert index table (cpp/src/hilbert_sort.cu:18-31)."""
+    out = np.zeros(128 * 128 * 128, dtype=np.uint32)
+    _check(_lib.tm_hilbert_lut(_ptr(out)))
+    return out
+
+
+def profile_set_enabled(enabled):
+    _check(_lib.tm_profile_set_enabled(_c_int(1 if enabled else 0)))
+
+
+def profile_read(name="nonbonded_tiles"):
+    ms, n = _c_double(0), ctypes.c_longlong(0)
+    _check(_lib.tm_profile_read(name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+    return ms.value, n.value
+
+
+def profile_reset():
+    _check(_lib.tm_profile_reset())
+
+
+# Entries of the reference module that are outside the MI355X hot path: fail loudly, by name.
+def _not_on_hot_path(name):
+    class _Missing:
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"custom_ops.{name} is outside the MI355X hot path of timemachine_amd (see DESIGN.md, 'out of scope')")
+
+    _Missing.__name__ = name
+    return _Missing
+
+
+for _name in (
+    "NonbondedInteractionGroup_f32", "NonbondedInteractionGroup_f64", "NonbondedPairListPrecomputed_f32",
+    "NonbondedPairListPrecomputed_f64", "ChiralAtomRestraint_f32", "ChiralAtomRestraint_f64", "ChiralBondRestraint_f32",
+    "ChiralBondRestraint_f64", "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
+    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "MonteCarloBarostat", "VelocityVerletIntegrator", "BDExchangeMove_f32",
+    "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
+):
+    globals()[_name] = _not_on_hot_path(_name)

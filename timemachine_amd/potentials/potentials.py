@@ -1,0 +1,175 @@
+"""The hot-path potentials as dataclasses with the reference's names, fields and field order
+(reference: timemachine/potentials/potentials.py:17-31,94-161,203-304).
+"""
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+from numpy.typing import NDArray
+
+from ..lib import custom_ops
+from .potential import BoundGpuImplWrapper, BoundPotential, GpuImplWrapper, Potential, Precision
+
+
+@dataclass
+class HarmonicBond(Potential):
+    idxs: NDArray[np.int32]
+
+
+@dataclass
+class HarmonicAngle(Potential):
+    idxs: NDArray[np.int32]
+
+
+@dataclass
+class PeriodicTorsion(Potential):
+    idxs: NDArray[np.int32]
+
+
+def filter_exclusions(atom_idxs, exclusion_idxs, scale_factors, update_idxs: bool = False):
+    """Exclusions (and scales) whose two atoms are both in ``atom_idxs``.
+    reference: timemachine/potentials/nonbonded.py:176-218."""
+    atom_idxs_set = set(int(a) for a in atom_idxs)
+    map_to_filtered = {int(j): i for i, j in enumerate(atom_idxs)}
+    kept_idxs, kept_scales = [], []
+    for (i, j), sf in zip(np.asarray(exclusion_idxs), np.asarray(scale_factors)):
+        i, j = int(i), int(j)
+        if i not in atom_idxs_set or j not in atom_idxs_set:
+            continue
+        if update_idxs:
+            i, j = map_to_filtered[i], map_to_filtered[j]
+        kept_idxs.append((i, j))
+        kept_scales.append(sf)
+    filtered_exclusion_idxs = np.array(kept_idxs, dtype=np.int32)
+    filtered_scale_factors = np.array(kept_scales)
+    if not filtered_scale_factors.shape[0]:
+        filtered_scale_factors = filtered_scale_factors.reshape((0, np.asarray(scale_factors).shape[1]))
+        filtered_exclusion_idxs = filtered_exclusion_idxs.reshape((0, 2))
+    return filtered_exclusion_idxs, filtered_scale_factors
+
+
+@dataclass
+class Nonbonded(Potential):
+    """All pairs minus exclusions: on the GPU a FanoutSummedPotential([NonbondedAllPairs, NonbondedExclusions]) whose
+    second member subtracts scale * pair in fixed point (reference: potentials.py:94-138)."""
+
+    num_atoms: int
+    exclusion_idxs: NDArray[np.int32]
+    scale_factors: NDArray[np.float64]
+    beta: float
+    cutoff: float
+    atom_idxs: Optional[NDArray[np.int32]] = None
+    disable_hilbert_sort: bool = False
+    nblist_padding: float = 0.1
+
+    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
+        all_pairs = NonbondedAllPairs(
+            self.num_atoms,
+            self.beta,
+            self.cutoff,
+            atom_idxs=self.atom_idxs,
+            disable_hilbert_sort=self.disable_hilbert_sort,
+            nblist_padding=self.nblist_padding,
+        )
+        atom_idxs = self.atom_idxs if self.atom_idxs is not None else np.arange(self.num_atoms, dtype=np.int32)
+        exclusion_idxs, scale_factors = filter_exclusions(atom_idxs, self.exclusion_idxs, self.scale_factors)
+        exclusions = NonbondedExclusions(exclusion_idxs, scale_factors, self.beta, self.cutoff)
+        return FanoutSummedPotential([all_pairs, exclusions]).to_gpu(precision)
+
+
+@dataclass
+class NonbondedAllPairs(Potential):
+    num_atoms: int
+    beta: float
+    cutoff: float
+    atom_idxs: Optional[NDArray[np.int32]] = None
+    disable_hilbert_sort: bool = False
+    nblist_padding: float = 0.1
+
+    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
+        # astuple() would deep-copy/convert the optional index array; pass fields explicitly in constructor order
+        ctor = getattr(custom_ops, self._custom_ops_class_name(precision))
+        return GpuImplWrapper(
+            ctor(self.num_atoms, self.beta, self.cutoff, self.atom_idxs, self.disable_hilbert_sort, self.nblist_padding)
+        )
+
+
+@dataclass
+class NonbondedPairList(Potential):
+    idxs: NDArray[np.int32]
+    rescale_mask: NDArray[np.float64]
+    beta: float
+    cutoff: float
+
+
+@dataclass
+class NonbondedExclusions(Potential):
+    idxs: NDArray[np.int32]
+    rescale_mask: NDArray[np.float64]
+    beta: float
+    cutoff: float
+
+
+@dataclass
+class SummedPotential(Potential):
+    potentials: Sequence[Potential]
+    params_init: Sequence[NDArray]
+    parallel: bool = True
+
+    def __post_init__(self):
+        if len(self.potentials) != len(self.params_init):
+            raise ValueError("number of potentials != number of parameter arrays")
+
+    def to_gpu(self, precision: Precision) -> "SummedPotentialGpuImplWrapper":
+        impls = [p.to_gpu(precision).unbound_impl for p in self.potentials]
+        sizes = [int(np.asarray(ps).size) for ps in self.params_init]
+        return SummedPotentialGpuImplWrapper(custom_ops.SummedPotential(impls, sizes, self.parallel))
+
+    def call_with_params_list(self, conf, params: Sequence[NDArray], box) -> float:
+        params_flat = np.concatenate([np.asarray(ps).reshape(-1) for ps in params])
+        return self(conf, params_flat, box)
+
+    def bind_params_list(self, params: Sequence[NDArray]) -> BoundPotential["SummedPotential"]:
+        params_flat = np.concatenate([np.asarray(ps).reshape(-1) for ps in params])
+        return BoundPotential(self, params_flat)
+
+    @property
+    def params_shapes(self):
+        return [np.asarray(ps).shape for ps in self.params_init]
+
+    def unflatten_params(self, params):
+        out, off = [], 0
+        for shape in self.params_shapes:
+            n = int(np.prod(shape))
+            out.append(np.asarray(params)[off : off + n].reshape(shape))
+            off += n
+        return out
+
+
+def make_summed_potential(bps: Sequence[BoundPotential]):
+    potentials = [bp.potential for bp in bps]
+    params = [bp.params for bp in bps]
+    return SummedPotential(potentials, params).bind_params_list(params)
+
+
+@dataclass
+class SummedPotentialGpuImplWrapper(GpuImplWrapper):
+    """Flattens parameter lists before calling the kernel wrapper (reference: potentials.py:275-291)."""
+
+    def call_with_params_list(self, conf, params: Sequence[NDArray], box) -> float:
+        params_flat = np.concatenate([np.asarray(ps).reshape(-1) for ps in params])
+        return self(conf, params_flat, box)
+
+    def bind_params_list(self, params: Sequence[NDArray]) -> BoundGpuImplWrapper:
+        params_flat = np.concatenate([np.asarray(ps).reshape(-1) for ps in params])
+        return BoundGpuImplWrapper(custom_ops.BoundPotential(self.unbound_impl, params_flat))
+
+
+@dataclass
+class FanoutSummedPotential(Potential):
+    potentials: Sequence[Potential]
+    parallel: bool = True
+
+    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
+        impls = [p.to_gpu(precision).unbound_impl for p in self.potentials]
+        return GpuImplWrapper(custom_ops.FanoutSummedPotential(impls, self.parallel))
