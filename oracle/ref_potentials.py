@@ -74,8 +74,15 @@ def nonbonded_pairs_energy(conf, params, box, pairs, beta, cutoff, rescale=None)
     return lj.sum() + es.sum()
 
 
-def nonbonded_all_pairs_energy(conf, params, box, beta, cutoff, atom_idxs=None, block=512, accumulate_backward=False):
-    """All i<j pairs among ``atom_idxs`` (default: every atom); nonbonded.py:221-339 with no exclusions.
+def nonbonded_all_pairs_energy(
+    conf, params, box, beta, cutoff, atom_idxs=None, block=512, accumulate_backward=False, exclusion_idxs=None, scale_factors=None
+):
+    """All i<j pairs among ``atom_idxs`` (default: every atom); nonbonded.py:221-339.
+
+    Exclusions are applied the way the reference applies them -- each excluded pair's (es, lj) is MULTIPLIED by
+    (1 - scale) (convert_exclusions_to_rescale_masks, nonbonded.py:159-173, then nonbonded.py:337) -- not subtracted
+    afterwards: with clashing excluded atoms a subtraction would cancel catastrophically in floating point.
+    ``exclusion_idxs`` index into the full atom array (the caller filters them to ``atom_idxs``).
 
     With ``accumulate_backward`` the function calls ``.backward()`` per row block (memory O(block x N))
     and returns a python float; otherwise it returns a torch scalar that is still attached to the graph."""
@@ -83,6 +90,17 @@ def nonbonded_all_pairs_energy(conf, params, box, beta, cutoff, atom_idxs=None, 
     idx = torch.arange(N) if atom_idxs is None else torch.as_tensor(np.asarray(atom_idxs, dtype=np.int64))
     K = idx.shape[0]
     box_diag = None if box is None else torch.diagonal(box)
+    # position of every atom inside `idx` (-1: not interacting)
+    pos = np.full(N, -1, dtype=np.int64)
+    pos[idx.numpy()] = np.arange(K)
+    ex_lo = ex_hi = ex_q = ex_lj = None
+    if exclusion_idxs is not None and len(exclusion_idxs):
+        e = pos[np.asarray(exclusion_idxs, dtype=np.int64)]
+        sf = np.asarray(scale_factors, dtype=np.float64).reshape(-1, 2)
+        keep = (e >= 0).all(axis=1)
+        e, sf = e[keep], sf[keep]
+        ex_lo, ex_hi = np.minimum(e[:, 0], e[:, 1]), np.maximum(e[:, 0], e[:, 1])
+        ex_q, ex_lj = 1.0 - sf[:, 0], 1.0 - sf[:, 1]
     total = 0.0 if accumulate_backward else conf.sum() * 0.0
     for r0 in range(0, K, block):
         r1 = min(r0 + block, K)
@@ -98,6 +116,17 @@ def nonbonded_all_pairs_energy(conf, params, box, beta, cutoff, atom_idxs=None, 
         sig_ij = params[ri, 1][:, None] + params[cj, 1][None, :]
         eps_ij = params[ri, 2][:, None] * params[cj, 2][None, :]
         lj, es = _pair_energies(dij, qij, sig_ij, eps_ij, beta, cutoff)
+        if ex_lo is not None:
+            sel = (ex_lo >= r0) & (ex_lo < r1)
+            if sel.any():
+                mq = torch.ones_like(es)
+                ml = torch.ones_like(lj)
+                rr = torch.as_tensor(ex_lo[sel] - r0)
+                cc = torch.as_tensor(ex_hi[sel] - r0)
+                mq[rr, cc] = torch.as_tensor(ex_q[sel])  # later duplicates overwrite earlier ones, as in the reference
+                ml[rr, cc] = torch.as_tensor(ex_lj[sel])
+                es = es * mq
+                lj = lj * ml
         u = lj.sum() + es.sum()
         if accumulate_backward:
             u.backward()
@@ -121,15 +150,10 @@ def filter_exclusions(atom_idxs, exclusion_idxs, scale_factors):
 
 
 def nonbonded_energy(conf, params, box, exclusion_idxs, scale_factors, beta, cutoff, atom_idxs=None, block=512):
-    """nonbonded.py:221-339: all pairs, with each excluded pair's (es, lj) multiplied by (1 - scale)
-    (convert_exclusions_to_rescale_masks, nonbonded.py:159-173) == all pairs - sum_excl scale * pair."""
-    N = conf.shape[0]
-    u = nonbonded_all_pairs_energy(conf, params, box, beta, cutoff, atom_idxs, block)
-    ai = np.arange(N) if atom_idxs is None else np.asarray(atom_idxs)
-    ei, sf = filter_exclusions(ai, exclusion_idxs, scale_factors)
-    if len(ei):
-        u = u - nonbonded_pairs_energy(conf, params, box, ei, beta, cutoff, rescale=sf)
-    return u
+    """nonbonded.py:221-339: all pairs with each excluded pair's (es, lj) multiplied by (1 - scale)."""
+    return nonbonded_all_pairs_energy(
+        conf, params, box, beta, cutoff, atom_idxs, block, exclusion_idxs=exclusion_idxs, scale_factors=scale_factors
+    )
 
 
 def harmonic_bond_energy(conf, params, bond_idxs):
@@ -237,12 +261,10 @@ def periodic_torsion(conf, params, box, idxs):
 
 def nonbonded_forces_blocked(conf, params, box, beta, cutoff, exclusion_idxs=None, scale_factors=None, block=512):
     """du/dx (and u) of the full Nonbonded term for large N with O(block x N) memory: per-row-block
-    backward passes.  Used by bench.py's cpu_baseline leg and by large-N parity tests."""
+    backward passes.  Used by large-N parity tests."""
     x = _t(conf, True)
     p = _t(params, False)
-    u = nonbonded_all_pairs_energy(x, p, _t(box), beta, cutoff, None, block, accumulate_backward=True)
-    if exclusion_idxs is not None and len(exclusion_idxs):
-        ue = -nonbonded_pairs_energy(x, p, _t(box), exclusion_idxs, beta, cutoff, rescale=scale_factors)
-        ue.backward()
-        u += float(ue.detach())
+    u = nonbonded_all_pairs_energy(
+        x, p, _t(box), beta, cutoff, None, block, accumulate_backward=True, exclusion_idxs=exclusion_idxs, scale_factors=scale_factors
+    )
     return u, x.grad.numpy()
