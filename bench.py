@@ -50,6 +50,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=400)
     ap.add_argument("--windows", type=int, default=8, help="lambda windows of the end-of-run u_kl gather")
+    ap.add_argument("--equil-scale", type=float, default=1.0, help="scale the untimed equilibration (profiling runs)")
+    ap.add_argument("--equil-precision", choices=["f64", "f32"], default="f32")
+    ap.add_argument("--parallel-children", action="store_true", help="SummedPotential(parallel=True): children on forked HIP streams")
+    ap.add_argument("--separate-potentials", action="store_true", help="pass the potentials to Context one by one (serial) instead of one SummedPotential")
     return ap.parse_args()
 
 
@@ -67,13 +71,13 @@ def init_distributed(n_gpus):
     return rank, local_rank, world
 
 
-def equilibrate(co, LangevinIntegrator, system, make_bps, seed):
+def equilibrate(co, LangevinIntegrator, system, make_bps, seed, scale=1.0, prec=np.float32):
     """Lattice start -> liquid: short, strongly thermostatted stages with growing time step (untimed)."""
     x, v, box = system.coords.copy(), np.zeros_like(system.coords), system.box
     for dt, friction, steps in ((0.1e-3, 100.0, 600), (0.5e-3, 50.0, 600), (1.0e-3, 10.0, 800), (DT, FRICTION, 1000)):
-        bps = make_bps(np.float32)
+        bps = make_bps(prec)
         ctxt = co.Context(x, v, box, LangevinIntegrator(TEMPERATURE, dt, friction, system.masses, seed).impl(), bps)
-        ctxt.multiple_steps(steps, 0)
+        ctxt.multiple_steps(max(int(steps * scale), 1), 0)
         x, v = ctxt.get_x_t(), ctxt.get_v_t()
         if not np.all(np.isfinite(x)):
             raise RuntimeError(f"equilibration diverged at dt={dt}")
@@ -133,6 +137,30 @@ def cpu_baseline(system, x, cutoff):
     }
 
 
+def _walk(pot):
+    yield pot
+    if hasattr(pot, "get_potentials"):
+        for c in pot.get_potentials():
+            yield from _walk(c)
+
+
+def find_all_pairs(bps):
+    for bp in bps:
+        for p in _walk(bp.get_potential()):
+            if type(p).__name__.startswith("NonbondedAllPairs"):
+                return p
+    raise RuntimeError("no NonbondedAllPairs in the state")
+
+
+def find_nonbonded(bps):
+    """the FanoutSummedPotential([AllPairs, Exclusions]) that Nonbonded.to_gpu builds"""
+    for bp in bps:
+        for p in _walk(bp.get_potential()):
+            if type(p).__name__ == "FanoutSummedPotential":
+                return p
+    raise RuntimeError("no Nonbonded in the state")
+
+
 def main():
     args = parse_args()
     rank, local_rank, world = init_distributed(args.gpus)
@@ -154,10 +182,16 @@ def main():
     N = system.num_atoms
 
     def make_bps(prec):
-        return [bp.to_gpu(prec).bound_impl for bp in ts.bound_potentials(system, prec)]
+        # one SummedPotential for the whole state, children on forked streams -- how the reference packs a state
+        # (fe/free_energy.py:614-657: make_summed_potential(...).to_gpu(np.float32) -> one BoundPotential)
+        bps = ts.bound_potentials(system, prec)
+        if args.separate_potentials:
+            return [bp.to_gpu(prec).bound_impl for bp in bps]
+        summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps], parallel=args.parallel_children)
+        return [summed.bind_params_list([bp.params for bp in bps]).to_gpu(prec).bound_impl]
 
     seed = 1234 + rank
-    x, v = equilibrate(co, LangevinIntegrator, system, make_bps, seed)
+    x, v = equilibrate(co, LangevinIntegrator, system, make_bps, seed, args.equil_scale, np.float64 if args.equil_precision == "f64" else np.float32)
 
     def run(prec, steps, warmup, profile_steps):
         bps = make_bps(prec)
@@ -183,7 +217,7 @@ def main():
             total_ms, launches = co.profile_read("nonbonded_tiles")
             co.profile_set_enabled(False)
             co.profile_reset()
-            nb = bps[-1].get_potential().get_potentials()[0]
+            nb = find_all_pairs(bps)
             prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": nb.get_tile_ixn_count()}
         return elapsed, xf, ctxt, bps, prof
 
@@ -197,7 +231,7 @@ def main():
     my_windows = parallel.windows_for_rank(world, world, rank)  # one replica per rank
     lambdas = np.linspace(0.0, 1.0, n_windows)
     params_l = np.stack([system.nb_params * np.array([1.0 - 0.1 * lam, 1.0, 1.0, 1.0]) for lam in lambdas])
-    nb_pot = bps[-1].get_potential()
+    nb_pot = find_nonbonded(bps)
     _, _, u_row = nb_pot.execute_batch(xf[None], params_l, system.box[None], False, False, True)
     kT = 0.008314462618 * TEMPERATURE
     u_kl = parallel.gather_rows(my_windows, u_row.reshape(1, -1) / kT, world)

@@ -94,6 +94,9 @@ int tm_nonbonded_all_pairs_get_num_atom_idxs(tm_potential_t pot, int *count);
 int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int cap);
 /* tiles (32 rows x 32 columns) in the current interaction list; diagnostic used by bench.py */
 int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count);
+/* per-wave cycle counters of the last tile-kernel launch: [waves][8] = {setup, phase1, phase2, flush, items, batches, total, 0};
+ * all zero unless the library was built with -DTM_TIMING (development aid, see scripts/ablate.py) */
+int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n);
 
 /* ---- potentials: evaluation --------------------------------------------------------------------------------
  * Potential.execute(coords[N,3], params[P], box[3,3], compute_du_dx, compute_du_dp, compute_u)

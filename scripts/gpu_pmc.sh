@@ -1,0 +1,41 @@
+#!/bin/bash
+# PMC counter passes (each in its own run, counters only -- never combined with sys/hip/hsa traces).
+set -u
+mkdir -p gpurun_out/pmc
+export TMPDIR=/tmp
+ROOT=$GRAFT_REPO_ROOT
+CMD="python $ROOT/bench.py --steps ${PMC_STEPS:-200} --warmup 10 --no-cpu-baseline --profile-steps 0 --equil-scale 0.2 --equil-precision ${PMC_PREC:-f64} --precision ${PMC_PREC:-f64} ${BENCH_ARGS:-}"
+cd /tmp
+pass() { # name, counters...
+  name=$1; shift
+  timeout 900 rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc/$name -o $name -- $CMD > $ROOT/gpurun_out/pmc/$name.log 2>&1
+  echo "pmc pass $name exit $?"
+}
+pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS
+pass sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+cd $ROOT
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob('gpurun_out/pmc/*/*counter_collection.csv')):
+    rows=list(csv.DictReader(open(f)))
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+    for r in rows:
+        k=r['Kernel_Name'].split('(')[0].replace('void tmamd::','')[:44]
+        agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+    disp=collections.Counter()
+    seen=set()
+    for r in rows:
+        k=r['Kernel_Name'].split('(')[0].replace('void tmamd::','')[:44]
+        key=(k,r['Dispatch_Id'])
+        if key not in seen:
+            seen.add(key); disp[k]+=1
+    print('==',f)
+    with open(f.replace('_counter_collection.csv','_summary.txt'),'w') as out:
+        for k in sorted(agg, key=lambda k:-disp[k]):
+            line=f"{k:46s} n={disp[k]:5d} "+' '.join(f"{c}={v/disp[k]:.5g}" for c,v in sorted(agg[k].items()))
+            out.write(line+"\n")
+            if 'tiles' in k or 'find_ixns' in k: print(line)
+PY
+find gpurun_out/pmc -name "*counter_collection.csv" -delete; find gpurun_out/pmc -name "*.db" -delete; du -sh gpurun_out

@@ -43,6 +43,26 @@ def _compile(src):
     return src, obj, r.returncode, r.stdout + r.stderr
 
 
+def build_variant(tag, defines):
+    """debug/ablation variant: lib<...>_<tag>.so with extra -D flags (selected at run time with TM_AMD_LIB)"""
+    out = os.path.join(HERE, f"libtimemachine_amd_{tag}.so")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, os.path.splitext(src)[0] + f".{tag}.o")
+        cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout + r.stderr, file=sys.stderr)
+            raise RuntimeError(f"hipcc failed on {src}")
+        objs.append(obj)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed")
+    for o in objs:
+        os.remove(o)
+    return out
+
+
 def build(force=False, verbose=True):
     stamp_file = os.path.join(HERE, ".build_stamp")
     stamp = _stamp()
@@ -67,4 +87,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2 :]))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -258,6 +258,17 @@ int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int c
     TM_CATCH
 }
 
+int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) {
+        std::vector<long long> v = p.debug_timing();
+        *n = static_cast<int>(v.size());
+        for (int i = 0; i < cap && i < static_cast<int>(v.size()); i++)
+            out[i] = v[i];
+    });
+    TM_CATCH
+}
+
 int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count) {
     TM_TRY
     with_all_pairs(pot, [&](auto &p) { *count = p.num_tile_ixns(); });

@@ -239,6 +239,7 @@ public:
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
+    std::vector<long long> debug_timing(); // [grid][8] raw counters of the last tile-kernel launch (TM_TIMING builds)
 
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
@@ -260,6 +261,8 @@ private:
     DeviceBuffer<double> d_snap_x_, d_snap_box_;
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;
+    DeviceBuffer<unsigned int> d_work_ctr_;
+    DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
 };
 
 void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);

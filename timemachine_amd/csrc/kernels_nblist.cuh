@@ -18,9 +18,12 @@
 
 namespace tmamd {
 
-// K2: block bounds (thread per block: the fold is inherently sequential), coordinate snapshot and counter reset.
+// K2: block bounds (one wave per 32-atom block), coordinate snapshot and counter reset.
+// The running min/max fold is inherently sequential (each atom is re-imaged around the CURRENT centre), so every lane
+// of the wave runs the same fold on shuffled-in positions: lanes 0-31 load one atom each (coalesced), no LDS, no
+// divergence, and the 32 dependent global loads of a thread-per-block version collapse into one.
 template <typename Real>
-__global__ void k_block_bounds(
+__global__ __launch_bounds__(256) void k_block_bounds(
     const int n_col_blocks, const int NC, const unsigned int *__restrict__ col_idxs, // nullptr => identity
     const int n_row_blocks, const int NR, const unsigned int *__restrict__ row_idxs, // only used when rows != cols
     const int rows_equal_cols, const Real *__restrict__ gathered, const double *__restrict__ box,
@@ -47,50 +50,65 @@ __global__ void k_block_bounds(
         }
     }
     const int total_blocks = n_col_blocks + (rows_equal_cols ? 0 : n_row_blocks);
-    if (tid >= total_blocks) {
-        return;
-    }
-    const bool is_row = tid >= n_col_blocks;
-    const int blk = is_row ? tid - n_col_blocks : tid;
-    const unsigned int *idxs = is_row ? row_idxs : col_idxs;
-    const int count = is_row ? NR : NC;
+    const int lane = threadIdx.x & 63;
     const NbBox<Real> bx = load_box<Real>(box);
     const Real half = static_cast<Real>(0.5);
-
-    const int first = blk * TILE;
-    const int n = (count - first) < TILE ? (count - first) : TILE;
-    Real lo[3], hi[3];
-    {
-        const unsigned int a = idxs ? idxs[first] : static_cast<unsigned int>(first);
-        for (int d = 0; d < 3; d++) {
-            lo[d] = hi[d] = gathered[static_cast<size_t>(a) * 8 + d];
+    const Real b[3] = {bx.x, bx.y, bx.z};
+    const Real ib[3] = {bx.inv_x, bx.inv_y, bx.inv_z};
+    for (int wblk = tid >> 6; wblk < total_blocks; wblk += nthreads >> 6) {
+        const bool is_row = wblk >= n_col_blocks;
+        const int blk = is_row ? wblk - n_col_blocks : wblk;
+        const unsigned int *idxs = is_row ? row_idxs : col_idxs;
+        const int count = is_row ? NR : NC;
+        const int first = blk * TILE;
+        const int n = (count - first) < TILE ? (count - first) : TILE;
+        Real p[3] = {0, 0, 0};
+        if (lane < n) {
+            const unsigned int a = idxs ? idxs[first + lane] : static_cast<unsigned int>(first + lane);
+            for (int d = 0; d < 3; d++) {
+                p[d] = gathered[static_cast<size_t>(a) * 8 + d];
+            }
         }
-    }
-    // visiting order of the reference's lane rotation: atoms 1, 2, ..., n-1, then atom 0 again
-    for (int k = 1; k <= n; k++) {
-        const int kk = k == n ? 0 : k;
-        const unsigned int a = idxs ? idxs[first + kk] : static_cast<unsigned int>(first + kk);
-        const Real p[3] = {gathered[static_cast<size_t>(a) * 8 + 0], gathered[static_cast<size_t>(a) * 8 + 1], gathered[static_cast<size_t>(a) * 8 + 2]};
-        const Real b[3] = {bx.x, bx.y, bx.z};
-        const Real ib[3] = {bx.inv_x, bx.inv_y, bx.inv_z};
+        Real lo[3], hi[3];
         for (int d = 0; d < 3; d++) {
-            const Real img = p[d] - b[d] * nearbyint((p[d] - half * (hi[d] + lo[d])) * ib[d]);
-            lo[d] = min(lo[d], img);
-            hi[d] = max(hi[d], img);
+            lo[d] = hi[d] = __shfl(p[d], 0, 64);
         }
-    }
-    Real *ctr = is_row ? row_ctr : col_ctr;
-    Real *ext = is_row ? row_ext : col_ext;
-    for (int d = 0; d < 3; d++) {
-        ctr[blk * 3 + d] = half * (hi[d] + lo[d]);
-        ext[blk * 3 + d] = half * (hi[d] - lo[d]);
+        // visiting order of the reference's lane rotation: atoms 1, 2, ..., n-1, then atom 0 again
+        for (int k = 1; k <= n; k++) {
+            const int kk = k == n ? 0 : k;
+            for (int d = 0; d < 3; d++) {
+                const Real pd = __shfl(p[d], kk, 64);
+                const Real img = pd - b[d] * nearbyint((pd - half * (hi[d] + lo[d])) * ib[d]);
+                lo[d] = min(lo[d], img);
+                hi[d] = max(hi[d], img);
+            }
+        }
+        if (lane < 3) {
+            Real *ctr = is_row ? row_ctr : col_ctr;
+            Real *ext = is_row ? row_ext : col_ext;
+            // every lane holds the same lo/hi; lane d writes component d
+            const Real l = lane == 0 ? lo[0] : (lane == 1 ? lo[1] : lo[2]);
+            const Real h = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : hi[2]);
+            ctr[blk * 3 + lane] = half * (h + l);
+            ext[blk * 3 + lane] = half * (h - l);
+        }
     }
 }
 
-// K3: per row block, find interacting column atoms.
-//   dynamic LDS: ceil(n_col_blocks / 64) 64-bit words holding the coarse (bbox-bbox) pass bitmap.
+// K3: per row block, find interacting column atoms.  One NBL_THREADS-thread workgroup (16 waves) per row block.
+//   pass 0  count the column blocks whose bounding box is within the list cutoff of the row block's box and claim a
+//           pool segment big enough for all their atoms with ONE atomic
+//   pass 1  per chunk of NBL_CHUNK column blocks: compact the passing block ids into an LDS list (ballot + popcount)
+//   pass 2  the waves stride over the list two column blocks at a time (lanes 0-31 / 32-63 = one column atom
+//           each).  As in the reference, row atoms are first filtered against the column block's box
+//           (k_neighborlist.cuh:349-365), here with one (row atom, column block) test per lane and two 32-bit row masks;
+//           every lane then walks only the set bits of its half's mask, and the wave leaves as soon as all of its
+//           lanes have found a partner.
+static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
+static const int NBL_THREADS = 1024; // 16 waves per row block: the per-row-block critical path is what bounds this kernel
+
 template <typename Real, bool UPPER_TRIANGULAR>
-__global__ __launch_bounds__(256) void k_find_ixns(
+__global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     const int K, const int NC, const int NR, const unsigned int *__restrict__ col_idxs, const unsigned int *__restrict__ row_idxs,
     const Real *__restrict__ col_ctr, const Real *__restrict__ col_ext, const Real *__restrict__ row_ctr,
     const Real *__restrict__ row_ext, const Real *__restrict__ gathered, const double *__restrict__ box, const double cutoff_d,
@@ -100,26 +118,23 @@ __global__ __launch_bounds__(256) void k_find_ixns(
     if (!force && *flag == 0) {
         return;
     }
-    extern __shared__ u64 s_bitmap[];
+    __shared__ int s_list[NBL_CHUNK];
     __shared__ Real s_rx[TILE], s_ry[TILE], s_rz[TILE];
-    __shared__ unsigned int s_npass, s_count, s_seg_start, s_item_base;
-    __shared__ int s_nrow;
+    __shared__ unsigned int s_npass, s_nlist, s_count, s_seg_start, s_item_base;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int rb = blockIdx.x;
     const int n_col_blocks = (NC + TILE - 1) / TILE;
-    const int n_words = (n_col_blocks + 63) / 64;
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
+    const int nrow = (NR - rb * TILE) < TILE ? (NR - rb * TILE) : TILE;
 
     if (tid == 0) {
         s_npass = 0;
         s_count = 0;
-        const int rem = NR - rb * TILE;
-        s_nrow = rem < TILE ? rem : TILE;
     }
     if (tid < TILE) {
         const int ridx = rb * TILE + tid;
@@ -134,69 +149,105 @@ __global__ __launch_bounds__(256) void k_find_ixns(
     }
     __syncthreads();
 
-    // ---- coarse pass: row bbox vs every column bbox (k_neighborlist.cuh:296-329)
     const Real rcx = row_ctr[rb * 3 + 0], rcy = row_ctr[rb * 3 + 1], rcz = row_ctr[rb * 3 + 2];
     const Real rex = row_ext[rb * 3 + 0], rey = row_ext[rb * 3 + 1], rez = row_ext[rb * 3 + 2];
+    const int cb_first = UPPER_TRIANGULAR ? rb : 0;
+
+    // row bbox vs column bbox (k_neighborlist.cuh:296-329)
+    auto coarse = [&](int cb) -> bool {
+        if (cb >= n_col_blocks) {
+            return false;
+        }
+        Real ddx = min_image(rcx - col_ctr[cb * 3 + 0], bx.x, bx.inv_x);
+        Real ddy = min_image(rcy - col_ctr[cb * 3 + 1], bx.y, bx.inv_y);
+        Real ddz = min_image(rcz - col_ctr[cb * 3 + 2], bx.z, bx.inv_z);
+        ddx = max(static_cast<Real>(0), fabs(ddx) - rex - col_ext[cb * 3 + 0]);
+        ddy = max(static_cast<Real>(0), fabs(ddy) - rey - col_ext[cb * 3 + 1]);
+        ddz = max(static_cast<Real>(0), fabs(ddz) - rez - col_ext[cb * 3 + 2]);
+        return (ddx * ddx + ddy * ddy + ddz * ddz) < cutoff2;
+    };
+
+    // ---- pass 0: count, then one pool claim per row block
     unsigned int my_pass = 0;
-    for (int w = wave; w < n_words; w += 4) {
-        const int cb = w * 64 + lane;
-        bool pass = cb < n_col_blocks && (!UPPER_TRIANGULAR || cb >= rb);
-        if (pass) {
-            Real ddx = min_image(rcx - col_ctr[cb * 3 + 0], bx.x, bx.inv_x);
-            Real ddy = min_image(rcy - col_ctr[cb * 3 + 1], bx.y, bx.inv_y);
-            Real ddz = min_image(rcz - col_ctr[cb * 3 + 2], bx.z, bx.inv_z);
-            ddx = max(static_cast<Real>(0), fabs(ddx) - rex - col_ext[cb * 3 + 0]);
-            ddy = max(static_cast<Real>(0), fabs(ddy) - rey - col_ext[cb * 3 + 1]);
-            ddz = max(static_cast<Real>(0), fabs(ddz) - rez - col_ext[cb * 3 + 2]);
-            pass = (ddx * ddx + ddy * ddy + ddz * ddz) < cutoff2;
-        }
-        const u64 m = __ballot(pass);
-        if (lane == 0) {
-            s_bitmap[w] = m;
-            my_pass += __popcll(m);
-        }
+    for (int cb0 = cb_first; cb0 < n_col_blocks; cb0 += NBL_THREADS) {
+        const u64 m = __ballot(coarse(cb0 + tid));
+        my_pass += __popcll(m);
     }
     if (lane == 0 && my_pass) {
         atomicAdd(&s_npass, my_pass);
     }
     __syncthreads();
     if (tid == 0) {
-        // one pool claim per row block, sized by the coarse upper bound (never more than 32 * passing blocks)
         s_seg_start = atomicAdd(&counters[0], s_npass * TILE);
     }
     __syncthreads();
     const unsigned int seg_start = s_seg_start;
-    const int nrow = s_nrow;
 
-    // ---- fine pass: two column blocks per wave iteration (lanes 0-31 / 32-63)
-    for (int w = wave; w < n_words; w += 4) {
-        u64 m = s_bitmap[w];
-        while (m) {
-            const int a0 = __builtin_ctzll(m);
-            m &= m - 1;
-            int a1 = -1;
+    for (int chunk0 = cb_first; chunk0 < n_col_blocks; chunk0 += NBL_CHUNK) {
+        // ---- pass 1: compact the passing column blocks of this chunk into s_list
+        if (tid == 0) {
+            s_nlist = 0;
+        }
+        __syncthreads();
+        const int chunk_end = (chunk0 + NBL_CHUNK) < n_col_blocks ? (chunk0 + NBL_CHUNK) : n_col_blocks;
+        for (int cb0 = chunk0; cb0 < chunk_end; cb0 += NBL_THREADS) {
+            const int cb = cb0 + tid;
+            const bool pass = cb < chunk_end && coarse(cb);
+            const u64 m = __ballot(pass);
             if (m) {
-                a1 = __builtin_ctzll(m);
-                m &= m - 1;
-            }
-            const int sel = lane < 32 ? a0 : a1;
-            unsigned int ja = K;
-            if (sel >= 0) {
-                const int jpos = (w * 64 + sel) * TILE + (lane & 31);
-                if (jpos < NC) {
-                    ja = col_idxs ? col_idxs[jpos] : static_cast<unsigned int>(jpos);
+                unsigned int base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&s_nlist, static_cast<unsigned int>(__popcll(m)));
+                }
+                base = __shfl(base, 0, 64);
+                if (pass) {
+                    s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = cb;
                 }
             }
+        }
+        __syncthreads();
+        const int nlist = s_nlist;
+
+        // ---- pass 2: two column blocks per wave iteration
+        const int half_id = lane >> 5; // 0: lanes 0-31, 1: lanes 32-63
+        const int sub = lane & 31;
+        for (int k = wave * 2; k < nlist; k += 2 * (NBL_THREADS / 64)) {
+            const int my_entry = k + half_id;
+            const int cb = my_entry < nlist ? s_list[my_entry] : -1;
+            unsigned int ja = K;
+            Real xj = 0, yj = 0, zj = 0;
+            bool row_near = false; // is row atom `sub` within the cutoff of column block cb's box?
+            if (cb >= 0) {
+                const int jpos = cb * TILE + sub;
+                if (jpos < NC) {
+                    ja = col_idxs ? col_idxs[jpos] : static_cast<unsigned int>(jpos);
+                    xj = gathered[static_cast<size_t>(ja) * 8 + 0];
+                    yj = gathered[static_cast<size_t>(ja) * 8 + 1];
+                    zj = gathered[static_cast<size_t>(ja) * 8 + 2];
+                }
+                if (sub < nrow) {
+                    Real ax = min_image(s_rx[sub] - col_ctr[cb * 3 + 0], bx.x, bx.inv_x);
+                    Real ay = min_image(s_ry[sub] - col_ctr[cb * 3 + 1], bx.y, bx.inv_y);
+                    Real az = min_image(s_rz[sub] - col_ctr[cb * 3 + 2], bx.z, bx.inv_z);
+                    ax = max(static_cast<Real>(0), fabs(ax) - col_ext[cb * 3 + 0]);
+                    ay = max(static_cast<Real>(0), fabs(ay) - col_ext[cb * 3 + 1]);
+                    az = max(static_cast<Real>(0), fabs(az) - col_ext[cb * 3 + 2]);
+                    row_near = (ax * ax + ay * ay + az * az) < cutoff2;
+                }
+            }
+            const u64 near = __ballot(row_near);
+            unsigned int rows = half_id ? static_cast<unsigned int>(near >> 32) : static_cast<unsigned int>(near);
+            const bool live = ja < static_cast<unsigned int>(K);
             bool interacts = false;
-            if (ja < static_cast<unsigned int>(K)) {
-                const Real xj = gathered[static_cast<size_t>(ja) * 8 + 0];
-                const Real yj = gathered[static_cast<size_t>(ja) * 8 + 1];
-                const Real zj = gathered[static_cast<size_t>(ja) * 8 + 2];
-                for (int i = 0; i < nrow && !interacts; i++) {
+            // all lanes of a half share `rows`; the loop is uniform across the wave (max of the two popcounts)
+            while (__ballot(rows != 0 && live && !interacts)) {
+                if (rows != 0) {
+                    const int i = __builtin_ctz(rows);
+                    rows &= rows - 1;
                     const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
                     const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
                     const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
-                    interacts = (dx * dx + dy * dy + dz * dz) < cutoff2;
+                    interacts = interacts || (live && (dx * dx + dy * dy + dz * dz) < cutoff2);
                 }
             }
             const u64 hits = __ballot(interacts);
@@ -211,8 +262,8 @@ __global__ __launch_bounds__(256) void k_find_ixns(
                 }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // ---- publish the segment and its work items
     const unsigned int count = s_count;

@@ -10,10 +10,13 @@
 //
 // Tile kernel design (one wave = one 64-thread workgroup per work item, grid-stride):
 //   phase 1  every lane owns one column atom in registers; 32 rounds, lane l meets row (round + l) & 31
-//            (rotation => the rows, and the columns, hit in one round are all distinct); the cheap distance test
-//            (`d2 < cutoff^2`, strict) is evaluated for all 32x64 slots; survivors are compacted with
+//            (rotation => the rows, and the columns, hit in one round are all distinct).  All 32x64 slots get a CHEAP,
+//            CONSERVATIVE distance filter in f32 on coordinates taken relative to the tile's first row atom (so f32
+//            resolution does not depend on how far the unwrapped coordinates have drifted): it keeps every pair whose
+//            exact d2 could be below cutoff^2 (margin >> f32 rounding error).  Survivors are compacted with
 //            ballot + popcount into an LDS queue of (row, col) byte pairs.
-//   phase 2  whenever >= 64 pairs are queued, all 64 lanes pop one pair each and run the expensive
+//   phase 2  whenever >= 64 pairs are queued, all 64 lanes pop one pair each, redo the distance in Real precision
+//            with the exact strict test `d2 < cutoff^2` (the only test that decides anything), and run the expensive
 //            erfc/exp/sincos path at full lane occupancy (the reference leaves ~2/3 of the lanes idle inside
 //            its `if (d2 < cutoff^2)` branch); results are converted to fixed point and added with LDS u64
 //            atomics into per-tile row / column accumulators.
@@ -24,7 +27,15 @@
 
 namespace tmamd {
 
-static const int NB_CHUNK = 64; // columns per work item == wave width
+// Waves per SIMD the tile kernel is register-budgeted for (512 / waves VGPRs per lane).  f64: the pair math plus the
+// VGPR-resident erfcx coefficients need ~130 registers -- 3 waves without spills beats 4 waves with 60+ spilled
+// dwords (measured: 148 vs 167 us per launch at 23.5k atoms).  f32: ~80 registers -> 5 waves.
+template <typename Real> struct TileWaves {
+    static const int value = sizeof(Real) == 8 ? 3 : 5;
+};
+static const int NB_CHUNK = 64;        // columns per work item == wave width
+static const int NB_SHARDS = 8;        // dynamic work queues for the tile kernel, one per XCD (blockIdx % 8)
+static const int NB_SHARD_STRIDE = 16; // queue heads live in separate 64-byte lines
 
 template <typename Real> struct NbBox {
     Real x, y, z, inv_x, inv_y, inv_z;
@@ -42,9 +53,14 @@ template <typename Real> __device__ __forceinline__ NbBox<Real> load_box(const d
 }
 
 // d2 in 4D; one definition shared by every kernel (the strict cutoff test must see identical bits everywhere).
-template <typename Real> __device__ __forceinline__ Real pair_d2(Real dx, Real dy, Real dz, Real dw) {
-    return dx * dx + dy * dy + dz * dz + dw * dw;
+__device__ __forceinline__ double pair_d2(double dx, double dy, double dz, double dw) {
+    return __builtin_fma(dw, dw, __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)));
 }
+__device__ __forceinline__ float pair_d2(float dx, float dy, float dz, float dw) {
+    return __builtin_fmaf(dw, dw, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+}
+__device__ __forceinline__ void lds_add(u64 *p, u64 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_sub(u64 *p, u64 v) { __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // ---- K1: rebuild check + gather (+ zero the Hilbert-order accumulators) -------------------------------------
 // reference: k_check_rebuild_coords_and_box_gather + k_gather_coords_and_params (k_nonbonded.cuh:12-84)
@@ -54,10 +70,16 @@ __global__ void k_check_gather(
     const double *__restrict__ box, const double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double pad2_quarter, // 0.25 * padding^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp) {
+    u64 *__restrict__ g_du_dp, unsigned int *__restrict__ work_ctr) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
+    }
+    if (idx < NB_SHARDS) {
+        work_ctr[idx * NB_SHARD_STRIDE] = 0; // the tile kernel's dynamic work queues (consumed later in this call)
+    }
+    if (idx < 8) {
+        gathered[static_cast<size_t>(K) * 8 + idx] = 0; // sentinel record: padded list slots point here
     }
     if (idx < 9) {
         if (snap_box[idx] != box[idx]) {
@@ -114,15 +136,26 @@ __global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ pe
 }
 
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
+// Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
+template <typename Real> struct TileRegs {
+    int rb, ccount;
+    unsigned int ja;  // this lane's column atom (K = padding)
+    unsigned int ra;  // lanes 0-31: this lane's row atom (K = beyond NR)
+    Real cj[7];       // column atom record
+    Real rr[7];       // lanes 0-31: row atom record
+    Real ox, oy, oz;  // tile origin (first row atom)
+};
+
 template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP>
-__global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
-    const int K,                               // atoms in `gathered` (sentinel index == K)
+__global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
+    const int K,                               // atoms in `gathered` (record K is an all-zero sentinel)
     const int NR,                              // number of row atoms
     const int upper_triangular,                // rows == cols == all: keep only row < col
     const unsigned int *__restrict__ row_idxs, // [NR] or nullptr (identity)
     const unsigned int *__restrict__ n_items_ptr, const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials) {
+    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials, unsigned int *__restrict__ work_ctr,
+    long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
     __shared__ Real s_row[7][TILE];
     __shared__ Real s_col[7][NB_CHUNK];
@@ -131,7 +164,8 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
     __shared__ u64 s_fj[COMPUTE_DU_DX ? 3 : 1][NB_CHUNK];
     __shared__ u64 s_pi[COMPUTE_DU_DP ? 4 : 1][TILE];
     __shared__ u64 s_pj[COMPUTE_DU_DP ? 4 : 1][NB_CHUNK];
-    __shared__ unsigned short s_queue[2 * NB_CHUNK];
+    __shared__ unsigned short s_queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // up to 4 rounds are appended between drains
+    __shared__ float4 s_rowf[TILE]; // phase-1 copy of the row atoms: (x, y, z, w) relative to the tile origin, f32
 
     const int lane = threadIdx.x;
     const NbBox<Real> bx = load_box<Real>(box);
@@ -139,24 +173,110 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
     const Real cutoff2 = cutoff * cutoff;
     const Real beta = static_cast<Real>(beta_d);
     i128 energy = 0;
+    // phase-1 filter in f32: box, and a cutoff^2 padded far beyond the rounding error of the filter arithmetic
+    const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
+    const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
+    const float fmaxb = fmaxf(fbx, fmaxf(fby, fbz));
+    const float fcut2 = static_cast<float>(cutoff_d * cutoff_d) + 1e-5f * (1.0f + fmaxb) * (1.0f + static_cast<float>(cutoff_d));
 
+    // Dynamic work distribution.  Work items differ in cost by an order of magnitude (0..2048 interacting pairs), and a
+    // wave only gets a handful of them, so a static grid-stride assignment leaves the average wave idle ~40 % of the
+    // kernel while the unluckiest one finishes.  Items are dealt round-robin into NB_SHARDS queues (item % 8); a wave
+    // pulls from the queue of its XCD (blockIdx % 8: atomics stay on one die).
+    //
+    // Software pipeline over items.  Fetching an item is a chain of dependent memory operations
+    //   ticket (atomic) -> items[] -> col_atoms[] -> gathered[]
+    // which costs several microseconds when paid up front.  Instead, while item k is being computed:
+    //   stage A (start of k)   items[k+1] is requested (its ticket was taken during k-1); the ticket for k+2 is taken
+    //   stage B, C (end of k)  column / row atom indices of k+1, then its atom records, are requested -- after k's
+    //                          heavy phase (no extra live registers there) but BEFORE k's flush atomics are issued
+    // so one L2 round trip (the index load) is exposed per item instead of four dependent hops.
     const unsigned int n_items = *n_items_ptr;
-    for (unsigned int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int4 it = items[item];
-        const int rb = it.x, cstart = it.y, ccount = it.z;
+    const unsigned int shard = blockIdx.x & (NB_SHARDS - 1);
+    unsigned int *ticket_ptr = work_ctr + shard * NB_SHARD_STRIDE;
+    const unsigned int uK = static_cast<unsigned int>(K);
 
-        __syncthreads(); // previous item's flush has finished reading LDS
+    auto take_ticket = [&]() -> unsigned int { // returns the ITEM index (>= n_items when the queue is exhausted)
+        unsigned int t = 0;
+        if (lane == 0) {
+            t = atomicAdd(ticket_ptr, 1u);
+        }
+        t = __builtin_amdgcn_readfirstlane(t); // provably wave-uniform: items[] is fetched with scalar loads into SGPRs
+        return t * NB_SHARDS + shard;
+    };
+    auto load_indices = [&](const int4 it, TileRegs<Real> &r) {
+        r.rb = it.x;
+        r.ccount = it.z;
+        r.ja = lane < it.z ? col_atoms[it.y + lane] : uK;
+        const int ridx = it.x * TILE + (lane & (TILE - 1));
+        r.ra = uK;
+        if (ridx < NR) {
+            r.ra = row_idxs ? row_idxs[ridx] : static_cast<unsigned int>(ridx);
+        }
+    };
+    auto load_records = [&](TileRegs<Real> &r) {
+        const unsigned int ra0 = __builtin_amdgcn_readfirstlane(r.ra); // first row atom of the tile: always valid
+        r.ox = gathered[static_cast<size_t>(ra0) * 8 + 0];
+        r.oy = gathered[static_cast<size_t>(ra0) * 8 + 1];
+        r.oz = gathered[static_cast<size_t>(ra0) * 8 + 2];
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            r.cj[c] = gathered[static_cast<size_t>(r.ja) * 8 + c]; // record K is the zero sentinel: no branch
+        }
         if (lane < TILE) {
-            const int ridx = rb * TILE + lane;
-            unsigned int ra = K;
-            if (ridx < NR) {
-                ra = row_idxs ? row_idxs[ridx] : static_cast<unsigned int>(ridx);
-            }
-            s_rowatom[lane] = ra;
 #pragma unroll
             for (int c = 0; c < 7; c++) {
-                s_row[c][lane] = ra < static_cast<unsigned int>(K) ? gathered[static_cast<size_t>(ra) * 8 + c] : static_cast<Real>(0);
+                r.rr[c] = gathered[static_cast<size_t>(r.ra) * 8 + c];
             }
+        }
+    };
+
+#ifdef TM_TIMING
+    long long tm_setup = 0, tm_p1 = 0, tm_p2 = 0, tm_flush = 0, tm_items = 0, tm_batches = 0;
+    const long long tm_begin = clock64();
+#define TM_T(var) const long long var = clock64()
+#else
+#define TM_T(var)
+#endif
+
+    // prologue: first item fetched the slow way; the second ticket is already taken
+    unsigned int item = take_ticket();
+    unsigned int item_next = take_ticket();
+    TileRegs<Real> cur;
+    if (item < n_items) {
+        load_indices(items[item], cur);
+        load_records(cur);
+    }
+
+    while (item < n_items) {
+        TM_T(t_a);
+        // ---- stage A
+        const bool have_next = item_next < n_items;
+        int4 it_next = make_int4(0, 0, 0, 0);
+        if (have_next) {
+            it_next = items[item_next];
+        }
+        const unsigned int item_after = take_ticket();
+        TileRegs<Real> nxt;
+        nxt.ja = uK;
+        nxt.ra = uK;
+
+        // ---- current item: registers -> LDS
+        const int rb = cur.rb;
+        const unsigned int ja = cur.ja;
+        __syncthreads(); // previous item's flush has finished reading LDS
+        if (lane < TILE) {
+            s_rowatom[lane] = cur.ra;
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                s_row[c][lane] = cur.rr[c];
+            }
+            float4 rf;
+            rf.x = static_cast<float>(min_image(cur.rr[0] - cur.ox, bx.x, bx.inv_x));
+            rf.y = static_cast<float>(min_image(cur.rr[1] - cur.oy, bx.y, bx.inv_y));
+            rf.z = static_cast<float>(min_image(cur.rr[2] - cur.oz, bx.z, bx.inv_z));
+            rf.w = cur.ra < uK ? static_cast<float>(cur.rr[3]) : 1e18f; // invalid row: never passes the filter
+            s_rowf[lane] = rf;
             if constexpr (COMPUTE_DU_DX) {
                 s_fi[0][lane] = 0;
                 s_fi[1][lane] = 0;
@@ -169,13 +289,15 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
                 s_pi[3][lane] = 0;
             }
         }
-        const unsigned int ja = lane < ccount ? col_atoms[cstart + lane] : static_cast<unsigned int>(K);
-        Real cj[7];
 #pragma unroll
         for (int c = 0; c < 7; c++) {
-            cj[c] = ja < static_cast<unsigned int>(K) ? gathered[static_cast<size_t>(ja) * 8 + c] : static_cast<Real>(0);
-            s_col[c][lane] = cj[c];
+            s_col[c][lane] = cur.cj[c];
         }
+        const float cfx = static_cast<float>(min_image(cur.cj[0] - cur.ox, bx.x, bx.inv_x));
+        const float cfy = static_cast<float>(min_image(cur.cj[1] - cur.oy, bx.y, bx.inv_y));
+        const float cfz = static_cast<float>(min_image(cur.cj[2] - cur.oz, bx.z, bx.inv_z));
+        const float cfw = ja < uK ? static_cast<float>(cur.cj[3]) : -1e18f; // padded column: never passes the filter
+        const unsigned int row_first = static_cast<unsigned int>(rb * TILE);
         if constexpr (COMPUTE_DU_DX) {
             s_fj[0][lane] = 0;
             s_fj[1][lane] = 0;
@@ -189,28 +311,49 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
         }
         __syncthreads();
 
+        TM_T(t_b);
+#ifdef TM_TIMING
+        long long tm_p2_item = 0;
+#endif
         int cnt = 0; // wave-uniform number of queued pairs
-        for (int round = 0; round < TILE; round++) {
-            // ---- phase 1: one distance test per lane
-            const int i = (round + lane) & (TILE - 1);
-            const unsigned int ia = s_rowatom[i];
-            const Real dx = min_image(s_row[0][i] - cj[0], bx.x, bx.inv_x);
-            const Real dy = min_image(s_row[1][i] - cj[1], bx.y, bx.inv_y);
-            const Real dz = min_image(s_row[2][i] - cj[2], bx.z, bx.inv_z);
-            const Real dw = s_row[3][i] - cj[3];
-            const Real d2 = pair_d2(dx, dy, dz, dw);
-            const bool valid = ia < static_cast<unsigned int>(K) && ja < static_cast<unsigned int>(K) && (!upper_triangular || ia < ja);
-            const bool hit = valid && d2 < cutoff2; // strict: atoms with w == cutoff never interact
-            const u64 mask = __ballot(hit);
-            if (hit) {
-                const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                s_queue[pos] = static_cast<unsigned short>((i << 8) | lane);
+        for (int round0 = 0; round0 < TILE; round0 += 4) {
+            // ---- phase 1: four conservative f32 distance filters per lane (four independent LDS reads in flight)
+            float4 rf[4];
+            int ri[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ri[k] = (round0 + k + lane) & (TILE - 1);
+                rf[k] = s_rowf[ri[k]];
             }
-            cnt += __popcll(mask);
-
-            // ---- phase 2: drain full batches (and everything on the last round)
-            const bool last = round == TILE - 1;
+            bool hit[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float fdx = rf[k].x - cfx, fdy = rf[k].y - cfy, fdz = rf[k].z - cfz;
+                fdx = __builtin_fmaf(-fbx, __builtin_rintf(fdx * fibx), fdx);
+                fdy = __builtin_fmaf(-fby, __builtin_rintf(fdy * fiby), fdy);
+                fdz = __builtin_fmaf(-fbz, __builtin_rintf(fdz * fibz), fdz);
+                const float fdw = rf[k].w - cfw;
+                const float fd2 = __builtin_fmaf(fdw, fdw, __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx)));
+                // upper-triangular launches keep only row < col (sorted indices; the row index is row_first + i)
+                const bool order_ok = !upper_triangular || (row_first + static_cast<unsigned int>(ri[k])) < ja;
+                hit[k] = order_ok && fd2 < fcut2;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u64 mask = __ballot(hit[k]);
+                if (hit[k]) {
+                    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    s_queue[pos] = static_cast<unsigned short>((ri[k] << 8) | lane);
+                }
+                cnt += __popcll(mask);
+            }
+#if defined(TM_ABLATE) && TM_ABLATE == 1
+            cnt = 0; // ablation: no phase 2 at all
+#endif
+            // ---- phase 2: drain full batches (and everything after the last rounds)
+            const bool last = round0 == TILE - 4;
             while (cnt >= NB_CHUNK || (last && cnt > 0)) {
+                TM_T(t_h0);
                 const int n = cnt < NB_CHUNK ? cnt : NB_CHUNK;
                 const int base = cnt - n;
                 __syncthreads();
@@ -222,51 +365,80 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
                     const Real ddz = min_image(s_row[2][pi] - s_col[2][pj], bx.z, bx.inv_z);
                     const Real ddw = s_row[3][pi] - s_col[3][pj];
                     const Real dd2 = pair_d2(ddx, ddy, ddz, ddw);
+                    if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
                     const Real qi = s_row[4][pi], qj = s_col[4][pj];
                     const Real eps_i = s_row[6][pi], eps_j = s_col[6][pj];
                     PairOut<Real> o;
+#if defined(TM_ABLATE) && TM_ABLATE == 4
+                    o.prefactor = dd2 * qi; o.u = qj; o.inv_dij = qi; o.ebd = qj; o.sig_grad = 0; o.eps_grad = 0; o.has_lj = false; // ablation: no math
+#else
                     nb_pair<Real>(1, 1, qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o);
+#endif
+#if defined(TM_ABLATE) && TM_ABLATE == 2
+                    if (o.prefactor == static_cast<Real>(1.2345e-30)) { energy += 1; } // ablation: math, no accumulation
+#else
                     if constexpr (COMPUTE_DU_DX) {
-                        atomicAdd(&s_fi[0][pi], float_to_fixed<Real>(o.prefactor * ddx));
-                        atomicAdd(&s_fi[1][pi], float_to_fixed<Real>(o.prefactor * ddy));
-                        atomicAdd(&s_fi[2][pi], float_to_fixed<Real>(o.prefactor * ddz));
-                        atomicAdd(&s_fj[0][pj], float_to_fixed<Real>(-o.prefactor * ddx));
-                        atomicAdd(&s_fj[1][pj], float_to_fixed<Real>(-o.prefactor * ddy));
-                        atomicAdd(&s_fj[2][pj], float_to_fixed<Real>(-o.prefactor * ddz));
+                        u64 fx, fy, fz;
+                        pair_force_fixed(o.prefactor, ddx, ddy, ddz, fx, fy, fz);
+                        lds_add(&s_fi[0][pi], fx);
+                        lds_add(&s_fi[1][pi], fy);
+                        lds_add(&s_fi[2][pi], fz);
+                        lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
+                        lds_sub(&s_fj[1][pj], fy);
+                        lds_sub(&s_fj[2][pj], fz);
                     }
+#endif
                     if constexpr (COMPUTE_DU_DP) {
-                        atomicAdd(&s_pi[0][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qj * o.inv_dij * o.ebd));
-                        atomicAdd(&s_pj[0][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qi * o.inv_dij * o.ebd));
+                        lds_add(&s_pi[0][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qj * o.inv_dij * o.ebd));
+                        lds_add(&s_pj[0][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qi * o.inv_dij * o.ebd));
                         if (o.has_lj) {
                             const u64 sg = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(o.sig_grad);
-                            atomicAdd(&s_pi[1][pi], sg);
-                            atomicAdd(&s_pj[1][pj], sg);
-                            atomicAdd(&s_pi[2][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j));
-                            atomicAdd(&s_pj[2][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i));
+                            lds_add(&s_pi[1][pi], sg);
+                            lds_add(&s_pj[1][pj], sg);
+                            lds_add(&s_pi[2][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j));
+                            lds_add(&s_pj[2][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i));
                         }
-                        atomicAdd(&s_pi[3][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * ddw));
-                        atomicAdd(&s_pj[3][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(-o.prefactor * ddw));
+                        const u64 gw = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * ddw);
+                        lds_add(&s_pi[3][pi], gw);
+                        lds_sub(&s_pj[3][pj], gw);
                     }
                     if constexpr (COMPUTE_U) {
                         energy += float_to_fixed_energy<Real>(o.u);
                     }
+                    } // exact cutoff test
                 }
                 cnt = base;
+#ifdef TM_TIMING
+                __syncthreads();
+                tm_p2_item += clock64() - t_h0;
+                tm_batches++;
+#endif
             }
         }
+        // ---- stages B + C: the next item's indices, then its atom records, enter the memory queue ahead of this item's
+        // flush atomics (returns are in order per wave: a load issued behind the atomics could not be observed before
+        // every one of them has been acknowledged by the memory side)
+        if (have_next) {
+            load_indices(it_next, nxt);
+            load_records(nxt);
+        }
         __syncthreads();
+        TM_T(t_c);
 
         // ---- flush: one global atomic per touched (atom, component)
+#if defined(TM_ABLATE) && TM_ABLATE == 3
+        if (false) // ablation: no global flush
+#endif
         if constexpr (COMPUTE_DU_DX) {
             for (int t = lane; t < TILE * 3; t += 64) {
                 const int a = t / 3, c = t - a * 3;
                 const u64 v = s_fi[c][a];
                 const unsigned int ra = s_rowatom[a];
-                if (v != 0 && ra < static_cast<unsigned int>(K)) {
+                if (v != 0 && ra < uK) {
                     atomicAdd(g_du_dx + static_cast<size_t>(ra) * 3 + c, v);
                 }
             }
-            if (ja < static_cast<unsigned int>(K)) {
+            if (ja < uK) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const u64 v = s_fj[c][lane];
@@ -281,11 +453,11 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
                 const int a = t >> 2, c = t & 3;
                 const u64 v = s_pi[c][a];
                 const unsigned int ra = s_rowatom[a];
-                if (v != 0 && ra < static_cast<unsigned int>(K)) {
+                if (v != 0 && ra < uK) {
                     atomicAdd(g_du_dp + static_cast<size_t>(ra) * 4 + c, v);
                 }
             }
-            if (ja < static_cast<unsigned int>(K)) {
+            if (ja < uK) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const u64 v = s_pj[c][lane];
@@ -295,7 +467,33 @@ __global__ __launch_bounds__(64, 2) void k_nonbonded_tiles(
                 }
             }
         }
+#ifdef TM_TIMING
+        {
+            const long long t_d = clock64();
+            tm_setup += t_b - t_a;
+            tm_p2 += tm_p2_item;
+            tm_p1 += (t_c - t_b) - tm_p2_item;
+            tm_flush += t_d - t_c;
+            tm_items++;
+        }
+#endif
+        cur = nxt;
+        item = item_next;
+        item_next = item_after;
     }
+#ifdef TM_TIMING
+    if (lane == 0 && timing) {
+        long long *t = timing + static_cast<size_t>(blockIdx.x) * 8;
+        t[0] = tm_setup;
+        t[1] = tm_p1;
+        t[2] = tm_p2;
+        t[3] = tm_flush;
+        t[4] = tm_items;
+        t[5] = tm_batches;
+        t[6] = clock64() - tm_begin;
+        t[7] = 0;
+    }
+#endif
 
     if constexpr (COMPUTE_U) {
         const i128 total = wave_sum_i128(energy);
@@ -338,12 +536,14 @@ __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
         atomicAdd((ptr), NEGATED ? (0ull - v_) : v_);                                                                  \
     } while (0)
             if (du_dx) {
-                TM_ACC(du_dx + ia * 3 + 0, float_to_fixed<Real>(o.prefactor * dx));
-                TM_ACC(du_dx + ia * 3 + 1, float_to_fixed<Real>(o.prefactor * dy));
-                TM_ACC(du_dx + ia * 3 + 2, float_to_fixed<Real>(o.prefactor * dz));
-                TM_ACC(du_dx + ja * 3 + 0, float_to_fixed<Real>(-o.prefactor * dx));
-                TM_ACC(du_dx + ja * 3 + 1, float_to_fixed<Real>(-o.prefactor * dy));
-                TM_ACC(du_dx + ja * 3 + 2, float_to_fixed<Real>(-o.prefactor * dz));
+                u64 fx, fy, fz;
+                pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
+                TM_ACC(du_dx + ia * 3 + 0, fx);
+                TM_ACC(du_dx + ia * 3 + 1, fy);
+                TM_ACC(du_dx + ia * 3 + 2, fz);
+                TM_ACC(du_dx + ja * 3 + 0, 0ull - fx);
+                TM_ACC(du_dx + ja * 3 + 1, 0ull - fy);
+                TM_ACC(du_dx + ja * 3 + 2, 0ull - fz);
             }
             if (du_dp) {
                 TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
@@ -355,8 +555,9 @@ __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
                     TM_ACC(du_dp + ia * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j)));
                     TM_ACC(du_dp + ja * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i)));
                 }
-                TM_ACC(du_dp + ia * 4 + 3, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * dw)));
-                TM_ACC(du_dp + ja * 4 + 3, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(-o.prefactor * dw)));
+                const u64 gw = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * dw);
+                TM_ACC(du_dp + ia * 4 + 3, gw);
+                TM_ACC(du_dp + ja * 4 + 3, 0ull - gw);
             }
 #undef TM_ACC
             if (u_partials) {

@@ -15,6 +15,7 @@
 //   prefactor = es_prefactor - lj_prefactor
 #pragma once
 #include "fixed_point.cuh"
+#include "nb_math.cuh"
 
 namespace tmamd {
 
@@ -32,39 +33,39 @@ template <typename Real> struct PairOut {
 };
 
 // ---------------- f64 ----------------
+// S(d) = cos^3((pi/2) (d/1.2)^8) and S'(d) = -12 pi/1.2^8 d^7 sin cos^2  (0 for d >= 1.2), branch-free
 __device__ __forceinline__ double switch_fn_and_deriv(double dij, double &dsdr) {
     const double cutoff = 1.2;
-    if (dij >= cutoff) {
-        dsdr = 0.0;
-        return 0.0;
-    }
     const double inv_cutoff = 1.0 / cutoff;
     const double pi = static_cast<double>(TM_PI);
     const double k2 = inv_cutoff * inv_cutoff;
     const double k4 = k2 * k2;
     const double k8 = k4 * k4;
-    double d2 = dij * dij;
-    double d4 = d2 * d2;
-    double d7 = d4 * d2 * dij;
-    double d8 = d4 * d4;
-    double arg = 0.5 * pi * (d8 * k8);
+    const bool inside = dij < cutoff;
+    const double d = inside ? dij : cutoff; // keep the polynomial argument in range; results are discarded outside
+    const double d2 = d * d;
+    const double d4 = d2 * d2;
+    const double d7 = d4 * d2 * d;
+    const double q = (d4 * d4) * k8; // (d/1.2)^8 in [0, 1]
     double s, c;
-    sincos(arg, &s, &c);
-    double c2 = c * c;
+    tm_sincos_halfpi_f64(q, s, c);
+    const double c2 = c * c;
     const double minus_12_pi_k8 = -12 * pi * k8;
-    dsdr = d7 * s * c2 * minus_12_pi_k8;
-    return c2 * c;
+    const double ds = d7 * s * c2 * minus_12_pi_k8;
+    dsdr = inside ? ds : 0.0;
+    return inside ? c2 * c : 0.0;
 }
 
 __device__ __forceinline__ double real_es_factor(double beta, double dij, double inv_dij, double inv_d2ij, double &damping) {
-    double bd = beta * dij;
-    double e = erfc(bd);
+    const double bd = beta * dij;
+    const double e2 = tm_exp_neg_f64(-(bd * bd)); // exp(-(beta d)^2)
+    const double e = e2 * tm_erfcx_f64(bd);       // erfc(beta d)
     double dsdr;
-    double sr = switch_fn_and_deriv(dij, dsdr);
+    const double sr = switch_fn_and_deriv(dij, dsdr);
     damping = e * sr;
-    double debd = -static_cast<double>(TM_TWO_OVER_SQRT_PI) * beta * exp(-bd * bd);
-    double damping_prime = (e * dsdr) + (debd * sr);
-    return damping_prime * inv_dij - damping * inv_d2ij;
+    const double debd = (-static_cast<double>(TM_TWO_OVER_SQRT_PI) * beta) * e2;
+    const double damping_prime = __builtin_fma(e, dsdr, debd * sr);
+    return __builtin_fma(damping_prime, inv_dij, -(damping * inv_d2ij));
 }
 
 // ---------------- f32 (what production MD runs; k_nonbonded_common.cuh:98-178) ----------------
@@ -106,7 +107,7 @@ __device__ __forceinline__ float real_es_factor(float beta, float dij, float inv
     return damping_prime * inv_dij - damping * inv_d2ij;
 }
 
-__device__ __forceinline__ double tm_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ double tm_rsqrt(double x) { return tm_rsqrt_f64(x); }
 __device__ __forceinline__ float tm_rsqrt(float x) { return rsqrtf(x); }
 
 // d2ij must already satisfy d2ij < cutoff^2.
@@ -147,9 +148,30 @@ __device__ __forceinline__ void nb_pair(
     o.ebd = damping;
 }
 
-// minimum-image displacement component: delta -= L * nearbyint(delta / L)   (round-half-even, Appendix B.2)
-template <typename Real> __device__ __forceinline__ Real min_image(Real delta, Real box, Real inv_box) {
-    return delta - box * nearbyint(delta * inv_box);
+// minimum-image displacement component: delta -= L * nearbyint(delta / L)   (round-half-even, Appendix B.2).
+// Odd in delta bit for bit (rint and fma are sign-symmetric), so swapping i and j only flips signs.
+__device__ __forceinline__ double min_image(double delta, double box, double inv_box) {
+    return __builtin_fma(-box, __builtin_rint(delta * inv_box), delta);
+}
+__device__ __forceinline__ float min_image(float delta, float box, float inv_box) {
+    return __builtin_fmaf(-box, __builtin_rintf(delta * inv_box), delta);
+}
+
+// Fixed-point force components of one pair.
+//   reference: g_i += FIX(p * d), g_j += FIX(-p * d) with FIX(v) = llrint(v * 2^36)   (k_nonbonded.cuh:244-252)
+// Scaling by 2^36 is exact, so llrint((p * 2^36) * d) == llrint((p * d) * 2^36) bit for bit: one multiply by 2^36 per
+// pair instead of one per component; and llrint is odd, so g_j is the two's-complement negation of g_i (callers use
+// an integer subtract / LDS ds_sub for it) -- three conversions per pair instead of six.
+__device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
+    const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
+    fx = static_cast<u64>(real_to_int64(ps * dx));
+    fy = static_cast<u64>(real_to_int64(ps * dy));
+    fz = static_cast<u64>(real_to_int64(ps * dz));
+}
+// f32 kernels: the products are formed in f64 from the f32 prefactor and displacement (exact widening), which is
+// cheaper on gfx950 than rounding each product to f32 first and then widening it for the 64-bit conversion.
+__device__ __forceinline__ void pair_force_fixed(float prefactor, float dx, float dy, float dz, u64 &fx, u64 &fy, u64 &fz) {
+    pair_force_fixed(static_cast<double>(prefactor), static_cast<double>(dx), static_cast<double>(dy), static_cast<double>(dz), fx, fy, fz);
 }
 
 } // namespace tmamd

@@ -254,23 +254,22 @@ void Neighborlist<Real>::build_device(
     const int nrb = this->num_row_blocks();
     const int total_blocks = ncb + (ut ? 0 : nrb);
     const int tpb = DEFAULT_TPB;
-    int work = std::max(total_blocks, d_snap_x ? n_snap : 0);
-    int grid = std::min(ceil_divide(work, tpb), 1024);
-    grid = std::max(grid, ceil_divide(total_blocks, tpb));
+    // one wave per block (4 per workgroup); the same threads also copy the coordinate snapshot grid-stride
+    int grid = std::min(std::max(ceil_divide(total_blocks, tpb / 64), 1), 2048);
     const int dummy_flag_force = d_flag ? force : 1;
     k_block_bounds<Real><<<grid, tpb, 0, stream>>>(
         ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
         d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
         d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
     HIP_CHECK(hipGetLastError());
-    const size_t lds = static_cast<size_t>(ceil_divide(ncb, 64)) * sizeof(u64);
+    const size_t lds = 0;
     if (ut) {
-        k_find_ixns<Real, true><<<nrb, 256, lds, stream>>>(
+        k_find_ixns<Real, true><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
             cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
             d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
     } else {
-        k_find_ixns<Real, false><<<nrb, 256, lds, stream>>>(
+        k_find_ixns<Real, false><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
             d_gathered, d_box, cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
             d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
@@ -328,7 +327,7 @@ void Neighborlist<Real>::compute_block_bounds_host(
     const int ncb = this->num_column_blocks();
     const int nrb = this->num_row_blocks();
     const int total_blocks = ncb + (ut ? 0 : nrb);
-    k_block_bounds<Real><<<ceil_divide(total_blocks, DEFAULT_TPB), DEFAULT_TPB, 0, 0>>>(
+    k_block_bounds<Real><<<std::max(ceil_divide(total_blocks, DEFAULT_TPB / 64), 1), DEFAULT_TPB, 0, 0>>>(
         ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_scratch_gathered_.data,
         d_box.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, 0, nullptr, nullptr, nullptr,
         reinterpret_cast<const int *>(d_counters_.data), 1);
@@ -397,7 +396,7 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
 
     d_atom_idxs_.realloc(N_);
     d_perm_.realloc(N_);
-    d_gathered_.realloc(static_cast<size_t>(N_) * 8);
+    d_gathered_.realloc(static_cast<size_t>(N_ + 1) * 8); // + one all-zero sentinel record
     d_g_du_dx_.realloc(static_cast<size_t>(N_) * 3);
     d_g_du_dp_.realloc(static_cast<size_t>(N_) * 4);
     d_snap_x_.realloc(static_cast<size_t>(N_) * 3);
@@ -406,8 +405,12 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
     HIP_CHECK(hipMemset(d_snap_box_.data, 0, d_snap_box_.size()));
     d_flags_.realloc(2);
     HIP_CHECK(hipMemset(d_flags_.data, 0, d_flags_.size()));
-    // persistent grid: one wave per workgroup, a few waves per SIMD on every CU
-    grid_ = device_cu_count() * 12;
+    // persistent grid: one wave per workgroup, TileWaves<Real> waves per SIMD on every CU
+    grid_ = device_cu_count() * 4 * TileWaves<Real>::value;
+    d_timing_.realloc(static_cast<size_t>(grid_) * 8);
+    HIP_CHECK(hipMemset(d_timing_.data, 0, d_timing_.size()));
+    d_work_ctr_.realloc(NB_SHARDS * NB_SHARD_STRIDE);
+    HIP_CHECK(hipMemset(d_work_ctr_.data, 0, d_work_ctr_.size()));
     d_u_partials_.realloc(grid_);
     if (!disable_hilbert_) {
         hilbert_.reset(new HilbertSort(N_));
@@ -425,6 +428,13 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
     K_ = K;
     calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
     force_rebuild_ = true;
+}
+
+template <typename Real> std::vector<long long> NonbondedAllPairs<Real>::debug_timing() {
+    std::vector<long long> raw(static_cast<size_t>(grid_) * 8);
+    HIP_CHECK(hipDeviceSynchronize());
+    d_timing_.copy_to(raw.data());
+    return raw;
 }
 
 template <typename Real> std::vector<int> NonbondedAllPairs<Real>::get_atom_idxs() {
@@ -464,9 +474,9 @@ void NonbondedAllPairs<Real>::execute_device(
     // pinned-memory flag every call, nonbonded_all_pairs.cu:217-236).
     int *flag_now = d_flags_.data + parity_;
     int *flag_next = d_flags_.data + (parity_ ^ 1);
-    k_check_gather<Real><<<ceil_divide(std::max(K_, 9), tpb), tpb, 0, stream>>>(
+    k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
         K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
-        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr);
+        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_work_ctr_.data);
     HIP_CHECK(hipGetLastError());
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
@@ -479,7 +489,7 @@ void NonbondedAllPairs<Real>::execute_device(
     k_nonbonded_tiles<Real, U, X, PP><<<grid_, 64, 0, stream>>>(                                                      \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(), d_counters + 1,\
         nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, d_g_du_dx_.data,            \
-        d_g_du_dp_.data, d_u_partials_.data)
+        d_g_du_dp_.data, d_u_partials_.data, d_work_ctr_.data, d_timing_.data)
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
     switch (sel) {

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtimemachine_amd.so")
+_LIB_PATH = os.environ.get("TM_AMD_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libtimemachine_amd.so")
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
