@@ -38,6 +38,35 @@ def worker():
         t = buf[: cnt.value].reshape(-1, 8)
         if t[:, 6].sum() > 0:
             tot = t[:, 6].astype(float)
+            bc = (t[:, 4] >> 20).astype(float); sa = (t[:, 5] >> 20).astype(float)
+            t[:, 4] &= (1 << 20) - 1; t[:, 5] &= (1 << 20) - 1
+            start = t[:, 7].astype(float) - t[:, 7].min(); end = start + tot
+            bt = t[:, 5].astype(float)
+            pct = lambda a: " ".join(f"{np.percentile(a, q):.0f}" for q in (0, 10, 50, 90, 100))
+            xcd = " ".join(f"{tot[k::8].mean():.0f}" for k in range(8))
+            out.append(f"[total pct {pct(tot)} | batches pct {pct(bt)} | corr {np.corrcoef(tot, bt)[0,1]:.2f} | per blockIdx%8 total {xcd} | "
+                       f"cycles/batch-equiv {np.polyfit(bt, tot, 1)}]")
+            idle = []
+            xcc = (t[:, 3] >> 56) & 0xf; hwid = (t[:, 3] >> 40) & 0xffff
+            t[:, 3] &= (1 << 40) - 1
+            out.append(f"[xcc of first 16 blocks {xcc[:16].tolist()} | waves per xcc {np.bincount(xcc, minlength=8).tolist()} | "
+                       f"distinct (xcc,se,sh,cu,simd) {len(set(zip(xcc.tolist(), ((hwid>>4)&0xfff).tolist())))}]")
+            st_all = (t[:, 7] & 0xffffffff).astype(float); en_all = ((t[:, 7] >> 32) & 0xffffffff).astype(float)
+            st0 = st_all.min(); span = en_all.max() - st0
+            simd_key = xcc * 65536 + ((hwid >> 4) & 0xfff)
+            simd_end = {}
+            for kk, e in zip(simd_key.tolist(), en_all.tolist()):
+                simd_end[kk] = max(simd_end.get(kk, 0), e)
+            se = np.array(list(simd_end.values())) - st0
+            out.append(f"[realtime (10 ns ticks): span {span:.0f} | wave end mean {(en_all - st0).mean():.0f} | latest start {(st_all - st0).max():.0f} | "
+                       f"SIMD last-wave end pct {pct(se)} mean {se.mean():.0f}]")
+            for k in range(8):
+                sel = xcc == k
+                st = st_all[sel]; en = en_all[sel]
+                span_k = en.max() - st0
+                idle.append(f"{span_k:.0f}/{(en - st0).mean() / span_k:.2f}")
+            out.append(f"[per xcc: end of last wave / mean wave end as a fraction of it: {' '.join(idle)}]")
+            out.append(f"[stageA {sa.mean():.0f} stageBC {bc.mean():.0f} start mean {start.mean():.0f} max {start.max():.0f} end mean {end.mean():.0f} max {end.max():.0f}]")
             out.append(
                 f"[waves {len(t)} items/wave {t[:,4].mean():.2f} batches/wave {t[:,5].mean():.1f} | mean cycles(100MHz ticks?) total {tot.mean():.0f} max {tot.max():.0f} "
                 f"setup {t[:,0].mean():.0f} p1 {t[:,1].mean():.0f} p2 {t[:,2].mean():.0f} flush {t[:,3].mean():.0f}]")

@@ -190,9 +190,10 @@ public:
     // `d_gathered` holds Real[K][8] records (x, y, z, ...).  If d_flag != nullptr the kernels return immediately
     // unless force != 0 or *d_flag != 0 (device-side rebuild decision: no host synchronisation).
     // When d_snap_x != nullptr the n_snap doubles of d_x (and the box) are copied into the snapshot as part of the build.
+    // `cost_cutoff` (<= cutoff) is the distance the work items' cost estimates count pairs within.
     void build_device(
-        const Real *d_gathered, const double *d_box, const double cutoff, const int *d_flag, const int force, const int n_snap,
-        const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream);
+        const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
+        const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream);
 
     int get_num_row_idxs() const { return NR_; }
     int num_row_blocks() const { return ceil_divide(NR_, TILE); }
@@ -204,6 +205,7 @@ public:
     const unsigned int *row_idxs_or_null() const { return upper_triangular() ? nullptr : d_row_idxs_.data; }
     const unsigned int *d_counters() const { return d_counters_.data; }
     const int4 *d_items() const { return d_items_.data; }
+    unsigned int items_cap() const { return static_cast<unsigned int>(items_cap_); }
     const unsigned int *d_col_atoms() const { return d_col_atoms_.data; }
 
 private:
@@ -211,9 +213,10 @@ private:
     int N_, NC_, NR_;
     DeviceBuffer<Real> d_col_ctr_, d_col_ext_, d_row_ctr_, d_row_ext_;
     DeviceBuffer<unsigned int> d_row_idxs_, d_col_idxs_;
-    DeviceBuffer<unsigned int> d_counters_;  // [0] pool cursor, [1] work items, [2] 32-wide tile count
+    DeviceBuffer<unsigned int> d_counters_;  // [0] pool cursor, [1] work items, [2] 32-wide tile count, [4..12) items per cost class
     DeviceBuffer<unsigned int> d_col_atoms_; // CSR pool
-    DeviceBuffer<int4> d_items_;
+    DeviceBuffer<int4> d_items_;             // NB_CLASSES buckets of items_cap_ work items, heaviest class first
+    size_t items_cap_ = 0;
     DeviceBuffer<int2> d_row_segments_;
     DeviceBuffer<Real> d_scratch_gathered_; // host entry points only
     void gather_host_coords(const int N, const double *h_coords, const double *h_box, DeviceBuffer<double> &d_box);
@@ -261,7 +264,6 @@ private:
     DeviceBuffer<double> d_snap_x_, d_snap_box_;
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;
-    DeviceBuffer<unsigned int> d_work_ctr_;
     DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
 };
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     const int n_row_blocks, const int NR, const unsigned int *__restrict__ row_idxs, // only used when rows != cols
     const int rows_equal_cols, const Real *__restrict__ gathered, const double *__restrict__ box,
     Real *__restrict__ col_ctr, Real *__restrict__ col_ext, Real *__restrict__ row_ctr, Real *__restrict__ row_ext,
-    unsigned int *__restrict__ counters, // [0]=pool cursor [1]=n_items [2]=tile count
+    unsigned int *__restrict__ counters, // [0]=pool cursor [1]=n_items [2]=tile count [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
     const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
     const int *__restrict__ flag, const int force) {
     if (!force && *flag == 0) {
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void k_block_bounds(
         counters[0] = 0;
         counters[1] = 0;
         counters[2] = 0;
+    }
+    if (tid < NB_SHARDS * NB_CLASSES) {
+        counters[NB_COUNTER_CLASS0 + tid] = 0;
     }
     if (snap_x) {
         for (int t = tid; t < n_snap; t += nthreads) {
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     const int K, const int NC, const int NR, const unsigned int *__restrict__ col_idxs, const unsigned int *__restrict__ row_idxs,
     const Real *__restrict__ col_ctr, const Real *__restrict__ col_ext, const Real *__restrict__ row_ctr,
     const Real *__restrict__ row_ext, const Real *__restrict__ gathered, const double *__restrict__ box, const double cutoff_d,
+    const double cost_cutoff_d, // pairs closer than this are what an item's cost estimate counts
     unsigned int *__restrict__ counters, unsigned int *__restrict__ col_atoms, int4 *__restrict__ items,
+    const unsigned int items_cap,    // capacity of each of the NB_SHARDS * NB_CLASSES item buckets
     int2 *__restrict__ row_segments, // per row block {start, count}
     const int *__restrict__ flag, const int force) {
     if (!force && *flag == 0) {
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     }
     __shared__ int s_list[NBL_CHUNK];
     __shared__ Real s_rx[TILE], s_ry[TILE], s_rz[TILE];
-    __shared__ unsigned int s_npass, s_nlist, s_count, s_seg_start, s_item_base;
+    __shared__ unsigned int s_npass, s_nlist, s_count, s_seg_start;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -266,19 +271,63 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     }
 
     // ---- publish the segment and its work items
+    // Every item gets a cost estimate -- the number of (row, column) pairs inside the list cutoff -- and is filed into
+    // bucket (shard = row block % 8, cost class), class 0 = heaviest.  The tile kernel's waves drain the buckets of their
+    // shard in class order (longest processing time first): items differ in cost by more than an order of magnitude and
+    // a wave only processes a handful, so an arbitrary order leaves most waves idle while the unluckiest one finishes a
+    // heavy item it drew last.  64 bucket cursors instead of one keep the (slow, memory-side) atomics off a single address.
     const unsigned int count = s_count;
     const unsigned int n_chunks = (count + NB_CHUNK - 1) / NB_CHUNK;
     if (tid == 0) {
         row_segments[rb] = make_int2(static_cast<int>(seg_start), static_cast<int>(count));
         atomicAdd(&counters[2], (count + TILE - 1) / TILE);
-        s_item_base = n_chunks ? atomicAdd(&counters[1], n_chunks) : 0;
+        if (n_chunks) {
+            atomicAdd(&counters[1], n_chunks);
+        }
     }
-    __syncthreads();
-    const unsigned int item_base = s_item_base;
-    for (unsigned int c = tid; c < n_chunks; c += blockDim.x) {
+    const Real cost_cutoff2 = static_cast<Real>(cost_cutoff_d) * static_cast<Real>(cost_cutoff_d);
+    for (unsigned int c = wave; c < n_chunks; c += NBL_THREADS / 64) {
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
-        items[item_base + c] = make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), 0);
+        unsigned int ja = K;
+        if (static_cast<unsigned int>(lane) < len) {
+            // written by other waves of this workgroup a barrier ago: read past the (non-coherent) vector L1
+            ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned int mine = 0;
+        if (ja < static_cast<unsigned int>(K)) {
+            const Real xj = gathered[static_cast<size_t>(ja) * 8 + 0];
+            const Real yj = gathered[static_cast<size_t>(ja) * 8 + 1];
+            const Real zj = gathered[static_cast<size_t>(ja) * 8 + 2];
+            for (int i = 0; i < nrow; i++) {
+                const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
+                const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
+                const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
+                const bool order_ok = !UPPER_TRIANGULAR || static_cast<unsigned int>(rb * TILE + i) < ja;
+                mine += (order_ok && (dx * dx + dy * dy + dz * dz) < cost_cutoff2) ? 1u : 0u;
+            }
+        }
+        unsigned int total = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            total += __shfl_xor(total, o, 64);
+        }
+        if (lane == 0) {
+            const unsigned int heavy = total / NB_CLASS_PAIRS;
+#ifdef TM_NO_COST_ORDER
+            const unsigned int cls = 0 * heavy; // debug builds: arbitrary order, for A/B measurements
+#else
+            const unsigned int cls = NB_CLASSES - 1 - (heavy < NB_CLASSES - 1 ? heavy : NB_CLASSES - 1);
+#endif
+#ifdef TM_SHARD_BY_CHUNK
+            const unsigned int bucket = ((static_cast<unsigned int>(rb) + c) & (NB_SHARDS - 1)) * NB_CLASSES + cls;
+#else
+            const unsigned int bucket = (static_cast<unsigned int>(rb) & (NB_SHARDS - 1)) * NB_CLASSES + cls;
+#endif
+            const unsigned int pos = atomicAdd(&counters[NB_COUNTER_CLASS0 + bucket], 1u);
+            items[static_cast<size_t>(bucket) * items_cap + pos] =
+                make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
+        }
     }
 }
 

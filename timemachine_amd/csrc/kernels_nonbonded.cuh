@@ -34,8 +34,13 @@ template <typename Real> struct TileWaves {
     static const int value = sizeof(Real) == 8 ? 3 : 5;
 };
 static const int NB_CHUNK = 64;        // columns per work item == wave width
-static const int NB_SHARDS = 8;        // dynamic work queues for the tile kernel, one per XCD (blockIdx % 8)
-static const int NB_SHARD_STRIDE = 16; // queue heads live in separate 64-byte lines
+static const int NB_SHARDS = 4;        // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
+static const int NB_CLASSES = 16;      // work items are bucketed by cost (estimated interacting pairs), heaviest first
+static const int NB_CLASS_PAIRS = 128; // bucket width; class NB_CLASSES-1 holds items with < 128 pairs
+static const int NB_COUNTER_CLASS0 = 4; // neighbor-list counters[4 + shard * NB_CLASSES + class]: items per bucket
+static const int NB_NUM_COUNTERS = NB_COUNTER_CLASS0 + NB_SHARDS * NB_CLASSES;
+static_assert(NB_SHARDS * NB_CLASSES == 64, "one bucket per lane of the tile kernel's prefix sum");
+
 
 template <typename Real> struct NbBox {
     Real x, y, z, inv_x, inv_y, inv_z;
@@ -70,13 +75,10 @@ __global__ void k_check_gather(
     const double *__restrict__ box, const double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double pad2_quarter, // 0.25 * padding^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp, unsigned int *__restrict__ work_ctr) {
+    u64 *__restrict__ g_du_dp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
-    }
-    if (idx < NB_SHARDS) {
-        work_ctr[idx * NB_SHARD_STRIDE] = 0; // the tile kernel's dynamic work queues (consumed later in this call)
     }
     if (idx < 8) {
         gathered[static_cast<size_t>(K) * 8 + idx] = 0; // sentinel record: padded list slots point here
@@ -152,9 +154,11 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     const int NR,                              // number of row atoms
     const int upper_triangular,                // rows == cols == all: keep only row < col
     const unsigned int *__restrict__ row_idxs, // [NR] or nullptr (identity)
-    const unsigned int *__restrict__ n_items_ptr, const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
+    const unsigned int *__restrict__ class_counts, // [NB_SHARDS][NB_CLASSES] items per bucket (class 0 = heaviest)
+    const unsigned int items_cap,                  // bucket capacity: bucket b lives at items[b * items_cap ...]
+    const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials, unsigned int *__restrict__ work_ctr,
+    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials,
     long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
     __shared__ Real s_row[7][TILE];
@@ -179,30 +183,52 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     const float fmaxb = fmaxf(fbx, fmaxf(fby, fbz));
     const float fcut2 = static_cast<float>(cutoff_d * cutoff_d) + 1e-5f * (1.0f + fmaxb) * (1.0f + static_cast<float>(cutoff_d));
 
-    // Dynamic work distribution.  Work items differ in cost by an order of magnitude (0..2048 interacting pairs), and a
-    // wave only gets a handful of them, so a static grid-stride assignment leaves the average wave idle ~40 % of the
-    // kernel while the unluckiest one finishes.  Items are dealt round-robin into NB_SHARDS queues (item % 8); a wave
-    // pulls from the queue of its XCD (blockIdx % 8: atomics stay on one die).
+    // Work distribution.  Work items differ in cost by an order of magnitude (0..2048 interacting pairs) and a wave only
+    // processes a handful.  The neighbor-list build files every item into bucket (shard, cost class); the cost-sorted order
+    // is the concatenation of the buckets, heaviest class first, and it is dealt to the (persistent, one-per-slot) waves
+    // statically.  Dynamic ticket counters were measured and rejected: a returning global atomic queues behind the wave's
+    // own flush atomics at the memory side and came back 10-40 us later, doubling the kernel's duration.
     //
     // Software pipeline over items.  Fetching an item is a chain of dependent memory operations
-    //   ticket (atomic) -> items[] -> col_atoms[] -> gathered[]
+    //   items[] -> col_atoms[] -> gathered[]
     // which costs several microseconds when paid up front.  Instead, while item k is being computed:
-    //   stage A (start of k)   items[k+1] is requested (its ticket was taken during k-1); the ticket for k+2 is taken
+    //   stage A (start of k)   items[k+1] is requested (scalar load)
     //   stage B, C (end of k)  column / row atom indices of k+1, then its atom records, are requested -- after k's
     //                          heavy phase (no extra live registers there) but BEFORE k's flush atomics are issued
-    // so one L2 round trip (the index load) is exposed per item instead of four dependent hops.
-    const unsigned int n_items = *n_items_ptr;
-    const unsigned int shard = blockIdx.x & (NB_SHARDS - 1);
-    unsigned int *ticket_ptr = work_ctr + shard * NB_SHARD_STRIDE;
+    // so one L2 round trip (the index load) is exposed per item instead of three dependent hops.
     const unsigned int uK = static_cast<unsigned int>(K);
-
-    auto take_ticket = [&]() -> unsigned int { // returns the ITEM index (>= n_items when the queue is exhausted)
-        unsigned int t = 0;
-        if (lane == 0) {
-            t = atomicAdd(ticket_ptr, 1u);
+    const unsigned int NO_ITEM = 0xffffffffu;
+    unsigned int bucket_end; // lane l: end (exclusive prefix sum) of bucket number l in class-major order
+    {
+        const unsigned int cls = lane / NB_SHARDS, sh = lane % NB_SHARDS;
+        unsigned int v = class_counts[sh * NB_CLASSES + cls];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int up = __shfl_up(v, o, 64);
+            if (lane >= o) {
+                v += up;
+            }
         }
-        t = __builtin_amdgcn_readfirstlane(t); // provably wave-uniform: items[] is fetched with scalar loads into SGPRs
-        return t * NB_SHARDS + shard;
+        bucket_end = v;
+    }
+    const unsigned int n_items_total = __shfl(bucket_end, 63, 64);
+    unsigned int next_round = 0;
+    auto request_ticket = [&]() -> unsigned int {
+        // serpentine deal: even rounds left to right, odd rounds right to left, so the wave that drew the heaviest item of
+        // one round draws the lightest of the next
+        const unsigned int w = (next_round & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        const unsigned int t = next_round * gridDim.x + w;
+        next_round++;
+        return t;
+    };
+    auto resolve_ticket = [&](unsigned int g) -> unsigned int {
+        if (g >= n_items_total) {
+            return NO_ITEM;
+        }
+        const unsigned int b = __popcll(__ballot(g >= bucket_end)); // first bucket whose end is beyond g
+        const unsigned int first = b ? __shfl(bucket_end, b - 1, 64) : 0u;
+        const unsigned int bucket = (b % NB_SHARDS) * NB_CLASSES + b / NB_SHARDS;
+        return __builtin_amdgcn_readfirstlane(bucket * items_cap + (g - first));
     };
     auto load_indices = [&](const int4 it, TileRegs<Real> &r) {
         r.rb = it.x;
@@ -232,31 +258,32 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     };
 
 #ifdef TM_TIMING
-    long long tm_setup = 0, tm_p1 = 0, tm_p2 = 0, tm_flush = 0, tm_items = 0, tm_batches = 0;
+    long long tm_setup = 0, tm_p1 = 0, tm_p2 = 0, tm_flush = 0, tm_items = 0, tm_batches = 0, tm_bc = 0, tm_stage_a = 0;
     const long long tm_begin = clock64();
+    const long long tm_real_begin = static_cast<long long>(__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
 #define TM_T(var) const long long var = clock64()
 #else
 #define TM_T(var)
 #endif
 
     // prologue: first item fetched the slow way; the second ticket is already taken
-    unsigned int item = take_ticket();
-    unsigned int item_next = take_ticket();
+    unsigned int item = resolve_ticket(request_ticket());
+    unsigned int item_next = resolve_ticket(request_ticket());
     TileRegs<Real> cur;
-    if (item < n_items) {
+    if (item != NO_ITEM) {
         load_indices(items[item], cur);
         load_records(cur);
     }
 
-    while (item < n_items) {
+    while (item != NO_ITEM) {
         TM_T(t_a);
         // ---- stage A
-        const bool have_next = item_next < n_items;
+        const bool have_next = item_next != NO_ITEM;
         int4 it_next = make_int4(0, 0, 0, 0);
         if (have_next) {
             it_next = items[item_next];
         }
-        const unsigned int item_after = take_ticket();
+        const unsigned int item_after = resolve_ticket(request_ticket());
         TileRegs<Real> nxt;
         nxt.ja = uK;
         nxt.ra = uK;
@@ -265,6 +292,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         const int rb = cur.rb;
         const unsigned int ja = cur.ja;
         __syncthreads(); // previous item's flush has finished reading LDS
+        TM_T(t_a2);
         if (lane < TILE) {
             s_rowatom[lane] = cur.ra;
 #pragma unroll
@@ -418,6 +446,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         // ---- stages B + C: the next item's indices, then its atom records, enter the memory queue ahead of this item's
         // flush atomics (returns are in order per wave: a load issued behind the atomics could not be observed before
         // every one of them has been acknowledged by the memory side)
+        TM_T(t_bc);
         if (have_next) {
             load_indices(it_next, nxt);
             load_records(nxt);
@@ -472,8 +501,10 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
             const long long t_d = clock64();
             tm_setup += t_b - t_a;
             tm_p2 += tm_p2_item;
-            tm_p1 += (t_c - t_b) - tm_p2_item;
+            tm_p1 += (t_bc - t_b) - tm_p2_item;
             tm_flush += t_d - t_c;
+            tm_bc += t_c - t_bc;
+            tm_stage_a += t_a2 - t_a;
             tm_items++;
         }
 #endif
@@ -487,11 +518,11 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         t[0] = tm_setup;
         t[1] = tm_p1;
         t[2] = tm_p2;
-        t[3] = tm_flush;
-        t[4] = tm_items;
-        t[5] = tm_batches;
+        t[3] = tm_flush | (static_cast<long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 56) | (static_cast<long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff) << 40);
+        t[4] = tm_items | (tm_bc << 20);      // low 20 bits: items; the rest: cycles in stages B + C
+        t[5] = tm_batches | (tm_stage_a << 20); // low 20 bits: batches; the rest: cycles in stage A (up to the barrier)
         t[6] = clock64() - tm_begin;
-        t[7] = 0;
+        t[7] = tm_real_begin | (static_cast<long long>(__builtin_amdgcn_s_memrealtime()) << 32); // 100 MHz, device-wide
     }
 #endif
 

@@ -159,13 +159,16 @@ Neighborlist<Real>::Neighborlist(const int N) : max_size_(N), N_(N), NC_(N), NR_
     d_row_ext_.realloc(nb * 3);
     d_row_idxs_.realloc(N);
     d_col_idxs_.realloc(N);
-    d_counters_.realloc(4);
-    HIP_CHECK(hipMemset(d_counters_.data, 0, 4 * sizeof(unsigned int)));
+    d_counters_.realloc(NB_NUM_COUNTERS);
+    HIP_CHECK(hipMemset(d_counters_.data, 0, NB_NUM_COUNTERS * sizeof(unsigned int)));
     // Pool sized for the worst case: every block pair interacting.  Row subsets need rows x cols <= (nb/2)^2 block
     // pairs, always below the upper-triangular count used by the reference (neighborlist.cu:368-376).
     const size_t max_block_pairs = static_cast<size_t>(nb) * (nb + 1) / 2;
     d_col_atoms_.realloc(max_block_pairs * TILE);
-    d_items_.realloc(max_block_pairs * TILE / NB_CHUNK + nb + 1);
+    // one bucket per (shard = row block % 8, cost class); a shard's row blocks each yield at most ceil(N / 64) items
+    items_cap_ = std::min(static_cast<size_t>(nb / NB_SHARDS + 1) * (ceil_divide(N, NB_CHUNK) + 1),
+                          max_block_pairs * TILE / NB_CHUNK + nb + 1);
+    d_items_.realloc(static_cast<size_t>(NB_SHARDS) * NB_CLASSES * items_cap_);
     d_row_segments_.realloc(nb);
     HIP_CHECK(hipMemset(d_row_segments_.data, 0, nb * sizeof(int2)));
     this->reset_row_idxs();
@@ -247,8 +250,8 @@ template <typename Real> unsigned int Neighborlist<Real>::num_tile_ixns() {
 
 template <typename Real>
 void Neighborlist<Real>::build_device(
-    const Real *d_gathered, const double *d_box, const double cutoff, const int *d_flag, const int force, const int n_snap,
-    const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream) {
+    const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
+    const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream) {
     const bool ut = this->upper_triangular();
     const int ncb = this->num_column_blocks();
     const int nrb = this->num_row_blocks();
@@ -266,12 +269,12 @@ void Neighborlist<Real>::build_device(
     if (ut) {
         k_find_ixns<Real, true><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
-            cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
+            cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
             d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
     } else {
         k_find_ixns<Real, false><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
-            d_gathered, d_box, cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, d_row_segments_.data,
+            d_gathered, d_box, cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
             d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
     }
     HIP_CHECK(hipGetLastError());
@@ -296,7 +299,7 @@ Neighborlist<Real>::get_nblist_host(const int N, const double *h_coords, const d
     }
     DeviceBuffer<double> d_box(9);
     this->gather_host_coords(N, h_coords, h_box, d_box);
-    this->build_device(d_scratch_gathered_.data, d_box.data, cutoff, nullptr, 1, 0, nullptr, nullptr, nullptr, 0);
+    this->build_device(d_scratch_gathered_.data, d_box.data, cutoff, cutoff, nullptr, 1, 0, nullptr, nullptr, nullptr, 0);
     HIP_CHECK(hipStreamSynchronize(0));
     const int nrb = this->num_row_blocks();
     std::vector<int2> segs(nrb);
@@ -409,8 +412,6 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
     grid_ = device_cu_count() * 4 * TileWaves<Real>::value;
     d_timing_.realloc(static_cast<size_t>(grid_) * 8);
     HIP_CHECK(hipMemset(d_timing_.data, 0, d_timing_.size()));
-    d_work_ctr_.realloc(NB_SHARDS * NB_SHARD_STRIDE);
-    HIP_CHECK(hipMemset(d_work_ctr_.data, 0, d_work_ctr_.size()));
     d_u_partials_.realloc(grid_);
     if (!disable_hilbert_) {
         hilbert_.reset(new HilbertSort(N_));
@@ -476,20 +477,20 @@ void NonbondedAllPairs<Real>::execute_device(
     int *flag_next = d_flags_.data + (parity_ ^ 1);
     k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
         K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
-        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_work_ctr_.data);
+        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr);
     HIP_CHECK(hipGetLastError());
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     nblist_.build_device(
-        d_gathered_.data, d_box, cutoff_ + nblist_padding_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream);
+        d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream);
 
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
 #define TM_LAUNCH_TILES(U, X, PP)                                                                                      \
     k_nonbonded_tiles<Real, U, X, PP><<<grid_, 64, 0, stream>>>(                                                      \
-        K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(), d_counters + 1,\
-        nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, d_g_du_dx_.data,            \
-        d_g_du_dp_.data, d_u_partials_.data, d_work_ctr_.data, d_timing_.data)
+        K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
+        d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
+        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, d_u_partials_.data, d_timing_.data)
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
     switch (sel) {
