@@ -147,6 +147,15 @@ def test_config2_all_terms(co, P, lamb, precision):
     np.testing.assert_array_equal(du_dx, du_dx_s)
     np.testing.assert_array_equal(du_dp, du_dp_s)
     assert u == u_s
+    # forces only (the MD path) runs bonded terms + exclusions in ONE fused launch: same bits again, and the same bits
+    # as the fixed-point sum of the children executed one by one
+    du_dx_f, none_p, none_u = serial.unbound_impl.execute(x, flat, box, True, False, False)
+    assert none_p is None and none_u is None
+    np.testing.assert_array_equal(du_dx_f, du_dx)
+    acc = np.zeros(x.size, dtype=np.uint64)
+    for pot, prm in zip(pots, prms):
+        acc += pot.to_gpu(precision).unbound_impl.execute_raw(x, np.asarray(prm, dtype=np.float64), box, True, False, False)[0].reshape(-1)
+    np.testing.assert_array_equal(acc.view(np.int64).astype(np.float64).reshape(x.shape) / co.FIXED_EXPONENT, du_dx_f)
 
 
 # ----------------------------------------------------------------------------------------------------------------

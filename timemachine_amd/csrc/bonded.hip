@@ -1,240 +1,8 @@
-// HarmonicBond / HarmonicAngle / PeriodicTorsion for gfx950.
-// reference kernels: cpp/src/kernels/k_harmonic_bond.cuh:6-60, k_harmonic_angle.cuh:9-146, k_periodic_torsion.cuh:20-131
-// reference JAX energies: timemachine/potentials/bonded.py:34-216
-//
-// One thread per term; fixed-point u64 atomics into du_dx / du_dp; energies are summed per wave (64 lanes) into
-// signed-128 partials and then reduced -- one 16-byte store per wave instead of one per term.
-// Compiled with -ffp-contract=off: a*b - c*d style expressions are never fused, which is what keeps the
-// index-reversal bitwise symmetry the reference gets from __dmul_rn/__dadd_rn (cpp/src/gpu_utils.cuh:111-121).
-#include "engine.hpp"
-#include "fixed_point.cuh"
+// HarmonicBond / HarmonicAngle / PeriodicTorsion host classes (device code: kernels_bonded.cuh).
+// reference: cpp/src/harmonic_bond.cu, harmonic_angle.cu, periodic_torsion.cu
+#include "kernels_bonded.cuh"
 
 namespace tmamd {
-
-template <typename Real> __device__ __forceinline__ Real tm_sqrt(Real x);
-template <> __device__ __forceinline__ float tm_sqrt<float>(float x) { return sqrtf(x); }
-template <> __device__ __forceinline__ double tm_sqrt<double>(double x) { return sqrt(x); }
-
-template <typename Real> __device__ __forceinline__ void store_wave_energy(i128 e, i128 *__restrict__ u_partials) {
-    const i128 total = wave_sum_i128(e);
-    if ((threadIdx.x & 63) == 0) {
-        u_partials[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = total;
-    }
-}
-
-template <typename Real>
-__global__ __launch_bounds__(256) void k_harmonic_bond(
-    const int B, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ bond_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    i128 energy = 0;
-    if (b < B) {
-        const int src = bond_idxs[b * 2 + 0], dst = bond_idxs[b * 2 + 1];
-        Real dx[3];
-        Real d2 = 0;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const Real delta = static_cast<Real>(coords[src * 3 + d]) - static_cast<Real>(coords[dst * 3 + d]);
-            dx[d] = delta;
-            d2 += delta * delta;
-        }
-        const Real kb = static_cast<Real>(params[b * 2 + 0]);
-        const Real b0 = static_cast<Real>(params[b * 2 + 1]);
-        const Real dij = tm_sqrt<Real>(d2);
-        const Real db = dij - b0;
-        if (du_dx) {
-            const Real inv_dij = 1 / dij;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const Real g = b0 != 0 ? kb * db * dx[d] * inv_dij : kb * dx[d];
-                atomicAdd(du_dx + src * 3 + d, float_to_fixed<Real>(g));
-                atomicAdd(du_dx + dst * 3 + d, float_to_fixed<Real>(-g));
-            }
-        }
-        if (du_dp) {
-            atomicAdd(du_dp + b * 2 + 0, float_to_fixed<Real>(static_cast<Real>(0.5) * db * db));
-            atomicAdd(du_dp + b * 2 + 1, float_to_fixed<Real>(-kb * db));
-        }
-        if (u_partials) {
-            energy = float_to_fixed_energy<Real>(kb / 2 * db * db);
-        }
-    }
-    if (u_partials) {
-        store_wave_energy<Real>(energy, u_partials);
-    }
-}
-
-template <typename Real>
-__global__ __launch_bounds__(256) void k_harmonic_angle(
-    const int A, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ angle_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
-    const int a_idx = blockIdx.x * blockDim.x + threadIdx.x;
-    i128 energy = 0;
-    if (a_idx < A) {
-        const int i = angle_idxs[a_idx * 3 + 0], j = angle_idxs[a_idx * 3 + 1], k = angle_idxs[a_idx * 3 + 2];
-        const Real ka = static_cast<Real>(params[a_idx * 3 + 0]);
-        const Real a0 = static_cast<Real>(params[a_idx * 3 + 1]);
-        const Real eps = static_cast<Real>(params[a_idx * 3 + 2]);
-
-        // 4-D vectors j->i and j->k with eps as the stabilising 4th component (bonded.py:82-97)
-        Real rji[4], rjk[4];
-        Real nji = 0, njk = 0;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const Real cj = static_cast<Real>(coords[j * 3 + d]);
-            rji[d] = static_cast<Real>(coords[i * 3 + d]) - cj;
-            rjk[d] = static_cast<Real>(coords[k * 3 + d]) - cj;
-            nji += rji[d] * rji[d];
-            njk += rjk[d] * rjk[d];
-        }
-        rji[3] = eps;
-        rjk[3] = eps;
-        nji = tm_sqrt<Real>(nji + eps * eps);
-        njk = tm_sqrt<Real>(njk + eps * eps);
-
-        // Kahan's angle: 2 atan2(|njk rji - nji rjk|, |njk rji + nji rjk|); products are rounded separately
-        // (no FMA) so swapping i and k reproduces the same bits
-        Real hi = 0, lo = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const Real p = njk * rji[d];
-            const Real q = nji * rjk[d];
-            const Real s = p - q;
-            const Real t = p + q;
-            hi += s * s;
-            lo += t * t;
-        }
-        const Real angle = 2 * atan2(tm_sqrt<Real>(hi), tm_sqrt<Real>(lo));
-        const Real delta = angle - a0;
-
-        // gradient direction via a x (a x b) = a (a.b) - b (a.a)
-        Real a_dot_b = 0, a_dot_a = 0, b_dot_b = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            a_dot_b += rji[d] * rjk[d];
-            a_dot_a += rji[d] * rji[d];
-            b_dot_b += rjk[d] * rjk[d];
-        }
-        Real aab[4], bba[4];
-        Real aab_n = 0, bba_n = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            aab[d] = rji[d] * a_dot_b - rjk[d] * a_dot_a;
-            bba[d] = rjk[d] * a_dot_b - rji[d] * b_dot_b;
-            aab_n += aab[d] * aab[d];
-            bba_n += bba[d] * bba[d];
-        }
-        aab_n = tm_sqrt<Real>(aab_n);
-        bba_n = tm_sqrt<Real>(bba_n);
-        const Real prefactor = ka * delta;
-        const Real coeff_i = prefactor * (1 / nji);
-        const Real coeff_k = prefactor * (1 / njk);
-
-        if (du_dx) {
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const Real gi = coeff_i * ((aab_n == 0) ? static_cast<Real>(0) : aab[d] / aab_n);
-                const Real gk = coeff_k * ((bba_n == 0) ? static_cast<Real>(0) : bba[d] / bba_n);
-                atomicAdd(du_dx + i * 3 + d, float_to_fixed<Real>(gi));
-                atomicAdd(du_dx + k * 3 + d, float_to_fixed<Real>(gk));
-                atomicAdd(du_dx + j * 3 + d, float_to_fixed<Real>(-gi - gk));
-            }
-        }
-        if (du_dp) {
-            atomicAdd(du_dp + a_idx * 3 + 0, float_to_fixed<Real>(delta * delta / 2));
-            atomicAdd(du_dp + a_idx * 3 + 1, float_to_fixed<Real>(-delta * ka));
-            const Real e0 = (aab_n == 0) ? static_cast<Real>(0) : coeff_i * aab[3] / aab_n;
-            const Real e1 = (bba_n == 0) ? static_cast<Real>(0) : coeff_k * bba[3] / bba_n;
-            atomicAdd(du_dp + a_idx * 3 + 2, float_to_fixed<Real>(e0 + e1));
-        }
-        if (u_partials) {
-            energy = float_to_fixed_energy<Real>((ka / 2) * delta * delta);
-        }
-    }
-    if (u_partials) {
-        store_wave_energy<Real>(energy, u_partials);
-    }
-}
-
-template <typename Real> __device__ __forceinline__ Real dot3(const Real a[3], const Real b[3]) {
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-}
-// every product individually rounded => cross(a, b) == -cross(b, a) bit for bit
-template <typename Real> __device__ __forceinline__ void cross3(const Real a[3], const Real b[3], Real c[3]) {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-template <typename Real>
-__global__ __launch_bounds__(256) void k_periodic_torsion(
-    const int T, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ torsion_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
-    const int t_idx = blockIdx.x * blockDim.x + threadIdx.x;
-    i128 energy = 0;
-    if (t_idx < T) {
-        const int i = torsion_idxs[t_idx * 4 + 0], j = torsion_idxs[t_idx * 4 + 1];
-        const int k = torsion_idxs[t_idx * 4 + 2], l = torsion_idxs[t_idx * 4 + 3];
-        Real rij[3], rkj[3], rkl[3];
-        Real rkj_n2 = 0;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const Real ci = static_cast<Real>(coords[i * 3 + d]), cj = static_cast<Real>(coords[j * 3 + d]);
-            const Real ck = static_cast<Real>(coords[k * 3 + d]), cl = static_cast<Real>(coords[l * 3 + d]);
-            rij[d] = cj - ci;
-            rkj[d] = cj - ck;
-            rkl[d] = cl - ck;
-            rkj_n2 += rkj[d] * rkj[d];
-        }
-        const Real rkj_norm = tm_sqrt<Real>(rkj_n2);
-        Real n1[3], n2[3], n3[3];
-        cross3(rij, rkj, n1);
-        cross3(rkj, rkl, n2);
-        cross3(n1, n2, n3);
-        const Real n1_n2sq = dot3(n1, n1), n2_n2sq = dot3(n2, n2);
-        const Real rij_dot_rkj = dot3(rij, rkj), rkl_dot_rkj = dot3(rkl, rkj);
-
-        Real dR0[3], dR1[3], dR2[3], dR3[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            dR0[d] = rkj_norm / n1_n2sq * n1[d];
-            dR3[d] = -rkj_norm / n2_n2sq * n2[d];
-            dR1[d] = (rij_dot_rkj / rkj_n2 - 1) * dR0[d] - dR3[d] * rkl_dot_rkj / rkj_n2;
-            dR2[d] = (rkl_dot_rkj / rkj_n2 - 1) * dR3[d] - dR0[d] * rij_dot_rkj / rkj_n2;
-        }
-        const Real rkj_n = tm_sqrt<Real>(dot3(rkj, rkj));
-        Real rkj_hat[3] = {rkj[0] / rkj_n, rkj[1] / rkj_n, rkj[2] / rkj_n};
-        const Real angle = atan2(dot3(n3, rkj_hat), dot3(n1, n2));
-
-        const Real kt = static_cast<Real>(params[t_idx * 3 + 0]);
-        const Real phase = static_cast<Real>(params[t_idx * 3 + 1]);
-        const Real period = static_cast<Real>(params[t_idx * 3 + 2]);
-        const Real arg = period * angle - phase;
-        const Real s = sin(arg), c = cos(arg);
-        const Real prefactor = kt * s * period;
-
-        if (du_dx) {
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                atomicAdd(du_dx + i * 3 + d, float_to_fixed<Real>(dR0[d] * prefactor));
-                atomicAdd(du_dx + j * 3 + d, float_to_fixed<Real>(dR1[d] * prefactor));
-                atomicAdd(du_dx + k * 3 + d, float_to_fixed<Real>(dR2[d] * prefactor));
-                atomicAdd(du_dx + l * 3 + d, float_to_fixed<Real>(dR3[d] * prefactor));
-            }
-        }
-        if (du_dp) {
-            atomicAdd(du_dp + t_idx * 3 + 0, float_to_fixed<Real>(1 + c));
-            atomicAdd(du_dp + t_idx * 3 + 1, float_to_fixed<Real>(kt * s));
-            atomicAdd(du_dp + t_idx * 3 + 2, float_to_fixed<Real>(-kt * s * angle));
-        }
-        if (u_partials) {
-            energy = float_to_fixed_energy<Real>(kt * (1 + c));
-        }
-    }
-    if (u_partials) {
-        store_wave_energy<Real>(energy, u_partials);
-    }
-}
 
 // ---- host classes ------------------------------------------------------------------------------------------
 
@@ -251,6 +19,16 @@ template <typename Real> HarmonicBond<Real>::HarmonicBond(const std::vector<int>
     if (B_ > 0)
         d_idxs_.copy_from(bond_idxs.data());
     d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
+}
+
+template <typename Real> void HarmonicBond<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    if (P != 2 * B_) {
+        throw std::runtime_error(
+            "HarmonicBond::execute_device(): expected P == 2*B, got P=" + std::to_string(P) + ", 2*B=" + std::to_string(2 * B_));
+    }
+    if (B_ > 0) {
+        plan.add_segment(sizeof(Real), FusedSegment{FUSED_BOND, B_, d_idxs_.data, d_p, nullptr, 0.0, 0.0}, this, P, d_p);
+    }
 }
 
 template <typename Real>
@@ -286,6 +64,16 @@ template <typename Real> HarmonicAngle<Real>::HarmonicAngle(const std::vector<in
     d_u_partials_.realloc(ceil_divide(A_, 256) * 4 + 1);
 }
 
+template <typename Real> void HarmonicAngle<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    if (P != 3 * A_) {
+        throw std::runtime_error(
+            "HarmonicAngle::execute_device(): expected P == 3*A, got P=" + std::to_string(P) + ", 3*A=" + std::to_string(3 * A_));
+    }
+    if (A_ > 0) {
+        plan.add_segment(sizeof(Real), FusedSegment{FUSED_ANGLE, A_, d_idxs_.data, d_p, nullptr, 0.0, 0.0}, this, P, d_p);
+    }
+}
+
 template <typename Real>
 void HarmonicAngle<Real>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
@@ -317,6 +105,16 @@ template <typename Real> PeriodicTorsion<Real>::PeriodicTorsion(const std::vecto
     if (T_ > 0)
         d_idxs_.copy_from(torsion_idxs.data());
     d_u_partials_.realloc(ceil_divide(T_, 256) * 4 + 1);
+}
+
+template <typename Real> void PeriodicTorsion<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    if (P != 3 * T_) {
+        throw std::runtime_error(
+            "PeriodicTorsion::execute_device(): expected P == 3*T, got P=" + std::to_string(P) + ", 3*T=" + std::to_string(3 * T_));
+    }
+    if (T_ > 0) {
+        plan.add_segment(sizeof(Real), FusedSegment{FUSED_TORSION, T_, d_idxs_.data, d_p, nullptr, 0.0, 0.0}, this, P, d_p);
+    }
 }
 
 template <typename Real>

@@ -17,10 +17,55 @@ int device_cu_count();
 
 // ------------------------------------------------------------------------------------------------------------
 // reference: cpp/src/potential.hpp:7-96, cpp/src/potential.cu
+// ---- fused force evaluation (the MD path: du_dx only) ---------------------------------------------------------
+// The bonded terms and the exclusion / pair lists are each a few microseconds of work -- shorter than a kernel launch
+// is worth.  When only forces are requested, potentials describe themselves to a ForcePlan instead of launching; the
+// plan runs every listed term in ONE kernel per precision and executes whatever cannot be fused (the neighbor-list
+// potentials) the normal way.  Integer accumulation makes the result independent of this regrouping, bit for bit.
+enum FusedKind : int { FUSED_BOND = 0, FUSED_ANGLE = 1, FUSED_TORSION = 2, FUSED_PAIR_LIST = 3, FUSED_PAIR_LIST_NEGATED = 4 };
+static const int FUSED_MAX_SEGMENTS = 16;
+struct FusedSegment {
+    int kind;
+    int count;            // terms
+    const int *idxs;      // [count][2|3|4]
+    const double *params; // bonded: [count][2|3]; pair lists: the [N][4] nonbonded parameters
+    const double *scales; // pair lists: [count][2]
+    double beta, cutoff;  // pair lists
+};
+struct FusedTable {
+    int n;
+    int block_end[FUSED_MAX_SEGMENTS]; // exclusive prefix sum of 256-thread blocks per segment
+    FusedSegment seg[FUSED_MAX_SEGMENTS];
+};
+class Potential;
+class ForcePlan {
+public:
+    struct Rest {
+        Potential *pot;
+        int P;
+        const double *d_p;
+    };
+    void clear();
+    void add_segment(const int precision_bytes, const FusedSegment &seg, Potential *owner, const int P, const double *d_p);
+    void add_rest(Potential *pot, const int P, const double *d_p) { rest_.push_back({pot, P, d_p}); }
+    // launches everything; accumulates into d_du_dx
+    void run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream);
+
+private:
+    FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
+    FusedTable uploaded_[2];              // what d_table_ currently holds
+    bool uploaded_valid_[2] = {false, false};
+    DeviceBuffer<FusedTable> d_table_[2];
+    std::vector<Rest> rest_;
+};
+
 class Potential {
 public:
     virtual ~Potential() {}
     static const int D = 3;
+
+    // Forces-only planning hook (see ForcePlan).  Default: not fusable, executed through execute_device.
+    virtual void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) { plan.add_rest(this, P, d_p); }
 
     // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
     virtual void execute_device(
@@ -96,6 +141,7 @@ public:
     SummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel);
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
     const std::vector<int> &get_parameter_sizes() { return params_sizes_; }
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
@@ -106,6 +152,7 @@ private:
     bool parallel_;
     DeviceBuffer<i128> d_u_buffer_;
     StreamFork fork_;
+    ForcePlan plan_;
 };
 
 // reference: cpp/src/fanout_summed_potential.cu:23-68
@@ -113,6 +160,7 @@ class FanoutSummedPotential : public Potential {
 public:
     FanoutSummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const bool parallel);
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
@@ -121,6 +169,7 @@ private:
     bool parallel_;
     DeviceBuffer<i128> d_u_buffer_;
     StreamFork fork_;
+    ForcePlan plan_;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -129,6 +178,7 @@ private:
 template <typename Real> class HarmonicBond : public Potential {
 public:
     explicit HarmonicBond(const std::vector<int> &bond_idxs);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
 private:
     int B_;
@@ -139,6 +189,7 @@ private:
 template <typename Real> class HarmonicAngle : public Potential {
 public:
     explicit HarmonicAngle(const std::vector<int> &angle_idxs);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
 private:
     int A_;
@@ -149,6 +200,7 @@ private:
 template <typename Real> class PeriodicTorsion : public Potential {
 public:
     explicit PeriodicTorsion(const std::vector<int> &torsion_idxs);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
 private:
     int T_;
@@ -273,6 +325,7 @@ void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);
 template <typename Real, bool Negated> class NonbondedPairList : public Potential {
 public:
     NonbondedPairList(const std::vector<int> &pair_idxs, const std::vector<double> &scales, const double beta, const double cutoff);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 private:
@@ -310,6 +363,7 @@ private:
     unsigned long long step_;
     DeviceBuffer<Real> d_cbs_, d_ccs_;
     DeviceBuffer<u64> d_du_dx_;
+    ForcePlan plan_;
 };
 
 // reference: cpp/src/mover.hpp (interface only; no movers are implemented on this path yet)

@@ -1,0 +1,94 @@
+// ForcePlan: all bonded terms and pair lists of a step in one kernel launch per precision (see engine.hpp).
+// The per-term device functions are the ones the stand-alone kernels call (kernels_bonded.cuh, kernels_nonbonded.cuh),
+// so a fused launch produces the same bits as separate launches.
+#include <cstring>
+
+#include "kernels_bonded.cuh"
+#include "kernels_nonbonded.cuh"
+#include "profiler.hpp"
+
+namespace tmamd {
+
+template <typename Real>
+__global__ __launch_bounds__(256) void k_fused_forces(
+    const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx) {
+    const int n = table->n;
+    int s = 0, first = 0;
+    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
+        const int end = table->block_end[k];
+        if (static_cast<int>(blockIdx.x) >= end) {
+            s = k + 1;
+            first = end;
+        }
+    }
+    const FusedSegment seg = table->seg[s];
+    const int idx = (static_cast<int>(blockIdx.x) - first) * 256 + static_cast<int>(threadIdx.x);
+    if (idx >= seg.count) {
+        return;
+    }
+    switch (seg.kind) {
+    case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_PAIR_LIST:
+        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        break;
+    case FUSED_PAIR_LIST_NEGATED:
+        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        break;
+    default: break;
+    }
+}
+
+void ForcePlan::clear() {
+    host_[0].n = 0;
+    host_[1].n = 0;
+    rest_.clear();
+}
+
+void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, Potential *owner, const int P, const double *d_p) {
+    FusedTable &t = host_[precision_bytes == 8 ? 1 : 0];
+    if (t.n >= FUSED_MAX_SEGMENTS) {
+        rest_.push_back({owner, P, d_p}); // table full: this one runs on its own
+        return;
+    }
+    const int blocks = ceil_divide(seg.count, 256);
+    t.block_end[t.n] = (t.n ? t.block_end[t.n - 1] : 0) + blocks;
+    t.seg[t.n] = seg;
+    t.n++;
+}
+
+void ForcePlan::run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream) {
+    for (const Rest &r : rest_) {
+        r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
+    }
+    for (int prec = 0; prec < 2; prec++) {
+        FusedTable &t = host_[prec];
+        if (t.n == 0) {
+            continue;
+        }
+        // unused tail of the table: keep it deterministic so the "unchanged since the last upload" test is exact
+        for (int k = t.n; k < FUSED_MAX_SEGMENTS; k++) {
+            t.block_end[k] = 0;
+            t.seg[k] = FusedSegment{0, 0, nullptr, nullptr, nullptr, 0.0, 0.0};
+        }
+        if (!uploaded_valid_[prec] || std::memcmp(&uploaded_[prec], &t, sizeof(FusedTable)) != 0) {
+            d_table_[prec].reserve(1);
+            // pageable source: the runtime stages the bytes before returning, so host_ may change right away
+            HIP_CHECK(hipMemcpyAsync(d_table_[prec].data, &t, sizeof(FusedTable), hipMemcpyHostToDevice, stream));
+            std::memcpy(&uploaded_[prec], &t, sizeof(FusedTable));
+            uploaded_valid_[prec] = true;
+        }
+        const int blocks = t.block_end[t.n - 1];
+        const int prof = Profiler::get().begin("fused_forces", stream);
+        if (prec == 1) {
+            k_fused_forces<double><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_du_dx);
+        } else {
+            k_fused_forces<float><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_du_dx);
+        }
+        HIP_CHECK(hipGetLastError());
+        Profiler::get().end("fused_forces", prof, stream);
+    }
+}
+
+} // namespace tmamd

@@ -118,9 +118,12 @@ template <typename Real>
 void LangevinIntegrator<Real>::step_fwd(
     std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
     hipStream_t stream) {
+    // forces only: every bound potential describes itself to one plan, so short per-term kernels share a launch
+    plan_.clear();
     for (auto &bp : bps) {
-        bp->execute_device(N_, d_x_t, d_box_t, d_du_dx_.data, nullptr, nullptr, stream); // forces only
+        bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
     }
+    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream);
     const int tpb = 256;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
         N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_);

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     __shared__ int s_list[NBL_CHUNK];
     __shared__ Real s_rx[TILE], s_ry[TILE], s_rz[TILE];
     __shared__ unsigned int s_npass, s_nlist, s_count, s_seg_start;
+    __shared__ unsigned int s_hist[NB_CLASSES], s_base[NB_CLASSES];
+    __shared__ float s_rf[3][TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -271,13 +273,16 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     }
 
     // ---- publish the segment and its work items
-    // Every item gets a cost estimate -- the number of (row, column) pairs inside the list cutoff -- and is filed into
-    // bucket (shard = row block % 8, cost class), class 0 = heaviest.  The tile kernel's waves drain the buckets of their
-    // shard in class order (longest processing time first): items differ in cost by more than an order of magnitude and
+    // Every item gets a cost estimate -- the number of (row, column) pairs inside `cost_cutoff` -- and is filed into
+    // bucket (shard = row block % NB_SHARDS, cost class), class 0 = heaviest.  The tile kernel deals the buckets to its
+    // waves in that order (longest processing time first): items differ in cost by more than an order of magnitude and
     // a wave only processes a handful, so an arbitrary order leaves most waves idle while the unluckiest one finishes a
-    // heavy item it drew last.  64 bucket cursors instead of one keep the (slow, memory-side) atomics off a single address.
+    // heavy item it drew last.  Bucket space is claimed per workgroup (one returning atomic per non-empty class --
+    // returning global atomics are slow) and spread over NB_SHARDS cursors per class.
     const unsigned int count = s_count;
     const unsigned int n_chunks = (count + NB_CHUNK - 1) / NB_CHUNK;
+    const unsigned int n_staged = n_chunks < static_cast<unsigned int>(NBL_CHUNK) ? n_chunks : NBL_CHUNK; // staged in s_list
+    const unsigned int shard = static_cast<unsigned int>(rb) & (NB_SHARDS - 1);
     if (tid == 0) {
         row_segments[rb] = make_int2(static_cast<int>(seg_start), static_cast<int>(count));
         atomicAdd(&counters[2], (count + TILE - 1) / TILE);
@@ -285,7 +290,20 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
             atomicAdd(&counters[1], n_chunks);
         }
     }
-    const Real cost_cutoff2 = static_cast<Real>(cost_cutoff_d) * static_cast<Real>(cost_cutoff_d);
+    if (tid < NB_CLASSES) {
+        s_hist[tid] = 0;
+    }
+    // the estimate runs in f32 on coordinates relative to the first row atom
+    const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
+    const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
+    const float cost_cutoff2 = static_cast<float>(cost_cutoff_d * cost_cutoff_d);
+    const Real ox = s_rx[0], oy = s_ry[0], oz = s_rz[0];
+    if (tid < TILE) {
+        s_rf[0][tid] = static_cast<float>(min_image(s_rx[tid] - ox, bx.x, bx.inv_x));
+        s_rf[1][tid] = static_cast<float>(min_image(s_ry[tid] - oy, bx.y, bx.inv_y));
+        s_rf[2][tid] = static_cast<float>(min_image(s_rz[tid] - oz, bx.z, bx.inv_z));
+    }
+    __syncthreads();
     for (unsigned int c = wave; c < n_chunks; c += NBL_THREADS / 64) {
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
@@ -296,15 +314,16 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         }
         unsigned int mine = 0;
         if (ja < static_cast<unsigned int>(K)) {
-            const Real xj = gathered[static_cast<size_t>(ja) * 8 + 0];
-            const Real yj = gathered[static_cast<size_t>(ja) * 8 + 1];
-            const Real zj = gathered[static_cast<size_t>(ja) * 8 + 2];
+            const float xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
+            const float yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
+            const float zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
             for (int i = 0; i < nrow; i++) {
-                const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
-                const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
-                const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
+                float dx = s_rf[0][i] - xj, dy = s_rf[1][i] - yj, dz = s_rf[2][i] - zj;
+                dx = __builtin_fmaf(-fbx, __builtin_rintf(dx * fibx), dx);
+                dy = __builtin_fmaf(-fby, __builtin_rintf(dy * fiby), dy);
+                dz = __builtin_fmaf(-fbz, __builtin_rintf(dz * fibz), dz);
                 const bool order_ok = !UPPER_TRIANGULAR || static_cast<unsigned int>(rb * TILE + i) < ja;
-                mine += (order_ok && (dx * dx + dy * dy + dz * dz) < cost_cutoff2) ? 1u : 0u;
+                mine += (order_ok && __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) < cost_cutoff2) ? 1u : 0u;
             }
         }
         unsigned int total = mine;
@@ -314,20 +333,30 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         }
         if (lane == 0) {
             const unsigned int heavy = total / NB_CLASS_PAIRS;
-#ifdef TM_NO_COST_ORDER
-            const unsigned int cls = 0 * heavy; // debug builds: arbitrary order, for A/B measurements
-#else
             const unsigned int cls = NB_CLASSES - 1 - (heavy < NB_CLASSES - 1 ? heavy : NB_CLASSES - 1);
-#endif
-#ifdef TM_SHARD_BY_CHUNK
-            const unsigned int bucket = ((static_cast<unsigned int>(rb) + c) & (NB_SHARDS - 1)) * NB_CLASSES + cls;
-#else
-            const unsigned int bucket = (static_cast<unsigned int>(rb) & (NB_SHARDS - 1)) * NB_CLASSES + cls;
-#endif
-            const unsigned int pos = atomicAdd(&counters[NB_COUNTER_CLASS0 + bucket], 1u);
-            items[static_cast<size_t>(bucket) * items_cap + pos] =
-                make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
+            if (c < n_staged) {
+                const unsigned int pos = atomicAdd(&s_hist[cls], 1u); // LDS
+                s_list[c] = static_cast<int>(total | (pos << 12) | (cls << 23)); // total <= 2048, pos < NBL_CHUNK = 2048
+            } else { // more chunks than the staging area holds (N > 131k): claim one by one
+                const unsigned int bucket = shard * NB_CLASSES + cls;
+                const unsigned int pos = atomicAdd(&counters[NB_COUNTER_CLASS0 + bucket], 1u);
+                items[static_cast<size_t>(bucket) * items_cap + pos] =
+                    make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
+            }
         }
+    }
+    __syncthreads();
+    if (tid < NB_CLASSES && s_hist[tid] != 0) {
+        s_base[tid] = atomicAdd(&counters[NB_COUNTER_CLASS0 + shard * NB_CLASSES + tid], s_hist[tid]);
+    }
+    __syncthreads();
+    for (unsigned int c = tid; c < n_staged; c += NBL_THREADS) {
+        const unsigned int packed = static_cast<unsigned int>(s_list[c]);
+        const unsigned int total = packed & 0xfffu, pos = (packed >> 12) & 0x7ffu, cls = packed >> 23;
+        const unsigned int off = c * NB_CHUNK;
+        const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
+        items[static_cast<size_t>(shard * NB_CLASSES + cls) * items_cap + s_base[cls] + pos] =
+            make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
     }
 }
 

@@ -536,6 +536,70 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 
 // ---- pair-list kernel (NonbondedPairList / NonbondedExclusions) ----------------------------------------------
 // reference: k_nonbonded_pair_list (k_nonbonded_pair_list.cuh:18-190).  One thread per listed pair, same nb_pair().
+// one listed pair; returns its (signed) energy in fixed point (0 unless want_u)
+template <typename Real, bool NEGATED>
+__device__ __forceinline__ i128 nonbonded_pair_list_term(
+    const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
+    const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    i128 energy = 0;
+    const NbBox<Real> bx = load_box<Real>(box);
+    const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
+    const Real cutoff = static_cast<Real>(cutoff_d);
+    const Real cutoff2 = cutoff * cutoff;
+    const Real dx = min_image(static_cast<Real>(coords[ia * 3 + 0]) - static_cast<Real>(coords[ja * 3 + 0]), bx.x, bx.inv_x);
+    const Real dy = min_image(static_cast<Real>(coords[ia * 3 + 1]) - static_cast<Real>(coords[ja * 3 + 1]), bx.y, bx.inv_y);
+    const Real dz = min_image(static_cast<Real>(coords[ia * 3 + 2]) - static_cast<Real>(coords[ja * 3 + 2]), bx.z, bx.inv_z);
+    const Real qi = static_cast<Real>(params[ia * 4 + 0]), qj = static_cast<Real>(params[ja * 4 + 0]);
+    const Real sig_i = static_cast<Real>(params[ia * 4 + 1]), sig_j = static_cast<Real>(params[ja * 4 + 1]);
+    const Real eps_i = static_cast<Real>(params[ia * 4 + 2]), eps_j = static_cast<Real>(params[ja * 4 + 2]);
+    const Real dw = static_cast<Real>(params[ia * 4 + 3]) - static_cast<Real>(params[ja * 4 + 3]);
+    const Real d2 = pair_d2(dx, dy, dz, dw);
+    if (d2 < cutoff2) {
+        const Real charge_scale = static_cast<Real>(scales[pair * 2 + 0]);
+        const Real lj_scale = static_cast<Real>(scales[pair * 2 + 1]);
+        PairOut<Real> o;
+        nb_pair<Real>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o);
+#define TM_ACC(ptr, val)                                                                                               \
+do {                                                                                                               \
+    const u64 v_ = (val);                                                                                          \
+    atomicAdd((ptr), NEGATED ? (0ull - v_) : v_);                                                                  \
+} while (0)
+        if (du_dx) {
+            u64 fx, fy, fz;
+            pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
+            TM_ACC(du_dx + ia * 3 + 0, fx);
+            TM_ACC(du_dx + ia * 3 + 1, fy);
+            TM_ACC(du_dx + ia * 3 + 2, fz);
+            TM_ACC(du_dx + ja * 3 + 0, 0ull - fx);
+            TM_ACC(du_dx + ja * 3 + 1, 0ull - fy);
+            TM_ACC(du_dx + ja * 3 + 2, 0ull - fz);
+        }
+        if (du_dp) {
+            TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
+            TM_ACC(du_dp + ja * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qi * o.inv_dij * o.ebd)));
+            if (o.has_lj) {
+                const u64 sg = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(o.sig_grad);
+                TM_ACC(du_dp + ia * 4 + 1, sg);
+                TM_ACC(du_dp + ja * 4 + 1, sg);
+                TM_ACC(du_dp + ia * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j)));
+                TM_ACC(du_dp + ja * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i)));
+            }
+            const u64 gw = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * dw);
+            TM_ACC(du_dp + ia * 4 + 3, gw);
+            TM_ACC(du_dp + ja * 4 + 3, 0ull - gw);
+        }
+#undef TM_ACC
+        if (want_u) {
+            // negate the fixed-point value, not the float (k_nonbonded_pair_list.cuh:185-188)
+            const i128 e = float_to_fixed_energy<Real>(o.u);
+            energy = NEGATED ? -e : e;
+        }
+    }
+
+    return energy;
+}
+
 template <typename Real, bool NEGATED>
 __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
     const int M, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
@@ -544,59 +608,8 @@ __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     i128 energy = 0;
     if (pair < M) {
-        const NbBox<Real> bx = load_box<Real>(box);
-        const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
-        const Real cutoff = static_cast<Real>(cutoff_d);
-        const Real cutoff2 = cutoff * cutoff;
-        const Real dx = min_image(static_cast<Real>(coords[ia * 3 + 0]) - static_cast<Real>(coords[ja * 3 + 0]), bx.x, bx.inv_x);
-        const Real dy = min_image(static_cast<Real>(coords[ia * 3 + 1]) - static_cast<Real>(coords[ja * 3 + 1]), bx.y, bx.inv_y);
-        const Real dz = min_image(static_cast<Real>(coords[ia * 3 + 2]) - static_cast<Real>(coords[ja * 3 + 2]), bx.z, bx.inv_z);
-        const Real qi = static_cast<Real>(params[ia * 4 + 0]), qj = static_cast<Real>(params[ja * 4 + 0]);
-        const Real sig_i = static_cast<Real>(params[ia * 4 + 1]), sig_j = static_cast<Real>(params[ja * 4 + 1]);
-        const Real eps_i = static_cast<Real>(params[ia * 4 + 2]), eps_j = static_cast<Real>(params[ja * 4 + 2]);
-        const Real dw = static_cast<Real>(params[ia * 4 + 3]) - static_cast<Real>(params[ja * 4 + 3]);
-        const Real d2 = pair_d2(dx, dy, dz, dw);
-        if (d2 < cutoff2) {
-            const Real charge_scale = static_cast<Real>(scales[pair * 2 + 0]);
-            const Real lj_scale = static_cast<Real>(scales[pair * 2 + 1]);
-            PairOut<Real> o;
-            nb_pair<Real>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o);
-#define TM_ACC(ptr, val)                                                                                               \
-    do {                                                                                                               \
-        const u64 v_ = (val);                                                                                          \
-        atomicAdd((ptr), NEGATED ? (0ull - v_) : v_);                                                                  \
-    } while (0)
-            if (du_dx) {
-                u64 fx, fy, fz;
-                pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
-                TM_ACC(du_dx + ia * 3 + 0, fx);
-                TM_ACC(du_dx + ia * 3 + 1, fy);
-                TM_ACC(du_dx + ia * 3 + 2, fz);
-                TM_ACC(du_dx + ja * 3 + 0, 0ull - fx);
-                TM_ACC(du_dx + ja * 3 + 1, 0ull - fy);
-                TM_ACC(du_dx + ja * 3 + 2, 0ull - fz);
-            }
-            if (du_dp) {
-                TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
-                TM_ACC(du_dp + ja * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qi * o.inv_dij * o.ebd)));
-                if (o.has_lj) {
-                    const u64 sg = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(o.sig_grad);
-                    TM_ACC(du_dp + ia * 4 + 1, sg);
-                    TM_ACC(du_dp + ja * 4 + 1, sg);
-                    TM_ACC(du_dp + ia * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j)));
-                    TM_ACC(du_dp + ja * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i)));
-                }
-                const u64 gw = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * dw);
-                TM_ACC(du_dp + ia * 4 + 3, gw);
-                TM_ACC(du_dp + ja * 4 + 3, 0ull - gw);
-            }
-#undef TM_ACC
-            if (u_partials) {
-                // negate the fixed-point value, not the float (k_nonbonded_pair_list.cuh:185-188)
-                const i128 e = float_to_fixed_energy<Real>(o.u);
-                energy = NEGATED ? -e : e;
-            }
-        }
+        energy = nonbonded_pair_list_term<Real, NEGATED>(
+            pair, coords, params, box, pair_idxs, scales, beta_d, cutoff_d, du_dx, du_dp, u_partials != nullptr);
     }
     if (u_partials) {
         // per-wave partial sums instead of one 16-byte store per pair

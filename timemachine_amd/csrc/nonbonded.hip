@@ -562,6 +562,16 @@ NonbondedPairList<Real, Negated>::NonbondedPairList(
 }
 
 template <typename Real, bool Negated>
+void NonbondedPairList<Real, Negated>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    if (M_ > 0) {
+        plan.add_segment(
+            sizeof(Real),
+            FusedSegment{Negated ? FUSED_PAIR_LIST_NEGATED : FUSED_PAIR_LIST, M_, d_pair_idxs_.data, d_p, d_scales_.data, beta_, cutoff_},
+            this, P, d_p);
+    }
+}
+
+template <typename Real, bool Negated>
 void NonbondedPairList<Real, Negated>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {

@@ -282,10 +282,17 @@ void SummedPotential::execute_device(
             "SummedPotential::execute_device(): expected " + std::to_string(P_) + " parameters, got " + std::to_string(P));
     }
     const int n = potentials_.size();
+    const bool par = parallel_ && n > 1;
+    if (d_du_dx && !d_du_dp && !d_u) {
+        // forces only (the MD path): fuse the short per-term kernels of all children into one launch
+        plan_.clear();
+        this->plan_forces(N, P, d_p, plan_);
+        plan_.run(N, d_x, d_box, d_du_dx, stream);
+        return;
+    }
     if (d_u) {
         d_u_buffer_.zero_async(stream, n);
     }
-    const bool par = parallel_ && n > 1;
     if (par) {
         for (int i = 0; i < n; i++)
             fork_.fork_from(i, stream);
@@ -305,6 +312,20 @@ void SummedPotential::execute_device(
     }
 }
 
+void SummedPotential::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    if (P != P_) {
+        throw std::runtime_error(
+            "SummedPotential::execute_device(): expected " + std::to_string(P_) + " parameters, got " + std::to_string(P));
+    }
+    // `parallel` asks for children on concurrent streams; it is an execution hint with no effect on results, and one
+    // fused launch beats several concurrent tiny ones (measured), so the forces-only plan supersedes it
+    int offset = 0;
+    for (size_t i = 0; i < potentials_.size(); i++) {
+        potentials_[i]->plan_forces(N, params_sizes_[i], d_p + offset, plan);
+        offset += params_sizes_[i];
+    }
+}
+
 void SummedPotential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
     int offset = 0;
     for (size_t i = 0; i < potentials_.size(); i++) {
@@ -320,10 +341,16 @@ void FanoutSummedPotential::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
     const int n = potentials_.size();
+    const bool par = parallel_ && n > 1;
+    if (d_du_dx && !d_du_dp && !d_u) {
+        plan_.clear();
+        this->plan_forces(N, P, d_p, plan_);
+        plan_.run(N, d_x, d_box, d_du_dx, stream);
+        return;
+    }
     if (d_u) {
         d_u_buffer_.zero_async(stream, n);
     }
-    const bool par = parallel_ && n > 1;
     if (par) {
         for (int i = 0; i < n; i++)
             fork_.fork_from(i, stream);
@@ -336,6 +363,12 @@ void FanoutSummedPotential::execute_device(
     }
     if (d_u) {
         reduce_i128_device(d_u_buffer_.data, n, d_u, stream);
+    }
+}
+
+void FanoutSummedPotential::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    for (auto &pot : potentials_) {
+        pot->plan_forces(N, P, d_p, plan);
     }
 }
 
