@@ -66,6 +66,9 @@ public:
 
     // Forces-only planning hook (see ForcePlan).  Default: not fusable, executed through execute_device.
     virtual void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) { plan.add_rest(this, P, d_p); }
+    // Offer of a ForcePlan table to run inside this potential's own (long) force kernel during its NEXT forces-only
+    // execute_device call, accumulating into that call's d_du_dx.  true = accepted (the plan then skips its own launch).
+    virtual bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) { return false; }
 
     // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
     virtual void execute_device(
@@ -291,6 +294,7 @@ public:
     void set_atom_idxs(const std::vector<int> &atom_idxs);
     std::vector<int> get_atom_idxs();
     int get_num_atom_idxs() const { return K_; }
+    bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
@@ -317,6 +321,8 @@ private:
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;
     DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
+    const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
+    int piggyback_blocks_ = 0;
 };
 
 void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);

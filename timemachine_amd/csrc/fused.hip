@@ -12,32 +12,7 @@ namespace tmamd {
 template <typename Real>
 __global__ __launch_bounds__(256) void k_fused_forces(
     const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx) {
-    const int n = table->n;
-    int s = 0, first = 0;
-    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
-        const int end = table->block_end[k];
-        if (static_cast<int>(blockIdx.x) >= end) {
-            s = k + 1;
-            first = end;
-        }
-    }
-    const FusedSegment seg = table->seg[s];
-    const int idx = (static_cast<int>(blockIdx.x) - first) * 256 + static_cast<int>(threadIdx.x);
-    if (idx >= seg.count) {
-        return;
-    }
-    switch (seg.kind) {
-    case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_PAIR_LIST:
-        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
-        break;
-    case FUSED_PAIR_LIST_NEGATED:
-        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
-        break;
-    default: break;
-    }
+    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx);
 }
 
 void ForcePlan::clear() {
@@ -59,14 +34,14 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
 }
 
 void ForcePlan::run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream) {
-    for (const Rest &r : rest_) {
-        r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
-    }
+    // 1. tables to the device (only when they changed since the last step)
+    bool pending[2] = {false, false};
     for (int prec = 0; prec < 2; prec++) {
         FusedTable &t = host_[prec];
         if (t.n == 0) {
             continue;
         }
+        pending[prec] = true;
         // unused tail of the table: keep it deterministic so the "unchanged since the last upload" test is exact
         for (int k = t.n; k < FUSED_MAX_SEGMENTS; k++) {
             t.block_end[k] = 0;
@@ -79,7 +54,25 @@ void ForcePlan::run(const int N, const double *d_x, const double *d_box, u64 *d_
             std::memcpy(&uploaded_[prec], &t, sizeof(FusedTable));
             uploaded_valid_[prec] = true;
         }
-        const int blocks = t.block_end[t.n - 1];
+    }
+    // 2. a long-running force kernel of the same precision may take a table along (its early-finishing waves run it)
+    for (const Rest &r : rest_) {
+        for (int prec = 0; prec < 2; prec++) {
+            if (pending[prec] && r.pot->piggyback_forces(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4)) {
+                pending[prec] = false;
+            }
+        }
+    }
+    // 3. the potentials that launch their own kernels
+    for (const Rest &r : rest_) {
+        r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
+    }
+    // 4. tables nobody took
+    for (int prec = 0; prec < 2; prec++) {
+        if (!pending[prec]) {
+            continue;
+        }
+        const int blocks = host_[prec].block_end[host_[prec].n - 1];
         const int prof = Profiler::get().begin("fused_forces", stream);
         if (prec == 1) {
             k_fused_forces<double><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_du_dx);

@@ -23,6 +23,7 @@
 //   flush    one global u64 atomic per touched (atom, component) per tile.
 // Integer accumulation is associative, so none of this reordering changes a single bit of the result.
 #pragma once
+#include "kernels_bonded.cuh"
 #include "nb_pair.cuh"
 
 namespace tmamd {
@@ -137,6 +138,19 @@ __global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ pe
     }
 }
 
+template <typename Real, bool NEGATED>
+__device__ __forceinline__ i128 nonbonded_pair_list_term(
+    const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
+    const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u);
+
+// One 256-term block of a ForcePlan table (engine.hpp): bonded terms and pair lists, forces only.  Defined at the end of
+// this header; called by k_fused_forces and by the tail of the tile kernel.
+template <typename Real>
+__device__ __forceinline__ void fused_dispatch(
+    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
+    const double *__restrict__ box, u64 *__restrict__ du_dx);
+
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
 // Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
 template <typename Real> struct TileRegs {
@@ -159,6 +173,9 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
     u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials,
+    // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
+    // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
+    const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
     long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
     __shared__ Real s_row[7][TILE];
@@ -273,6 +290,19 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     if (item != NO_ITEM) {
         load_indices(items[item], cur);
         load_records(cur);
+    }
+
+    if constexpr (!COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) {
+        if (fused) {
+            // Piggy-backed bonded terms / pair lists: 64-term slices of the table's 256-term blocks, one per few waves.
+            // Done here, while this wave's first tile is still on its way from memory (both are chains of dependent
+            // loads with little arithmetic) and the SIMD's other waves are computing.  Measured alternatives: at the
+            // end of the wave, or in extra workgroups appended / prepended to the grid -- all slower (f32: this placement
+            // costs nothing, the others 8-10 us per launch).
+            for (int t = static_cast<int>(gridDim.x - 1 - blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(gridDim.x)) {
+                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx);
+            }
+        }
     }
 
     while (item != NO_ITEM) {
@@ -617,6 +647,38 @@ __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
         if ((threadIdx.x & 63) == 0) {
             u_partials[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = total;
         }
+    }
+}
+
+template <typename Real>
+__device__ __forceinline__ void fused_dispatch(
+    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
+    const double *__restrict__ box, u64 *__restrict__ du_dx) {
+    const int n = table->n;
+    int s = 0, first = 0;
+    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
+        const int end = table->block_end[k];
+        if (block >= end) {
+            s = k + 1;
+            first = end;
+        }
+    }
+    const FusedSegment seg = table->seg[s];
+    const int idx = (block - first) * 256 + thread;
+    if (idx >= seg.count) {
+        return;
+    }
+    switch (seg.kind) {
+    case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_PAIR_LIST:
+        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        break;
+    case FUSED_PAIR_LIST_NEGATED:
+        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        break;
+    default: break;
     }
 }
 

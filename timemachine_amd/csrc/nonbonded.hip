@@ -431,6 +431,16 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
     force_rebuild_ = true;
 }
 
+template <typename Real>
+bool NonbondedAllPairs<Real>::piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) {
+    if (precision_bytes != static_cast<int>(sizeof(Real)) || piggyback_table_ != nullptr) {
+        return false;
+    }
+    piggyback_table_ = d_table;
+    piggyback_blocks_ = blocks;
+    return true;
+}
+
 template <typename Real> std::vector<long long> NonbondedAllPairs<Real>::debug_timing() {
     std::vector<long long> raw(static_cast<size_t>(grid_) * 8);
     HIP_CHECK(hipDeviceSynchronize());
@@ -490,8 +500,18 @@ void NonbondedAllPairs<Real>::execute_device(
     k_nonbonded_tiles<Real, U, X, PP><<<grid_, 64, 0, stream>>>(                                                      \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
-        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, d_u_partials_.data, d_timing_.data)
+        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, d_u_partials_.data, pig_table, pig_blocks, d_x, d_du_dx,       \
+        d_timing_.data)
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
+    // a ForcePlan table offered through piggyback_forces() rides on the forces-only launch; any other call drops it
+    // back to its owner's stand-alone path by never having accepted it (the plan only offers it for forces-only calls)
+    const FusedTable *pig_table = sel == 2 ? piggyback_table_ : nullptr;
+    const int pig_blocks = sel == 2 ? piggyback_blocks_ : 0;
+    if (piggyback_table_ != nullptr && sel != 2) {
+        throw std::runtime_error("NonbondedAllPairs: a piggy-backed force table is pending but this call is not forces-only");
+    }
+    piggyback_table_ = nullptr;
+    piggyback_blocks_ = 0;
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
     switch (sel) {
     case 0: TM_LAUNCH_TILES(false, false, false); break;
