@@ -14,6 +14,10 @@ template <int MODE> __global__ __launch_bounds__(64) void k(long long *out, int 
     int idx = lane;
     if (stride_mode == 1) idx = lane & 31;
     if (stride_mode == 2) idx = (lane * 37 + 11) & 63;
+    if (stride_mode == 3) idx = lane & 15;               // every address hit by 4 lanes
+    if (stride_mode == 4) idx = lane & 7;                // 8 lanes per address
+    if (stride_mode == 5) idx = (lane * 2654435761u >> 27) & 31; // hashed onto 32 addresses (a realistic batch: ~2 per row, max ~5)
+    if (stride_mode == 6) idx = lane * 2;                // distinct addresses, stride 16 B (u64 view): 2-way bank conflict
     unsigned long long v = lane + 1;
     const long long t0 = clock64();
     for (int it = 0; it < iters; it++) {
@@ -42,7 +46,7 @@ template <int MODE> void run(const char *name, int ninstr) {
     const int grid = 256 * 16, iters = 2000;
     long long *d;
     hipMalloc(&d, grid * sizeof(long long));
-    for (int sm = 0; sm < 3; sm++) {
+    for (int sm = 0; sm < 7; sm++) {
         hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, d, iters, sm);
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);

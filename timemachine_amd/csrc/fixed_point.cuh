@@ -17,14 +17,23 @@ namespace tmamd {
 // exact llrintf for every finite input in range, so llrintf/llrint are the contract.
 //
 // f64 fast path: for |x| < 2^51 adding 1.5*2^52 leaves round-half-even(x) in the low mantissa bits, so
-// the integer is one add + one 64-bit integer subtract instead of the ~8-instruction cvt sequence.
+// the integer is one add + one 32-bit integer subtract instead of the ~8-instruction cvt sequence.  The slow
+// conversion (|x| >= 2^51, i.e. forces beyond 2^15 kJ/mol/nm, or NaN) sits behind a WAVE-UNIFORM branch: a per-lane
+// branch would be if-converted and its instructions issued (masked off) for every pair.
+#define TM_FIXED_MAGIC 6755399441055744.0     // 1.5 * 2^52
+#define TM_FIXED_FAST_LIMIT 2251799813685248.0 // 2^51
+__device__ __forceinline__ long long real_to_int64_fast(double x) {
+    return __double_as_longlong(x + TM_FIXED_MAGIC) - __double_as_longlong(TM_FIXED_MAGIC);
+}
 __device__ __forceinline__ long long real_to_int64(double x) {
-    const double magic = 6755399441055744.0; // 1.5 * 2^52
-    if (__builtin_fabs(x) < 2251799813685248.0) { // 2^51
-        double t = x + magic;
-        return __double_as_longlong(t) - __double_as_longlong(magic);
+    long long r = real_to_int64_fast(x);
+    const bool big = !(__builtin_fabs(x) < TM_FIXED_FAST_LIMIT);
+    if (__ballot(big) != 0ull) {
+        if (big) {
+            r = llrint(x);
+        }
     }
-    return llrint(x);
+    return r;
 }
 __device__ __forceinline__ long long real_to_int64(float x) {
     // widening is exact; reuse the f64 path (|x| < 2^51 almost always)

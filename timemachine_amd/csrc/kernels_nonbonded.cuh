@@ -23,6 +23,7 @@
 //   flush    one global u64 atomic per touched (atom, component) per tile.
 // Integer accumulation is associative, so none of this reordering changes a single bit of the result.
 #pragma once
+#include <type_traits>
 #include "kernels_bonded.cuh"
 #include "nb_pair.cuh"
 
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         const int rb = cur.rb;
         const unsigned int ja = cur.ja;
         __syncthreads(); // previous item's flush has finished reading LDS
+        float4 s_rowf_mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // lanes 0-31: this lane's row atom, as stored in s_rowf
         TM_T(t_a2);
         if (lane < TILE) {
             s_rowatom[lane] = cur.ra;
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
             rf.z = static_cast<float>(min_image(cur.rr[2] - cur.oz, bx.z, bx.inv_z));
             rf.w = cur.ra < uK ? static_cast<float>(cur.rr[3]) : 1e18f; // invalid row: never passes the filter
             s_rowf[lane] = rf;
+            s_rowf_mine = rf;
             if constexpr (COMPUTE_DU_DX) {
                 s_fi[0][lane] = 0;
                 s_fi[1][lane] = 0;
@@ -356,6 +359,26 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         const float cfz = static_cast<float>(min_image(cur.cj[2] - cur.oz, bx.z, bx.inv_z));
         const float cfw = ja < uK ? static_cast<float>(cur.cj[3]) : -1e18f; // padded column: never passes the filter
         const unsigned int row_first = static_cast<unsigned int>(rb * TILE);
+        // Filter specialisations.  compact: every |row - origin| + |col - origin| stays below half a box length, so
+        // row - col IS the minimum image and the three rint/fma pairs per slot are skipped.  needs_order: only tiles
+        // whose columns reach back into (or before) the row block's own index range need the row < col test.
+        bool compact, needs_order;
+        {
+            const bool col_live = ja < uK;
+            float cfrac = fmaxf(fabsf(cfx) * fibx, fmaxf(fabsf(cfy) * fiby, fabsf(cfz) * fibz));
+            cfrac = col_live ? cfrac : 0.0f;
+            float rfrac = 0.0f;
+            if (lane < TILE && cur.ra < uK) {
+                const float4 r4 = s_rowf_mine;
+                rfrac = fmaxf(fabsf(r4.x) * fibx, fmaxf(fabsf(r4.y) * fiby, fabsf(r4.z) * fibz));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                rfrac = fmaxf(rfrac, __shfl_xor(rfrac, o, 64));
+            }
+            compact = __ballot(!(cfrac + rfrac < 0.49f)) == 0ull;
+            needs_order = upper_triangular && __ballot(col_live && ja <= row_first + (TILE - 1)) != 0ull;
+        }
         if constexpr (COMPUTE_DU_DX) {
             s_fj[0][lane] = 0;
             s_fj[1][lane] = 0;
@@ -384,17 +407,38 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
                 rf[k] = s_rowf[ri[k]];
             }
             bool hit[4];
+            auto filter4 = [&](auto wrap, auto ordered) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float fdx = rf[k].x - cfx, fdy = rf[k].y - cfy, fdz = rf[k].z - cfz;
-                fdx = __builtin_fmaf(-fbx, __builtin_rintf(fdx * fibx), fdx);
-                fdy = __builtin_fmaf(-fby, __builtin_rintf(fdy * fiby), fdy);
-                fdz = __builtin_fmaf(-fbz, __builtin_rintf(fdz * fibz), fdz);
-                const float fdw = rf[k].w - cfw;
-                const float fd2 = __builtin_fmaf(fdw, fdw, __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx)));
-                // upper-triangular launches keep only row < col (sorted indices; the row index is row_first + i)
-                const bool order_ok = !upper_triangular || (row_first + static_cast<unsigned int>(ri[k])) < ja;
-                hit[k] = order_ok && fd2 < fcut2;
+                for (int k = 0; k < 4; k++) {
+                    float fdx = rf[k].x - cfx, fdy = rf[k].y - cfy, fdz = rf[k].z - cfz;
+                    if constexpr (decltype(wrap)::value) {
+                        fdx = __builtin_fmaf(-fbx, __builtin_rintf(fdx * fibx), fdx);
+                        fdy = __builtin_fmaf(-fby, __builtin_rintf(fdy * fiby), fdy);
+                        fdz = __builtin_fmaf(-fbz, __builtin_rintf(fdz * fibz), fdz);
+                    }
+                    const float fdw = rf[k].w - cfw;
+                    const float fd2 = __builtin_fmaf(fdw, fdw, __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx)));
+                    bool ok = fd2 < fcut2;
+                    if constexpr (decltype(ordered)::value) {
+                        // upper-triangular launches keep only row < col (sorted indices; the row index is row_first + i)
+                        ok = ok && (row_first + static_cast<unsigned int>(ri[k])) < ja;
+                    }
+                    hit[k] = ok;
+                }
+            };
+            // wave-uniform specialisation (decided per item at setup): most tiles are compact and off the diagonal
+            if (compact) {
+                if (needs_order) {
+                    filter4(std::false_type{}, std::true_type{});
+                } else {
+                    filter4(std::false_type{}, std::false_type{});
+                }
+            } else {
+                if (needs_order) {
+                    filter4(std::true_type{}, std::true_type{});
+                } else {
+                    filter4(std::true_type{}, std::false_type{});
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {

@@ -97,7 +97,7 @@ __device__ __forceinline__ float real_es_factor(float beta, float dij, float inv
     float x = beta * dij;
     float exp_x2 = __expf(-x * x);
     // Abramowitz & Stegun 7.1.26 (|err| < 1.5e-7), same approximation the reference's f32 path uses
-    float t = 1.0f / (1.0f + 0.3275911f * x);
+    float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x); // v_rcp_f32: 1 ulp, no division sequence
     float ebd = (0.254829592f + (-0.284496736f + (1.421413741f + (-1.453152027f + 1.061405429f * t) * t) * t) * t) * t * exp_x2;
     float debd = beta * (-static_cast<float>(TM_TWO_OVER_SQRT_PI) * exp_x2);
     float dsdr;
@@ -108,7 +108,7 @@ __device__ __forceinline__ float real_es_factor(float beta, float dij, float inv
 }
 
 __device__ __forceinline__ double tm_rsqrt(double x) { return tm_rsqrt_f64(x); }
-__device__ __forceinline__ float tm_rsqrt(float x) { return rsqrtf(x); }
+__device__ __forceinline__ float tm_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); } // v_rsq_f32: 1 ulp; d2 is never denormal
 
 // d2ij must already satisfy d2ij < cutoff^2.
 template <typename Real>
@@ -164,9 +164,20 @@ __device__ __forceinline__ float min_image(float delta, float box, float inv_box
 // an integer subtract / LDS ds_sub for it) -- three conversions per pair instead of six.
 __device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
     const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
-    fx = static_cast<u64>(real_to_int64(ps * dx));
-    fy = static_cast<u64>(real_to_int64(ps * dy));
-    fz = static_cast<u64>(real_to_int64(ps * dz));
+    const double a = ps * dx, b = ps * dy, c = ps * dz;
+    fx = static_cast<u64>(real_to_int64_fast(a));
+    fy = static_cast<u64>(real_to_int64_fast(b));
+    fz = static_cast<u64>(real_to_int64_fast(c));
+    // one wave-uniform escape for all three components (see real_to_int64)
+    const bool big = !(__builtin_fabs(a) < TM_FIXED_FAST_LIMIT && __builtin_fabs(b) < TM_FIXED_FAST_LIMIT &&
+                       __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
+    if (__ballot(big) != 0ull) {
+        if (big) {
+            fx = static_cast<u64>(llrint(a));
+            fy = static_cast<u64>(llrint(b));
+            fz = static_cast<u64>(llrint(c));
+        }
+    }
 }
 // f32 kernels: the products are formed in f64 from the f32 prefactor and displacement (exact widening), which is
 // cheaper on gfx950 than rounding each product to f32 first and then widening it for the 64-bit conversion.
