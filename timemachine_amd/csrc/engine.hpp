@@ -37,6 +37,13 @@ struct FusedTable {
     int block_end[FUSED_MAX_SEGMENTS]; // exclusive prefix sum of 256-thread blocks per segment
     FusedSegment seg[FUSED_MAX_SEGMENTS];
 };
+// A force contribution left in a potential's own (sorted) accumulator instead of being scattered into du_dx: the
+// consumer adds g_du_dx[slot_of_atom[a] * 3 + d] for every atom a with slot_of_atom[a] >= 0.  Lets the integrator's
+// update kernel pick the nonbonded forces up directly (one launch and one pass over du_dx less per step).
+struct DeferredForces {
+    const u64 *g_du_dx = nullptr;
+    const int *slot_of_atom = nullptr;
+};
 class Potential;
 class ForcePlan {
 public:
@@ -48,8 +55,10 @@ public:
     void clear();
     void add_segment(const int precision_bytes, const FusedSegment &seg, Potential *owner, const int P, const double *d_p);
     void add_rest(Potential *pot, const int P, const double *d_p) { rest_.push_back({pot, P, d_p}); }
-    // launches everything; accumulates into d_du_dx
-    void run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream);
+    // launches everything; accumulates into d_du_dx.  With `deferred` != nullptr, up to `max_deferred` contributions may
+    // be handed back un-scattered instead (see DeferredForces).
+    void run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
+             std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0);
 
 private:
     FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
@@ -69,6 +78,13 @@ public:
     // Offer of a ForcePlan table to run inside this potential's own (long) force kernel during its NEXT forces-only
     // execute_device call, accumulating into that call's d_du_dx.  true = accepted (the plan then skips its own launch).
     virtual bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) { return false; }
+    // Forces-only evaluation that leaves the result in the potential's own accumulator (see DeferredForces) instead of
+    // adding it to a du_dx array.  A piggy-backed table still accumulates into d_du_dx.  false = not supported.
+    virtual bool execute_forces_deferred(
+        const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
+        DeferredForces &out) {
+        return false;
+    }
 
     // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
     virtual void execute_device(
@@ -295,6 +311,7 @@ public:
     std::vector<int> get_atom_idxs();
     int get_num_atom_idxs() const { return K_; }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
+    bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
@@ -321,6 +338,9 @@ private:
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;
     DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
+    DeviceBuffer<int> d_slot_of_atom_;            // [N]: position of each atom in the sorted order, -1 = not one of ours
+    void check_sizes(const int N, const int P) const;
+    void run_pipeline(const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx, hipStream_t stream);
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
 };
@@ -370,6 +390,7 @@ private:
     DeviceBuffer<Real> d_cbs_, d_ccs_;
     DeviceBuffer<u64> d_du_dx_;
     ForcePlan plan_;
+    std::vector<DeferredForces> deferred_;
 };
 
 // reference: cpp/src/mover.hpp (interface only; no movers are implemented on this path yet)

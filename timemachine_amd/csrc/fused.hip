@@ -33,7 +33,9 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
     t.n++;
 }
 
-void ForcePlan::run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream) {
+void ForcePlan::run(
+    const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
+    const int max_deferred) {
     // 1. tables to the device (only when they changed since the last step)
     bool pending[2] = {false, false};
     for (int prec = 0; prec < 2; prec++) {
@@ -65,7 +67,13 @@ void ForcePlan::run(const int N, const double *d_x, const double *d_box, u64 *d_
     }
     // 3. the potentials that launch their own kernels
     for (const Rest &r : rest_) {
-        r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
+        DeferredForces df;
+        if (deferred != nullptr && static_cast<int>(deferred->size()) < max_deferred &&
+            r.pot->execute_forces_deferred(N, r.P, d_x, r.d_p, d_box, d_du_dx, stream, df)) {
+            deferred->push_back(df);
+        } else {
+            r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
+        }
     }
     // 4. tables nobody took
     for (int prec = 0; prec < 2; prec++) {

@@ -68,7 +68,9 @@ template <typename Real>
 __global__ __launch_bounds__(256) void k_update_forward_baoab(
     const int N, const Real ca, const unsigned int *__restrict__ idxs, const Real *__restrict__ cbs, const Real *__restrict__ ccs,
     const unsigned long long seed, const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t,
-    u64 *__restrict__ du_dx, const Real dt) {
+    u64 *__restrict__ du_dx, const Real dt,
+    // up to two force contributions picked up from their producers' sorted accumulators (DeferredForces); nullptr = none
+    const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1, const int *__restrict__ slot1) {
     for (int kidx = blockIdx.x * blockDim.x + threadIdx.x; kidx < N; kidx += gridDim.x * blockDim.x) {
         const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
         if (atom < N) {
@@ -79,9 +81,18 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 normal3(seed, step, static_cast<unsigned int>(atom), nz);
             }
             const Real half_dt = static_cast<Real>(0.5) * dt;
+            const int s0 = g0 ? slot0[atom] : -1;
+            const int s1 = g1 ? slot1[atom] : -1;
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                const Real force = -fixed_to_float<Real>(du_dx[atom * 3 + d]);
+                u64 f = du_dx[atom * 3 + d]; // wrapping integer sum: same bits as a scatter-add into du_dx would give
+                if (s0 >= 0) {
+                    f += g0[static_cast<size_t>(s0) * 3 + d];
+                }
+                if (s1 >= 0) {
+                    f += g1[static_cast<size_t>(s1) * 3 + d];
+                }
+                const Real force = -fixed_to_float<Real>(f);
                 const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
                 const Real v_new = ca * v_mid + cc * static_cast<Real>(nz[d]);
                 v_t[atom * 3 + d] = static_cast<double>(v_new);
@@ -123,10 +134,15 @@ void LangevinIntegrator<Real>::step_fwd(
     for (auto &bp : bps) {
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
     }
-    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream);
+    deferred_.clear();
+    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2);
+    const DeferredForces none;
+    const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
+    const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
     const int tpb = 256;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
-        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_);
+        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_, df0.g_du_dx, df0.slot_of_atom,
+        df1.g_du_dx, df1.slot_of_atom);
     HIP_CHECK(hipGetLastError());
     step_++;
 }

@@ -33,7 +33,13 @@ namespace tmamd {
 // VGPR-resident erfcx coefficients need ~130 registers -- 3 waves without spills beats 4 waves with 60+ spilled
 // dwords (measured: 148 vs 167 us per launch at 23.5k atoms).  f32: ~80 registers -> 5 waves.
 template <typename Real> struct TileWaves {
-    static const int value = sizeof(Real) == 8 ? 3 : 5;
+#ifndef TM_TILE_WAVES_F64
+#define TM_TILE_WAVES_F64 3
+#endif
+#ifndef TM_TILE_WAVES_F32
+#define TM_TILE_WAVES_F32 5
+#endif
+    static const int value = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : TM_TILE_WAVES_F32;
 };
 static const int NB_CHUNK = 64;        // columns per work item == wave width
 static const int NB_SHARDS = 4;        // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
@@ -77,7 +83,7 @@ __global__ void k_check_gather(
     const double *__restrict__ box, const double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double pad2_quarter, // 0.25 * padding^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp) {
+    u64 *__restrict__ g_du_dp, int *__restrict__ slot_of_atom) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
@@ -94,6 +100,7 @@ __global__ void k_check_gather(
         return;
     }
     const unsigned int a = perm[idx];
+    slot_of_atom[a] = idx; // inverse of perm (for consumers that pick forces up from the sorted accumulator)
     const double xd = x[a * 3 + 0], yd = x[a * 3 + 1], zd = x[a * 3 + 2];
     Real xo = static_cast<Real>(snap_x[a * 3 + 0]), yo = static_cast<Real>(snap_x[a * 3 + 1]),
          zo = static_cast<Real>(snap_x[a * 3 + 2]);

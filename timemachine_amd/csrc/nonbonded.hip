@@ -408,6 +408,8 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
     HIP_CHECK(hipMemset(d_snap_box_.data, 0, d_snap_box_.size()));
     d_flags_.realloc(2);
     HIP_CHECK(hipMemset(d_flags_.data, 0, d_flags_.size()));
+    d_slot_of_atom_.realloc(N_);
+    HIP_CHECK(hipMemset(d_slot_of_atom_.data, 0xff, d_slot_of_atom_.size())); // -1: no atom is ours until K1 says so
     // persistent grid: one wave per workgroup, TileWaves<Real> waves per SIMD on every CU
     grid_ = device_cu_count() * 4 * TileWaves<Real>::value;
     d_timing_.realloc(static_cast<size_t>(grid_) * 8);
@@ -424,6 +426,7 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
     std::vector<unsigned int> u(atom_idxs.begin(), atom_idxs.end());
     const int K = static_cast<int>(u.size());
     HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(d_slot_of_atom_.data, 0xff, d_slot_of_atom_.size())); // atoms that leave the set must read -1
     d_atom_idxs_.copy_from(u.data(), K);
     nblist_.resize(K);
     K_ = K;
@@ -455,9 +458,25 @@ template <typename Real> std::vector<int> NonbondedAllPairs<Real>::get_atom_idxs
 }
 
 template <typename Real>
+bool NonbondedAllPairs<Real>::execute_forces_deferred(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
+    DeferredForces &out) {
+    this->check_sizes(N, P);
+    this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream);
+    out.g_du_dx = d_g_du_dx_.data;
+    out.slot_of_atom = d_slot_of_atom_.data;
+    return true;
+}
+
+template <typename Real>
 void NonbondedAllPairs<Real>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
+    this->check_sizes(N, P);
+    this->run_pipeline(d_x, d_p, d_box, d_du_dx, d_du_dp, d_u, true, stream);
+}
+
+template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, const int P) const {
     if (N != N_) {
         throw std::runtime_error(
             "NonbondedAllPairs::execute_device(): expected N == N_, got N=" + std::to_string(N) + ", N_=" + std::to_string(N_));
@@ -467,6 +486,12 @@ void NonbondedAllPairs<Real>::execute_device(
             "NonbondedAllPairs::execute_device(): expected P == N_*" + std::to_string(PARAMS_PER_ATOM) + ", got P=" +
             std::to_string(P) + ", N_*" + std::to_string(PARAMS_PER_ATOM) + "=" + std::to_string(N_ * PARAMS_PER_ATOM));
     }
+}
+
+template <typename Real>
+void NonbondedAllPairs<Real>::run_pipeline(
+    const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx,
+    hipStream_t stream) {
     const int tpb = DEFAULT_TPB;
 
     // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
@@ -487,7 +512,7 @@ void NonbondedAllPairs<Real>::execute_device(
     int *flag_next = d_flags_.data + (parity_ ^ 1);
     k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
         K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
-        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr);
+        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_slot_of_atom_.data);
     HIP_CHECK(hipGetLastError());
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
@@ -528,7 +553,7 @@ void NonbondedAllPairs<Real>::execute_device(
     HIP_CHECK(hipGetLastError());
 
     // (e) K5: back to the caller's atom order
-    if (d_du_dx) {
+    if (d_du_dx && scatter_du_dx) {
         k_scatter_accum<3><<<ceil_divide(K_ * 3, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dx_.data, d_du_dx);
         HIP_CHECK(hipGetLastError());
     }
