@@ -9,10 +9,10 @@
 //                  which is what Neighborlist.get_nblist must report (tests/test_nblist.py:180-186)
 //   work items     {row_block, col_start, col_count<=64} for the tile kernel
 //
-// Differences from the reference's CUDA structure, on purpose: one 256-thread workgroup (4 waves) per row block
+// Differences from the reference's CUDA structure, on purpose: one 1024-thread workgroup (16 waves) per row block
 // scans ALL column blocks (the reference launches a (row, col/32) grid of 32-thread blocks and needs a second
-// "trim compaction" kernel); 64-wide ballots; segments are claimed from the pool with one atomic per row block
-// after the coarse pass, so a row block's columns are contiguous and no per-tile atomics are issued.
+// "trim compaction" kernel); 64-wide ballots; every row block owns a fixed, worst-case-sized segment of the pool, so
+// its columns are contiguous and neither per-tile atomics nor a counting pass are needed.
 #pragma once
 #include "kernels_nonbonded.cuh"
 
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     const int n_row_blocks, const int NR, const unsigned int *__restrict__ row_idxs, // only used when rows != cols
     const int rows_equal_cols, const Real *__restrict__ gathered, const double *__restrict__ box,
     Real *__restrict__ col_ctr, Real *__restrict__ col_ext, Real *__restrict__ row_ctr, Real *__restrict__ row_ext,
-    unsigned int *__restrict__ counters, // [0]=pool cursor [1]=n_items [2]=tile count [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
+    unsigned int *__restrict__ counters, // [0]=unused [1]=n_items [2]=tile count [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
     const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
     const int *__restrict__ flag, const int force) {
     if (!force && *flag == 0) {
@@ -99,16 +99,18 @@ __global__ __launch_bounds__(256) void k_block_bounds(
 }
 
 // K3: per row block, find interacting column atoms.  One NBL_THREADS-thread workgroup (16 waves) per row block.
-//   pass 0  count the column blocks whose bounding box is within the list cutoff of the row block's box and claim a
-//           pool segment big enough for all their atoms with ONE atomic
 //   pass 1  per chunk of NBL_CHUNK column blocks: compact the passing block ids into an LDS list (ballot + popcount)
 //   pass 2  the waves stride over the list two column blocks at a time (lanes 0-31 / 32-63 = one column atom
 //           each).  As in the reference, row atoms are first filtered against the column block's box
 //           (k_neighborlist.cuh:349-365), here with one (row atom, column block) test per lane and two 32-bit row masks;
 //           every lane then walks only the set bits of its half's mask, and the wave leaves as soon as all of its
 //           lanes have found a partner.
+static const int NBL_COST_STRIDE = 4; // cost estimates sample every 4th row (lane-staggered start)
 static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
-static const int NBL_THREADS = 1024; // 16 waves per row block: the per-row-block critical path is what bounds this kernel
+#ifndef TM_NBL_THREADS
+#define TM_NBL_THREADS 1024
+#endif
+static const int NBL_THREADS = TM_NBL_THREADS; // 16 waves per row block: the per-row-block critical path is what bounds this kernel
 
 template <typename Real, bool UPPER_TRIANGULAR>
 __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     }
     __shared__ int s_list[NBL_CHUNK];
     __shared__ Real s_rx[TILE], s_ry[TILE], s_rz[TILE];
-    __shared__ unsigned int s_npass, s_nlist, s_count, s_seg_start;
+    __shared__ unsigned int s_nlist, s_count;
     __shared__ unsigned int s_hist[NB_CLASSES], s_base[NB_CLASSES];
     __shared__ float s_rf[3][TILE];
 
@@ -140,7 +142,6 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     const int nrow = (NR - rb * TILE) < TILE ? (NR - rb * TILE) : TILE;
 
     if (tid == 0) {
-        s_npass = 0;
         s_count = 0;
     }
     if (tid < TILE) {
@@ -174,21 +175,13 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         return (ddx * ddx + ddy * ddy + ddz * ddz) < cutoff2;
     };
 
-    // ---- pass 0: count, then one pool claim per row block
-    unsigned int my_pass = 0;
-    for (int cb0 = cb_first; cb0 < n_col_blocks; cb0 += NBL_THREADS) {
-        const u64 m = __ballot(coarse(cb0 + tid));
-        my_pass += __popcll(m);
-    }
-    if (lane == 0 && my_pass) {
-        atomicAdd(&s_npass, my_pass);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        s_seg_start = atomicAdd(&counters[0], s_npass * TILE);
-    }
-    __syncthreads();
-    const unsigned int seg_start = s_seg_start;
+    // The row block's segment of the pool has a fixed place and worst-case room: an upper-triangular list only ever sees
+    // columns from its own block onwards (triangular layout, exactly the pool's size); a row/column-subset list gets
+    // NC entries per row block.  No counting pass and no claim (a returning global atomic) before the real work.
+    const unsigned int ncp = static_cast<unsigned int>(n_col_blocks) * TILE;
+    const unsigned int seg_start =
+        UPPER_TRIANGULAR ? static_cast<unsigned int>(rb) * ncp - static_cast<unsigned int>(TILE) * (static_cast<unsigned int>(rb) * (rb - 1) / 2)
+                         : static_cast<unsigned int>(rb) * ncp;
 
     for (int chunk0 = cb_first; chunk0 < n_col_blocks; chunk0 += NBL_CHUNK) {
         // ---- pass 1: compact the passing column blocks of this chunk into s_list
@@ -215,6 +208,9 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         __syncthreads();
         const int nlist = s_nlist;
 
+#if defined(TM_NBL_ABL) && TM_NBL_ABL == 4
+        if (nlist >= 0) { continue; } // ablation: coarse passes only
+#endif
         // ---- pass 2: two column blocks per wave iteration
         const int half_id = lane >> 5; // 0: lanes 0-31, 1: lanes 32-63
         const int sub = lane & 31;
@@ -244,9 +240,23 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
             }
             const u64 near = __ballot(row_near);
             unsigned int rows = half_id ? static_cast<unsigned int>(near >> 32) : static_cast<unsigned int>(near);
-            const bool live = ja < static_cast<unsigned int>(K);
+            bool live = ja < static_cast<unsigned int>(K);
+            if (live) {
+                // the mirror-image filter: a column atom farther than the cutoff from the row block's BOX has no partner,
+                // and would otherwise walk every set bit of the row mask to find that out (the wave waits for it)
+                Real ax = min_image(xj - rcx, bx.x, bx.inv_x);
+                Real ay = min_image(yj - rcy, bx.y, bx.inv_y);
+                Real az = min_image(zj - rcz, bx.z, bx.inv_z);
+                ax = max(static_cast<Real>(0), fabs(ax) - rex);
+                ay = max(static_cast<Real>(0), fabs(ay) - rey);
+                az = max(static_cast<Real>(0), fabs(az) - rez);
+                live = (ax * ax + ay * ay + az * az) < cutoff2;
+            }
             bool interacts = false;
             // all lanes of a half share `rows`; the loop is uniform across the wave (max of the two popcounts)
+#if defined(TM_NBL_ABL) && TM_NBL_ABL == 2
+            interacts = live; // ablation: no fine pass (every atom of a passing column block is listed)
+#endif
             while (__ballot(rows != 0 && live && !interacts)) {
                 if (rows != 0) {
                     const int i = __builtin_ctz(rows);
@@ -272,6 +282,9 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         __syncthreads();
     }
 
+#if defined(TM_NBL_ABL) && TM_NBL_ABL >= 3
+    if (tid >= 0) { return; } // ablation: nothing published
+#endif
     // ---- publish the segment and its work items
     // Every item gets a cost estimate -- the number of (row, column) pairs inside `cost_cutoff` -- and is filed into
     // bucket (shard = row block % NB_SHARDS, cost class), class 0 = heaviest.  The tile kernel deals the buckets to its
@@ -313,11 +326,16 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
             ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         unsigned int mine = 0;
+#if defined(TM_NBL_ABL) && TM_NBL_ABL == 1
+        if (false) { // ablation: no cost estimate
+#else
         if (ja < static_cast<unsigned int>(K)) {
+#endif
             const float xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
             const float yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
             const float zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
-            for (int i = 0; i < nrow; i++) {
+            // every NBL_COST_STRIDE-th row only: the estimate feeds a 128-pair-wide cost class, a sampled count is plenty
+            for (int i = (lane & (NBL_COST_STRIDE - 1)); i < nrow; i += NBL_COST_STRIDE) {
                 float dx = s_rf[0][i] - xj, dy = s_rf[1][i] - yj, dz = s_rf[2][i] - zj;
                 dx = __builtin_fmaf(-fbx, __builtin_rintf(dx * fibx), dx);
                 dy = __builtin_fmaf(-fby, __builtin_rintf(dy * fiby), dy);
@@ -331,6 +349,8 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         for (int o = 32; o > 0; o >>= 1) {
             total += __shfl_xor(total, o, 64);
         }
+        total *= NBL_COST_STRIDE;
+        total = total < 2048u ? total : 2048u;
         if (lane == 0) {
             const unsigned int heavy = total / NB_CLASS_PAIRS;
             const unsigned int cls = NB_CLASSES - 1 - (heavy < NB_CLASSES - 1 ? heavy : NB_CLASSES - 1);

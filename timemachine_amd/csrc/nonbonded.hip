@@ -304,18 +304,14 @@ Neighborlist<Real>::get_nblist_host(const int N, const double *h_coords, const d
     const int nrb = this->num_row_blocks();
     std::vector<int2> segs(nrb);
     HIP_CHECK(hipMemcpy(segs.data(), d_row_segments_.data, nrb * sizeof(int2), hipMemcpyDeviceToHost));
-    unsigned int counters[4];
-    HIP_CHECK(hipMemcpy(counters, d_counters_.data, sizeof(counters), hipMemcpyDeviceToHost));
-    std::vector<unsigned int> pool(counters[0]);
-    if (counters[0] > 0) {
-        HIP_CHECK(hipMemcpy(pool.data(), d_col_atoms_.data, counters[0] * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    }
     std::vector<std::vector<int>> out(nrb);
+    std::vector<unsigned int> seg;
     for (int r = 0; r < nrb; r++) {
-        out[r].reserve(segs[r].y);
-        for (int k = 0; k < segs[r].y; k++) {
-            out[r].push_back(static_cast<int>(pool[segs[r].x + k]));
+        seg.resize(segs[r].y);
+        if (segs[r].y > 0) {
+            HIP_CHECK(hipMemcpy(seg.data(), d_col_atoms_.data + segs[r].x, segs[r].y * sizeof(unsigned int), hipMemcpyDeviceToHost));
         }
+        out[r].assign(seg.begin(), seg.end());
         std::sort(out[r].begin(), out[r].end());
     }
     return out;
