@@ -79,6 +79,24 @@ int tm_nonbonded_all_pairs_create(int precision, int num_atoms, double beta, dou
  *                                                                    wrap_kernels.cpp:1563-1589; nonbonded_pair_list.cu:12-50 */
 int tm_nonbonded_pair_list_create(int precision, int negated, const int32_t *pair_idxs, int num_pairs, const double *scales,
                                   int num_scales, double beta, double cutoff, tm_potential_t *out);
+/* NonbondedInteractionGroup_*(num_atoms, row_atom_idxs_i, beta, cutoff, col_atom_idxs_i=None, disable_hilbert_sort=False,
+ * nblist_padding=0.1)                                                wrap_kernels.cpp:1481-1561; nonbonded_interaction_group.cu:21-101
+ * col_atom_idxs == NULL means "every atom that is not a row atom". */
+int tm_nonbonded_interaction_group_create(int precision, int num_atoms, const int32_t *row_atom_idxs, int num_rows,
+                                          const int32_t *col_atom_idxs, int num_cols, double beta, double cutoff,
+                                          int disable_hilbert_sort, double nblist_padding, tm_potential_t *out);
+/* NonbondedInteractionGroup_*.set_atom_idxs(row_atom_idxs, col_atom_idxs)   wrap_kernels.cpp:1485-1504; nonbonded_interaction_group.cu:262-334 */
+int tm_nonbonded_interaction_group_set_atom_idxs(tm_potential_t pot, const int32_t *row_atom_idxs, int num_rows,
+                                                 const int32_t *col_atom_idxs, int num_cols);
+/* NonbondedPairListPrecomputed_*(pair_idxs int32[B,2], beta, cutoff); params are [B,4] = (q_ij, sig_ij, eps_ij, w_offset_ij)
+ *                                                                    wrap_kernels.cpp:1353-1364; nonbonded_precomputed.cu:12-87 */
+int tm_nonbonded_pair_list_precomputed_create(int precision, const int32_t *pair_idxs, int num_pairs, double beta, double cutoff,
+                                              tm_potential_t *out);
+/* ChiralAtomRestraint_*(idxs int32[R,4]); params [R]                 wrap_kernels.cpp:1366-1378; chiral_atom_restraint.cu:10-68 */
+int tm_chiral_atom_restraint_create(int precision, const int32_t *idxs, int num_restraints, tm_potential_t *out);
+/* ChiralBondRestraint_*(idxs int32[R,4], signs int32[R]); params [R] wrap_kernels.cpp:1380-1394; chiral_bond_restraint.cu:10-82 */
+int tm_chiral_bond_restraint_create(int precision, const int32_t *idxs, int num_restraints, const int32_t *signs, int num_signs,
+                                    tm_potential_t *out);
 /* SummedPotential(potentials, params_sizes, parallel=True)          wrap_kernels.cpp:1661-1676; summed_potential.cu:13-26 */
 int tm_summed_potential_create(const tm_potential_t *potentials, int num_potentials, const int32_t *params_sizes,
                                int num_params_sizes, int parallel, tm_potential_t *out);

@@ -212,6 +212,65 @@ def periodic_torsion_energy(conf, params, torsion_idxs):
     return (params[:, 0] * (1 + torch.cos(params[:, 2] * ang - params[:, 1]))).sum()
 
 
+# ---- interaction groups, precomputed pair lists, chiral restraints ----
+
+
+def interaction_group_pairs(num_atoms, row_atom_idxs, col_atom_idxs=None):
+    """All (row, col) pairs; nonbonded.py:449-481 (col defaults to the complement of the rows)."""
+    rows = np.asarray(row_atom_idxs, dtype=np.int64)
+    cols = np.setdiff1d(np.arange(num_atoms), rows) if col_atom_idxs is None else np.asarray(col_atom_idxs, dtype=np.int64)
+    assert set(rows.tolist()).isdisjoint(cols.tolist())
+    return np.stack([np.repeat(rows, len(cols)), np.tile(cols, len(rows))], 1)
+
+
+def nonbonded_interaction_group_energy(conf, params, box, row_atom_idxs, col_atom_idxs, beta, cutoff):
+    """nonbonded_interaction_groups (nonbonded.py:460-481): the pair-list energy over rows x cols."""
+    pairs = interaction_group_pairs(conf.shape[0], row_atom_idxs, col_atom_idxs)
+    return nonbonded_pairs_energy(conf, params, box, pairs, beta, cutoff)
+
+
+def nonbonded_precomputed_energy(conf, params, box, pairs, beta, cutoff):
+    """nonbonded_on_precomputed_pairs (nonbonded.py:403-446): params[pair] = (q_ij, sig_ij, eps_ij, w_offset_ij)."""
+    if len(pairs) == 0:
+        return conf.sum() * 0.0
+    pairs = torch.as_tensor(np.asarray(pairs, dtype=np.int64))
+    il, ir = pairs[:, 0], pairs[:, 1]
+    box_diag = None if box is None else torch.diagonal(box)
+    d3 = delta_r(conf[il], conf[ir], box_diag)
+    dw = params[:, 3]
+    dij = torch.sqrt((d3 * d3).sum(-1) + dw * dw)
+    lj, es = _pair_energies(dij, params[:, 0], params[:, 1], params[:, 2], beta, cutoff)
+    # nonbonded.py:443-444: q_ij == 0 selects the constant branch of a `where`, so d/dq_ij is 0 there (as in the kernel)
+    es = torch.where(params[:, 0] != 0, es, torch.zeros_like(es))
+    return lj.sum() + es.sum()
+
+
+def _unit(v):
+    return v / torch.linalg.norm(v, dim=-1, keepdim=True)
+
+
+def chiral_atom_restraint_energy(conf, params, idxs):
+    """chiral_restraints.py:9-37,60-72,107-117: k vol^2 where vol = (v0 x v1) . v2 > 0, else 0."""
+    if len(idxs) == 0:
+        return conf.sum() * 0.0
+    idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
+    xc, x1, x2, x3 = (conf[idxs[:, k]] for k in range(4))
+    vol = (torch.cross(_unit(x1 - xc), _unit(x2 - xc), dim=-1) * _unit(x3 - xc)).sum(-1)
+    return torch.where(vol > 0, params * vol * vol, torch.zeros_like(vol)).sum()
+
+
+def chiral_bond_restraint_energy(conf, params, idxs, signs):
+    """chiral_restraints.py:40-58,75-91,120-130: k vol^2 where sign * vol > 0, vol = (rij x rkj) . (rkj x rkl)."""
+    if len(idxs) == 0:
+        return conf.sum() * 0.0
+    idxs = torch.as_tensor(np.asarray(idxs, dtype=np.int64))
+    ci, cj, ck, cl = (conf[idxs[:, k]] for k in range(4))
+    rij, rkj, rkl = _unit(cj - ci), _unit(cj - ck), _unit(cl - ck)
+    vol = (torch.cross(rij, rkj, dim=-1) * torch.cross(rkj, rkl, dim=-1)).sum(-1)
+    sgn = _t(np.asarray(signs, dtype=np.float64))
+    return torch.where(vol * sgn > 0, params * vol * vol, torch.zeros_like(vol)).sum()
+
+
 def value_and_grads(energy_fn, conf, params, *args, **kwargs) -> Tuple[float, np.ndarray, np.ndarray]:
     """u, du/dx, du/dp of ``energy_fn(conf, params, *args)`` by autograd (mirrors jax.grad(ref,(0,1)))."""
     x = _t(conf, True)
@@ -268,3 +327,20 @@ def nonbonded_forces_blocked(conf, params, box, beta, cutoff, exclusion_idxs=Non
         x, p, _t(box), beta, cutoff, None, block, accumulate_backward=True, exclusion_idxs=exclusion_idxs, scale_factors=scale_factors
     )
     return u, x.grad.numpy()
+
+
+def nonbonded_interaction_group(conf, params, box, row_atom_idxs, beta, cutoff, col_atom_idxs=None):
+    return value_and_grads(
+        lambda x, p: nonbonded_interaction_group_energy(x, p, _t(box), row_atom_idxs, col_atom_idxs, beta, cutoff), conf, params)
+
+
+def nonbonded_pair_list_precomputed(conf, params, box, idxs, beta, cutoff):
+    return value_and_grads(lambda x, p: nonbonded_precomputed_energy(x, p, _t(box), idxs, beta, cutoff), conf, params)
+
+
+def chiral_atom_restraint(conf, params, box, idxs):
+    return value_and_grads(lambda x, p: chiral_atom_restraint_energy(x, p, idxs), conf, params)
+
+
+def chiral_bond_restraint(conf, params, box, idxs, signs):
+    return value_and_grads(lambda x, p: chiral_bond_restraint_energy(x, p, idxs, signs), conf, params)

@@ -159,6 +159,153 @@ def test_config2_all_terms(co, P, lamb, precision):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Interaction groups, precomputed pair lists, chiral restraints vs the reference's goldens
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_interaction_group_golden(co, P, precision):
+    """reference tests: tests/nonbonded/test_nonbonded_interaction_group.py (vs nonbonded_interaction_groups, and the
+    all-pairs decomposition of test_consistency.py)."""
+    g = load("groups.npz")
+    x, p, box, rows = g["ig_x"], g["ig_params"], g["ig_box"], g["ig_rows"]
+    beta, cutoff = float(g["beta"]), float(g["cutoff"])
+    n = x.shape[0]
+    for tag, cols in (("ig_all", None), ("ig_sub", g["ig_cols_sub"])):
+        pot = P.NonbondedInteractionGroup(n, rows, beta, cutoff, col_atom_idxs=cols)
+        impl = pot.to_gpu(precision).unbound_impl
+        compare_forces(impl, x, p, box, float(g[f"{tag}_u"]), g[f"{tag}_du_dx"], g[f"{tag}_du_dp"], precision)
+        # Hilbert sorting off / a different padding: same bits
+        ref = impl.execute_raw(x, p, box)
+        for kw in (dict(disable_hilbert_sort=True), dict(nblist_padding=0.25)):
+            other = P.NonbondedInteractionGroup(n, rows, beta, cutoff, col_atom_idxs=cols, **kw).to_gpu(precision).unbound_impl
+            got = other.execute_raw(x, p, box)
+            np.testing.assert_array_equal(ref[0], got[0])
+            np.testing.assert_array_equal(ref[1], got[1])
+            assert ref[2] == got[2]
+    # bitwise decomposition in fixed point: AllPairs(rows U cols) == AllPairs(rows) + AllPairs(cols) + Group(rows, cols)
+    cols = g["ig_cols_sub"]
+    union = np.sort(np.concatenate([rows, cols])).astype(np.int32)
+    parts = [
+        P.NonbondedAllPairs(n, beta, cutoff, atom_idxs=rows.astype(np.int32)),
+        P.NonbondedAllPairs(n, beta, cutoff, atom_idxs=cols.astype(np.int32)),
+        P.NonbondedInteractionGroup(n, rows, beta, cutoff, col_atom_idxs=cols),
+    ]
+    whole = P.NonbondedAllPairs(n, beta, cutoff, atom_idxs=union).to_gpu(precision).unbound_impl.execute_raw(x, p, box)
+    acc_x, acc_p, acc_u = np.zeros_like(whole[0]), np.zeros_like(whole[1]), 0
+    for part in parts:
+        gx, gp, u = part.to_gpu(precision).unbound_impl.execute_raw(x, p, box)
+        acc_x += gx
+        acc_p += gp
+        acc_u += u
+    np.testing.assert_array_equal(acc_x, whole[0])
+    np.testing.assert_array_equal(acc_p, whole[1])
+    assert acc_u == whole[2]
+    # set_atom_idxs swaps the groups in place
+    impl = P.NonbondedInteractionGroup(n, rows, beta, cutoff).to_gpu(precision).unbound_impl
+    impl.set_atom_idxs(rows, cols)
+    du_dx, _, u = impl.execute(x, p, box, True, False, True)
+    t = TOL[precision]
+    np.testing.assert_allclose(u, float(g["ig_sub_u"]), rtol=t["rtol"], atol=t["atol"])
+    assert_equal_vectors(g["ig_sub_du_dx"], du_dx, t["rtol"])
+    # validation (nonbonded_interaction_group.cu:353-381)
+    ctor = co.NonbondedInteractionGroup_f32
+    with pytest.raises(RuntimeError, match="row_atom_idxs must be nonempty"):
+        ctor(n, np.zeros(0, np.int32), beta, cutoff)
+    with pytest.raises(RuntimeError, match="row and col indices must be disjoint"):
+        ctor(n, np.array([0, 1], np.int32), beta, cutoff, np.array([1, 2], np.int32))
+    with pytest.raises(RuntimeError, match="atom indices must be unique"):
+        ctor(n, np.array([0, 0], np.int32), beta, cutoff)
+    with pytest.raises(RuntimeError, match=r"NonbondedInteractionGroup::execute_device\(\): expected N == N_"):
+        ctor(n, np.array([0], np.int32), beta, cutoff).execute(x[:-1], p[:-1], box)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_pair_list_precomputed_golden(co, P, precision):
+    """reference test: tests/nonbonded/test_nonbonded_precomputed.py"""
+    g = load("groups.npz")
+    impl = P.NonbondedPairListPrecomputed(g["pre_idxs"], float(g["beta"]), float(g["cutoff"])).to_gpu(precision).unbound_impl
+    compare_forces(impl, g["ig_x"], g["pre_params"], g["ig_box"], float(g["pre_u"]), g["pre_du_dx"], g["pre_du_dp"], precision)
+    with pytest.raises(RuntimeError, match="illegal pair with src == dst: 3, 3"):
+        co.NonbondedPairListPrecomputed_f32(np.array([[3, 3]], np.int32), 2.0, 1.2)
+    with pytest.raises(RuntimeError, match=r"expected P == 4\*B"):
+        impl.execute(g["ig_x"], g["pre_params"][:-1], g["ig_box"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_chiral_restraints_golden(co, P, precision):
+    """reference tests: tests/test_chiral_restraints.py (GPU vs chiral_atom_restraint / chiral_bond_restraint)"""
+    g = load("groups.npz")
+    x = g["chiral_x"]
+    box = np.eye(3) * 100.0
+    brt = 1e-7 if precision == np.float64 else 2e-3
+    for key, pot, prm in (
+        ("chiral_atom", P.ChiralAtomRestraint(g["chiral_atom_idxs"]), g["chiral_atom_params"]),
+        ("chiral_bond", P.ChiralBondRestraint(g["chiral_bond_idxs"], g["chiral_bond_signs"]), g["chiral_bond_params"]),
+    ):
+        impl = pot.to_gpu(precision).unbound_impl
+        for flags in itertools.product([False, True], repeat=3):
+            du_dx, du_dp, u = impl.execute(x, prm, box, *flags)
+            if flags[2]:
+                np.testing.assert_allclose(u, float(g[f"{key}_u"]), rtol=brt, atol=brt * 10)
+            if flags[0]:
+                assert_equal_vectors(g[f"{key}_du_dx"], du_dx, brt)
+            if flags[1]:
+                np.testing.assert_allclose(du_dp, g[f"{key}_du_dp"], rtol=brt * 10, atol=brt * 10)
+            again = impl.execute(x, prm, box, *flags)
+            for a, b in zip((du_dx, du_dp), again[:2]):
+                np.testing.assert_array_equal(a, b)
+            assert u == again[2]
+    with pytest.raises(RuntimeError, match="signs must be comprised exclusively of 1 or -1"):
+        co.ChiralBondRestraint_f32(np.array([[0, 1, 2, 3]], np.int32), np.array([0], np.int32))
+    with pytest.raises(RuntimeError, match=r"ChiralAtomRestraint::execute_device\(\): expected P == R"):
+        P.ChiralAtomRestraint(g["chiral_atom_idxs"]).to_gpu(precision).unbound_impl.execute(x, g["chiral_atom_params"][:-1], box)
+
+
+@pytest.mark.gpu
+def test_rbfe_shaped_state_runs_fused(co, P):
+    """A HostGuestSystem-shaped state (fe/system.py:132-143): host-host Nonbonded(atom_idxs=host), ligand-environment
+    interaction group, ligand-ligand precomputed pairs, chiral restraints, bonded terms -- as one SummedPotential in an
+    MD Context.  Forces-only evaluation (one fused launch + two tile launches) must equal the sum of the parts bit for bit."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    n = s.num_atoms
+    lig = np.arange(n - 20, n, dtype=np.int32)
+    host = np.arange(0, n - 20, dtype=np.int32)
+    rng = np.random.default_rng(7)
+    lig_pairs = np.array([(i, j) for i in lig for j in lig if i < j], dtype=np.int32)[::3]
+    pre_params = np.stack([rng.normal(size=len(lig_pairs)), rng.uniform(0.2, 0.3, len(lig_pairs)), rng.uniform(0.1, 0.5, len(lig_pairs)), np.zeros(len(lig_pairs))], 1)
+    chiral_idxs = np.stack([rng.permutation(lig)[:4] for _ in range(6)]).astype(np.int32)
+    pots = [
+        (P.HarmonicBond(s.bond_idxs), s.bond_params),
+        (P.HarmonicAngle(s.angle_idxs), s.angle_params),
+        (P.PeriodicTorsion(s.torsion_idxs), s.torsion_params),
+        (P.Nonbonded(n, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, atom_idxs=host), s.nb_params),
+        (P.NonbondedInteractionGroup(n, lig, s.beta, s.cutoff), s.nb_params),
+        (P.NonbondedPairListPrecomputed(lig_pairs, s.beta, s.cutoff), pre_params),
+        (P.ChiralAtomRestraint(chiral_idxs), np.full(6, 100.0)),
+        (P.ChiralBondRestraint(chiral_idxs, np.array([1, -1, 1, -1, 1, -1], np.int32)), np.full(6, 100.0)),
+    ]
+    x, box = s.coords, s.box
+    summed = P.SummedPotential([p for p, _ in pots], [q for _, q in pots], parallel=False).to_gpu(np.float32).unbound_impl
+    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in pots])
+    fused = summed.execute_raw(x, flat, box, True, False, False)[0]
+    acc = np.zeros_like(fused)
+    for pot, prm in pots:
+        acc += pot.to_gpu(np.float32).unbound_impl.execute_raw(x, np.asarray(prm, dtype=np.float64), box, True, False, False)[0]
+    np.testing.assert_array_equal(acc, fused)
+    # and it integrates
+    bps = [pot.bind(prm).to_gpu(np.float32).bound_impl for pot, prm in pots]
+    ctxt = co.Context(x, np.zeros_like(x), box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 11).impl(), bps)
+    xs, _ = ctxt.multiple_steps(50, 50)
+    assert np.all(np.isfinite(xs))
+    assert np.abs(xs[-1] - x).max() < 0.5
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Bitwise invariances (integer accumulation => reordering must not change one bit)
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", [np.float64, np.float32])

@@ -159,3 +159,32 @@ def test_brute_force_ixn_list_is_symmetric_cover():
         for j in np.nonzero(within[i])[0]:
             if j >= (i // 32) * 32:
                 assert j in lst[i // 32]
+
+
+def test_groups_precomputed_chiral_match_reference_golden():
+    """the expected energies in groups.npz came from the reference's nonbonded_interaction_groups,
+    nonbonded_on_precomputed_pairs, chiral_atom_restraint and chiral_bond_restraint."""
+    g = load("groups.npz")
+    beta, cutoff = float(g["beta"]), float(g["cutoff"])
+    for tag, cols in (("ig_all", None), ("ig_sub", g["ig_cols_sub"])):
+        u, gx, gp = rp.nonbonded_interaction_group(g["ig_x"], g["ig_params"], g["ig_box"], g["ig_rows"], beta, cutoff, cols)
+        np.testing.assert_allclose(u, float(g[f"{tag}_u"]), rtol=1e-12)
+        np.testing.assert_allclose(gx, g[f"{tag}_du_dx"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(gp, g[f"{tag}_du_dp"], rtol=1e-10, atol=1e-10)
+    # an interaction group is the all-pairs energy of the union minus the two within-group energies
+    rows, cols = g["ig_rows"], g["ig_cols_sub"]
+    union = np.sort(np.concatenate([rows, cols])).astype(np.int32)
+    u_union, _, _ = rp.nonbonded_all_pairs(g["ig_x"], g["ig_params"], g["ig_box"], beta, cutoff, atom_idxs=union)
+    u_rows, _, _ = rp.nonbonded_all_pairs(g["ig_x"], g["ig_params"], g["ig_box"], beta, cutoff, atom_idxs=rows)
+    u_cols, _, _ = rp.nonbonded_all_pairs(g["ig_x"], g["ig_params"], g["ig_box"], beta, cutoff, atom_idxs=cols)
+    np.testing.assert_allclose(u_union - u_rows - u_cols, float(g["ig_sub_u"]), rtol=1e-10)
+    u, gx, gp = rp.nonbonded_pair_list_precomputed(g["ig_x"], g["pre_params"], g["ig_box"], g["pre_idxs"], beta, cutoff)
+    np.testing.assert_allclose(u, float(g["pre_u"]), rtol=1e-12)
+    np.testing.assert_allclose(gx, g["pre_du_dx"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gp, g["pre_du_dp"], rtol=1e-10, atol=1e-10)
+    u, gx, gp = rp.chiral_atom_restraint(g["chiral_x"], g["chiral_atom_params"], None, g["chiral_atom_idxs"])
+    np.testing.assert_allclose(u, float(g["chiral_atom_u"]), rtol=1e-12)
+    np.testing.assert_allclose(gx, g["chiral_atom_du_dx"], rtol=1e-10, atol=1e-10)
+    u, gx, gp = rp.chiral_bond_restraint(g["chiral_x"], g["chiral_bond_params"], None, g["chiral_bond_idxs"], g["chiral_bond_signs"])
+    np.testing.assert_allclose(u, float(g["chiral_bond_u"]), rtol=1e-12)
+    np.testing.assert_allclose(gx, g["chiral_bond_du_dx"], rtol=1e-10, atol=1e-10)

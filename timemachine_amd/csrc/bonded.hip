@@ -134,6 +134,100 @@ void PeriodicTorsion<Real>::execute_device(
     }
 }
 
+// ---- chiral restraints ---------------------------------------------------------------------------------------
+template <typename Real> ChiralAtomRestraint<Real>::ChiralAtomRestraint(const std::vector<int> &idxs) : R_(idxs.size() / 4) {
+    if (idxs.size() % 4 != 0) {
+        throw std::runtime_error("idxs.size() must be exactly 4*k!");
+    }
+    d_idxs_.realloc(R_ * 4);
+    if (R_ > 0)
+        d_idxs_.copy_from(idxs.data());
+    d_u_partials_.realloc(ceil_divide(R_, 256) * 4 + 1);
+}
+
+template <typename Real> void ChiralAtomRestraint<Real>::check_size(const int P) const {
+    if (P != R_) {
+        throw std::runtime_error(
+            "ChiralAtomRestraint::execute_device(): expected P == R, got P=" + std::to_string(P) + ", R=" + std::to_string(R_));
+    }
+}
+
+template <typename Real> void ChiralAtomRestraint<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    this->check_size(P);
+    if (R_ > 0) {
+        plan.add_segment(sizeof(Real), FusedSegment{FUSED_CHIRAL_ATOM, R_, d_idxs_.data, d_p, nullptr, 0.0, 0.0, nullptr}, this, P, d_p);
+    }
+}
+
+template <typename Real>
+void ChiralAtomRestraint<Real>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    this->check_size(P);
+    if (R_ > 0) {
+        const int blocks = ceil_divide(R_, 256);
+        k_chiral_atom_restraint<Real><<<blocks, 256, 0, stream>>>(R_, d_x, d_p, d_idxs_.data, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (d_u)
+            reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+    }
+}
+
+template <typename Real>
+ChiralBondRestraint<Real>::ChiralBondRestraint(const std::vector<int> &idxs, const std::vector<int> &signs) : R_(idxs.size() / 4) {
+    if (idxs.size() % 4 != 0) {
+        throw std::runtime_error("idxs.size() must be exactly 4*R!");
+    }
+    if (static_cast<size_t>(R_) != signs.size()) {
+        throw std::runtime_error("signs.size() must be exactly R!");
+    }
+    for (auto sgn : signs) {
+        if (sgn != -1 && sgn != 1) {
+            throw std::runtime_error("signs must be comprised exclusively of 1 or -1");
+        }
+    }
+    d_idxs_.realloc(R_ * 4);
+    d_signs_.realloc(R_);
+    if (R_ > 0) {
+        d_idxs_.copy_from(idxs.data());
+        d_signs_.copy_from(signs.data());
+    }
+    d_u_partials_.realloc(ceil_divide(R_, 256) * 4 + 1);
+}
+
+template <typename Real> void ChiralBondRestraint<Real>::check_size(const int P) const {
+    if (P != R_) {
+        throw std::runtime_error(
+            "ChiralBondRestraint::execute_device(): expected P == R, got P=" + std::to_string(P) + ", R=" + std::to_string(R_));
+    }
+}
+
+template <typename Real> void ChiralBondRestraint<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    this->check_size(P);
+    if (R_ > 0) {
+        plan.add_segment(sizeof(Real), FusedSegment{FUSED_CHIRAL_BOND, R_, d_idxs_.data, d_p, nullptr, 0.0, 0.0, d_signs_.data}, this, P, d_p);
+    }
+}
+
+template <typename Real>
+void ChiralBondRestraint<Real>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    this->check_size(P);
+    if (R_ > 0) {
+        const int blocks = ceil_divide(R_, 256);
+        k_chiral_bond_restraint<Real><<<blocks, 256, 0, stream>>>(
+            R_, d_x, d_p, d_idxs_.data, d_signs_.data, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (d_u)
+            reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+    }
+}
+
+template class ChiralAtomRestraint<float>;
+template class ChiralAtomRestraint<double>;
+template class ChiralBondRestraint<float>;
+template class ChiralBondRestraint<double>;
 template class HarmonicBond<float>;
 template class HarmonicBond<double>;
 template class HarmonicAngle<float>;

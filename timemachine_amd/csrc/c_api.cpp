@@ -194,6 +194,61 @@ int tm_nonbonded_pair_list_create(
     TM_CATCH
 }
 
+int tm_nonbonded_interaction_group_create(
+    int precision, int num_atoms, const int32_t *row_atom_idxs, int num_rows, const int32_t *col_atom_idxs, int num_cols, double beta,
+    double cutoff, int disable_hilbert_sort, double nblist_padding, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> rows(row_atom_idxs, row_atom_idxs + num_rows);
+    std::vector<int> cols;
+    if (col_atom_idxs != nullptr) {
+        cols.assign(col_atom_idxs, col_atom_idxs + num_cols);
+    } else { // every atom that is not a row atom (wrap_kernels.cpp:1519-1522)
+        const std::set<int> row_set(rows.begin(), rows.end());
+        for (int i = 0; i < num_atoms; i++) {
+            if (!row_set.count(i)) {
+                cols.push_back(i);
+            }
+        }
+    }
+    *out = new tm_potential_s{make_by_precision<NonbondedInteractionGroup>(precision, num_atoms, rows, cols, beta, cutoff, disable_hilbert_sort != 0, nblist_padding)};
+    TM_CATCH
+}
+
+int tm_nonbonded_interaction_group_set_atom_idxs(
+    tm_potential_t pot, const int32_t *row_atom_idxs, int num_rows, const int32_t *col_atom_idxs, int num_cols) {
+    TM_TRY
+    std::vector<int> rows(row_atom_idxs, row_atom_idxs + num_rows), cols(col_atom_idxs, col_atom_idxs + num_cols);
+    if (auto a = std::dynamic_pointer_cast<NonbondedInteractionGroup<float>>(pot->p))
+        a->set_atom_idxs(rows, cols);
+    else if (auto b = std::dynamic_pointer_cast<NonbondedInteractionGroup<double>>(pot->p))
+        b->set_atom_idxs(rows, cols);
+    else
+        throw std::runtime_error("unable to cast potential to NonbondedInteractionGroup");
+    TM_CATCH
+}
+
+int tm_nonbonded_pair_list_precomputed_create(
+    int precision, const int32_t *pair_idxs, int num_pairs, double beta, double cutoff, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> p(pair_idxs, pair_idxs + static_cast<size_t>(num_pairs) * 2);
+    *out = new tm_potential_s{make_by_precision<NonbondedPairListPrecomputed>(precision, p, beta, cutoff)};
+    TM_CATCH
+}
+
+int tm_chiral_atom_restraint_create(int precision, const int32_t *idxs, int n, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 4);
+    *out = new tm_potential_s{make_by_precision<ChiralAtomRestraint>(precision, v)};
+    TM_CATCH
+}
+
+int tm_chiral_bond_restraint_create(int precision, const int32_t *idxs, int n, const int32_t *signs, int num_signs, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 4), sg(signs, signs + num_signs);
+    *out = new tm_potential_s{make_by_precision<ChiralBondRestraint>(precision, v, sg)};
+    TM_CATCH
+}
+
 int tm_summed_potential_create(
     const tm_potential_t *potentials, int n, const int32_t *params_sizes, int n_sizes, int parallel, tm_potential_t *out) {
     TM_TRY

@@ -22,7 +22,16 @@ int device_cu_count();
 // is worth.  When only forces are requested, potentials describe themselves to a ForcePlan instead of launching; the
 // plan runs every listed term in ONE kernel per precision and executes whatever cannot be fused (the neighbor-list
 // potentials) the normal way.  Integer accumulation makes the result independent of this regrouping, bit for bit.
-enum FusedKind : int { FUSED_BOND = 0, FUSED_ANGLE = 1, FUSED_TORSION = 2, FUSED_PAIR_LIST = 3, FUSED_PAIR_LIST_NEGATED = 4 };
+enum FusedKind : int {
+    FUSED_BOND = 0,
+    FUSED_ANGLE = 1,
+    FUSED_TORSION = 2,
+    FUSED_PAIR_LIST = 3,
+    FUSED_PAIR_LIST_NEGATED = 4,
+    FUSED_PAIR_LIST_PRECOMPUTED = 5,
+    FUSED_CHIRAL_ATOM = 6,
+    FUSED_CHIRAL_BOND = 7
+};
 static const int FUSED_MAX_SEGMENTS = 16;
 struct FusedSegment {
     int kind;
@@ -31,6 +40,7 @@ struct FusedSegment {
     const double *params; // bonded: [count][2|3]; pair lists: the [N][4] nonbonded parameters
     const double *scales; // pair lists: [count][2]
     double beta, cutoff;  // pair lists
+    const int *aux;       // chiral bond restraints: signs [count]
 };
 struct FusedTable {
     int n;
@@ -227,6 +237,31 @@ private:
     DeviceBuffer<i128> d_u_partials_;
 };
 
+// reference: cpp/src/chiral_atom_restraint.{hpp,cu}, chiral_bond_restraint.{hpp,cu}
+template <typename Real> class ChiralAtomRestraint : public Potential {
+public:
+    explicit ChiralAtomRestraint(const std::vector<int> &idxs);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int R_;
+    DeviceBuffer<int> d_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+    void check_size(const int P) const;
+};
+
+template <typename Real> class ChiralBondRestraint : public Potential {
+public:
+    ChiralBondRestraint(const std::vector<int> &idxs, const std::vector<int> &signs);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int R_;
+    DeviceBuffer<int> d_idxs_, d_signs_;
+    DeviceBuffer<i128> d_u_partials_;
+    void check_size(const int P) const;
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // reference: cpp/src/hilbert_sort.{hpp,cu}
 class HilbertSort {
@@ -320,7 +355,15 @@ public:
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
-private:
+protected:
+    // shared with NonbondedInteractionGroup: same pipeline over K_ = (rows | columns) atoms with a row/column list
+    struct GroupTag {};
+    NonbondedAllPairs(const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, GroupTag);
+    void allocate();
+    const char *name_ = "NonbondedAllPairs"; // class name used in error messages
+    int steps_per_sort_;
+    int group_rows_ = 0;  // > 0: the first group_rows_ entries of d_atom_idxs_ are the row group (sorted separately)
+    bool empty_ = false;  // interaction group with an empty side: execute_device does nothing
     const int N_;
     int K_;
     const double beta_, cutoff_, nblist_padding_;
@@ -345,6 +388,19 @@ private:
     int piggyback_blocks_ = 0;
 };
 
+// reference: cpp/src/nonbonded_interaction_group.{hpp,cu}.  Row atoms x column atoms (disjoint sets); both groups are
+// Hilbert-sorted independently and laid out as [rows | columns] in the sorted order the tile pipeline works on.
+template <typename Real> class NonbondedInteractionGroup : public NonbondedAllPairs<Real> {
+public:
+    NonbondedInteractionGroup(const int N, const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding);
+    void set_atom_idxs(const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs);
+    int get_num_row_idxs() const { return this->group_rows_; }
+    int get_num_col_idxs() const { return this->empty_ ? n_cols_ : this->K_ - this->group_rows_; }
+private:
+    int n_cols_ = 0;
+    static void validate_idxs(const int N, const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs, const bool allow_empty);
+};
+
 void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);
 
 // reference: cpp/src/nonbonded_pair_list.{hpp,cu}; Negated == true is bound as NonbondedExclusions_*
@@ -360,6 +416,21 @@ private:
     DeviceBuffer<int> d_pair_idxs_;
     DeviceBuffer<double> d_scales_;
     DeviceBuffer<i128> d_u_partials_;
+};
+
+// reference: cpp/src/nonbonded_precomputed.{hpp,cu}
+template <typename Real> class NonbondedPairListPrecomputed : public Potential {
+public:
+    NonbondedPairListPrecomputed(const std::vector<int> &pair_idxs, const double beta, const double cutoff);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+    void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+private:
+    int B_;
+    double beta_, cutoff_;
+    DeviceBuffer<int> d_pair_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+    void check_size(const int P) const;
 };
 
 // ------------------------------------------------------------------------------------------------------------

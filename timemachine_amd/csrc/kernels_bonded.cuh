@@ -270,4 +270,149 @@ __global__ __launch_bounds__(256) void k_periodic_torsion(
     }
 }
 
+// ---- chiral restraints --------------------------------------------------------------------------------------
+// reference: cpp/src/kernels/k_chiral_restraint.cuh:9-183, chiral_utils.cuh:92-177; JAX: potentials/chiral_restraints.py:9-125
+// U = k vol^2 where the normalised chiral volume has the penalised sign, else 0.
+//
+// Gradients are written in closed form instead of chaining 3x3 Jacobians: for a unit vector u^ = u/|u| and a scalar
+// f(u^, ...), df/du = (g - u^ (u^.g)) / |u| with g = df/du^ (projection onto the tangent plane of the unit sphere).
+template <typename Real> struct Vec3 {
+    Real x, y, z;
+};
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_sub(const Vec3<Real> a, const Vec3<Real> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_add(const Vec3<Real> a, const Vec3<Real> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_neg(const Vec3<Real> a) { return {-a.x, -a.y, -a.z}; }
+template <typename Real> __device__ __forceinline__ Real v_dot(const Vec3<Real> a, const Vec3<Real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_cross(const Vec3<Real> a, const Vec3<Real> b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_load(const double *__restrict__ coords, const int a) {
+    return {static_cast<Real>(coords[a * 3 + 0]), static_cast<Real>(coords[a * 3 + 1]), static_cast<Real>(coords[a * 3 + 2])};
+}
+// u -> (u^, 1/|u|)
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_unit(const Vec3<Real> u, Real &inv_norm) {
+    inv_norm = 1 / tm_sqrt<Real>(v_dot(u, u));
+    return {u.x * inv_norm, u.y * inv_norm, u.z * inv_norm};
+}
+// gradient w.r.t. the un-normalised vector, given g = df/d(unit vector)
+template <typename Real> __device__ __forceinline__ Vec3<Real> v_unit_pullback(const Vec3<Real> uhat, const Real inv_norm, const Vec3<Real> g) {
+    const Real along = v_dot(uhat, g);
+    return {(g.x - uhat.x * along) * inv_norm, (g.y - uhat.y * along) * inv_norm, (g.z - uhat.z * along) * inv_norm};
+}
+template <typename Real> __device__ __forceinline__ void v_atomic_add_scaled(u64 *__restrict__ du_dx, const int a, const Vec3<Real> g, const Real scale) {
+    atomicAdd(du_dx + a * 3 + 0, float_to_fixed<Real>(g.x * scale));
+    atomicAdd(du_dx + a * 3 + 1, float_to_fixed<Real>(g.y * scale));
+    atomicAdd(du_dx + a * 3 + 2, float_to_fixed<Real>(g.z * scale));
+}
+
+// centre c with neighbours 1, 2, 3: vol = (a^ x b^) . c^ with a = x1 - xc, b = x2 - xc, c = x3 - xc; penalised when vol > 0
+template <typename Real>
+__device__ __forceinline__ i128 chiral_atom_term(
+    const int r, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    const int ic = idxs[r * 4 + 0], i1 = idxs[r * 4 + 1], i2 = idxs[r * 4 + 2], i3 = idxs[r * 4 + 3];
+    const Vec3<Real> xc = v_load<Real>(coords, ic);
+    Real na, nb, nc;
+    const Vec3<Real> a = v_unit(v_sub(v_load<Real>(coords, i1), xc), na);
+    const Vec3<Real> b = v_unit(v_sub(v_load<Real>(coords, i2), xc), nb);
+    const Vec3<Real> c = v_unit(v_sub(v_load<Real>(coords, i3), xc), nc);
+    const Vec3<Real> ab = v_cross(a, b);
+    const Real vol = v_dot(ab, c);
+    const Real k = static_cast<Real>(params[r]);
+    i128 energy = 0;
+    if (want_u && vol > 0) {
+        energy = float_to_fixed_energy<Real>(k * vol * vol);
+    }
+    if (!(vol > 0)) {
+        return energy;
+    }
+    // (the reference kernel also returns early when k == 0, which zeroes du/dk there; d(k vol^2)/dk = vol^2 regardless,
+    // as its JAX definition has it)
+    if (du_dx && k != 0) {
+        // vol is the scalar triple product: d vol / d a^ = b^ x c^, and cyclically
+        const Vec3<Real> ga = v_unit_pullback(a, na, v_cross(b, c));
+        const Vec3<Real> gb = v_unit_pullback(b, nb, v_cross(c, a));
+        const Vec3<Real> gc = v_unit_pullback(c, nc, ab);
+        const Real pref = 2 * k * vol;
+        v_atomic_add_scaled(du_dx, ic, v_neg(v_add(v_add(ga, gb), gc)), pref);
+        v_atomic_add_scaled(du_dx, i1, ga, pref);
+        v_atomic_add_scaled(du_dx, i2, gb, pref);
+        v_atomic_add_scaled(du_dx, i3, gc, pref);
+    }
+    if (du_dp) {
+        atomicAdd(du_dp + r, float_to_fixed<Real>(vol * vol));
+    }
+    return energy;
+}
+
+// bond j-k with substituents i, l: vol = (a^ x b^) . (b^ x c^), a = xj - xi, b = xj - xk, c = xl - xk; penalised when
+// sign * vol > 0
+template <typename Real>
+__device__ __forceinline__ i128 chiral_bond_term(
+    const int r, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
+    const int *__restrict__ signs, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    const int ii = idxs[r * 4 + 0], ij = idxs[r * 4 + 1], ik = idxs[r * 4 + 2], il = idxs[r * 4 + 3];
+    const Vec3<Real> xi = v_load<Real>(coords, ii), xj = v_load<Real>(coords, ij);
+    const Vec3<Real> xk = v_load<Real>(coords, ik), xl = v_load<Real>(coords, il);
+    Real na, nb, nc;
+    const Vec3<Real> a = v_unit(v_sub(xj, xi), na);
+    const Vec3<Real> b = v_unit(v_sub(xj, xk), nb);
+    const Vec3<Real> c = v_unit(v_sub(xl, xk), nc);
+    const Vec3<Real> n1 = v_cross(a, b);
+    const Vec3<Real> n2 = v_cross(b, c);
+    const Real vol = v_dot(n1, n2);
+    const Real k = static_cast<Real>(params[r]);
+    const Real signed_vol = static_cast<Real>(signs[r]) * vol;
+    i128 energy = 0;
+    if (want_u && signed_vol > 0) {
+        energy = float_to_fixed_energy<Real>(k * vol * vol);
+    }
+    if (!(signed_vol > 0)) {
+        return energy;
+    }
+    if (du_dx && k != 0) {
+        // (a x b).n2 = a.(b x n2);  n1.(b x c) = c.(n1 x b);  and b enters both factors: n2 x a + c x n1
+        const Vec3<Real> ga = v_unit_pullback(a, na, v_cross(b, n2));
+        const Vec3<Real> gb = v_unit_pullback(b, nb, v_add(v_cross(n2, a), v_cross(c, n1)));
+        const Vec3<Real> gc = v_unit_pullback(c, nc, v_cross(n1, b));
+        const Real pref = 2 * k * vol;
+        v_atomic_add_scaled(du_dx, ii, v_neg(ga), pref);
+        v_atomic_add_scaled(du_dx, ij, v_add(ga, gb), pref);
+        v_atomic_add_scaled(du_dx, ik, v_neg(v_add(gb, gc)), pref);
+        v_atomic_add_scaled(du_dx, il, gc, pref);
+    }
+    if (du_dp) {
+        atomicAdd(du_dp + r, float_to_fixed<Real>(vol * vol));
+    }
+    return energy;
+}
+
+template <typename Real>
+__global__ __launch_bounds__(256) void k_chiral_atom_restraint(
+    const int R, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    i128 energy = 0;
+    if (r < R) {
+        energy = chiral_atom_term<Real>(r, coords, params, idxs, du_dx, du_dp, u_partials != nullptr);
+    }
+    if (u_partials) {
+        store_wave_energy<Real>(energy, u_partials);
+    }
+}
+
+template <typename Real>
+__global__ __launch_bounds__(256) void k_chiral_bond_restraint(
+    const int R, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
+    const int *__restrict__ signs, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    i128 energy = 0;
+    if (r < R) {
+        energy = chiral_bond_term<Real>(r, coords, params, idxs, signs, du_dx, du_dp, u_partials != nullptr);
+    }
+    if (u_partials) {
+        store_wave_energy<Real>(energy, u_partials);
+    }
+}
+
 } // namespace tmamd

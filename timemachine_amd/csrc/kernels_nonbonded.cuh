@@ -701,6 +701,91 @@ __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
     }
 }
 
+// ---- pair list with precomputed pair parameters (NonbondedPairListPrecomputed) ---------------------------------
+// reference: k_nonbonded_precomputed (k_nonbonded_precomputed.cuh:11-186); JAX: nonbonded_on_precomputed_pairs
+// (potentials/nonbonded.py:403-446).  params[pair] = (q_ij, sig_ij, eps_ij, w_offset_ij): combining rules and scale
+// factors already applied.  Note: the reference kernel only issues its force / du_dp atomics inside the LJ branch,
+// silently dropping pairs with eps_ij == 0 or sig_ij == 0; this follows the JAX definition instead (every pair counts).
+template <typename Real>
+__device__ __forceinline__ i128 nonbonded_precomputed_term(
+    const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
+    const int *__restrict__ pair_idxs, const double beta_d, const double cutoff_d, u64 *__restrict__ du_dx,
+    u64 *__restrict__ du_dp, const bool want_u) {
+    i128 energy = 0;
+    const NbBox<Real> bx = load_box<Real>(box);
+    const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
+    const Real cutoff = static_cast<Real>(cutoff_d);
+    const Real q_ij = static_cast<Real>(params[pair * 4 + 0]);
+    const Real sig_ij = static_cast<Real>(params[pair * 4 + 1]);
+    const Real eps_ij = static_cast<Real>(params[pair * 4 + 2]);
+    const Real dw = static_cast<Real>(params[pair * 4 + 3]);
+    const Real dx = min_image(static_cast<Real>(coords[ia * 3 + 0]) - static_cast<Real>(coords[ja * 3 + 0]), bx.x, bx.inv_x);
+    const Real dy = min_image(static_cast<Real>(coords[ia * 3 + 1]) - static_cast<Real>(coords[ja * 3 + 1]), bx.y, bx.inv_y);
+    const Real dz = min_image(static_cast<Real>(coords[ia * 3 + 2]) - static_cast<Real>(coords[ja * 3 + 2]), bx.z, bx.inv_z);
+    const Real d2 = pair_d2(dx, dy, dz, dw);
+    if (d2 < cutoff * cutoff) {
+        const Real inv = tm_rsqrt(d2);
+        const Real d = d2 * inv;
+        const Real inv2 = inv * inv;
+        Real prefactor = 0, u = 0, g_q = 0, g_sig = 0, g_eps = 0;
+        if (q_ij != 0) {
+            Real damping;
+            const Real es_factor = real_es_factor(static_cast<Real>(beta_d), d, inv, inv2, damping);
+            u += q_ij * inv * damping;
+            prefactor += q_ij * inv * es_factor;
+            g_q = damping * inv;
+        }
+        if (eps_ij != 0 && sig_ij != 0) {
+            const Real s = sig_ij * inv;
+            const Real s2 = s * s;
+            const Real s6 = s2 * s2 * s2;
+            g_eps = 4 * (s6 - 1) * s6;
+            u += eps_ij * g_eps;
+            const Real w24 = 24 * eps_ij * s6 * (2 * s6 - 1);
+            prefactor -= w24 * inv2;
+            g_sig = w24 / sig_ij;
+        }
+        if (du_dx) {
+            u64 fx, fy, fz;
+            pair_force_fixed(prefactor, dx, dy, dz, fx, fy, fz);
+            atomicAdd(du_dx + ia * 3 + 0, fx);
+            atomicAdd(du_dx + ia * 3 + 1, fy);
+            atomicAdd(du_dx + ia * 3 + 2, fz);
+            atomicAdd(du_dx + ja * 3 + 0, 0ull - fx);
+            atomicAdd(du_dx + ja * 3 + 1, 0ull - fy);
+            atomicAdd(du_dx + ja * 3 + 2, 0ull - fz);
+        }
+        if (du_dp) {
+            atomicAdd(du_dp + pair * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(g_q)));
+            atomicAdd(du_dp + pair * 4 + 1, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(g_sig)));
+            atomicAdd(du_dp + pair * 4 + 2, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(g_eps)));
+            atomicAdd(du_dp + pair * 4 + 3, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(prefactor * dw)));
+        }
+        if (want_u) {
+            energy = float_to_fixed_energy<Real>(u);
+        }
+    }
+    return energy;
+}
+
+template <typename Real>
+__global__ __launch_bounds__(256) void k_nonbonded_precomputed(
+    const int M, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
+    const int *__restrict__ pair_idxs, const double beta_d, const double cutoff_d, u64 *__restrict__ du_dx,
+    u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    i128 energy = 0;
+    if (pair < M) {
+        energy = nonbonded_precomputed_term<Real>(pair, coords, params, box, pair_idxs, beta_d, cutoff_d, du_dx, du_dp, u_partials != nullptr);
+    }
+    if (u_partials) {
+        const i128 total = wave_sum_i128(energy);
+        if ((threadIdx.x & 63) == 0) {
+            u_partials[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = total;
+        }
+    }
+}
+
 template <typename Real>
 __device__ __forceinline__ void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
@@ -729,6 +814,11 @@ __device__ __forceinline__ void fused_dispatch(
     case FUSED_PAIR_LIST_NEGATED:
         nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
         break;
+    case FUSED_PAIR_LIST_PRECOMPUTED:
+        nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        break;
+    case FUSED_CHIRAL_ATOM: chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_CHIRAL_BOND: chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, du_dx, nullptr, false); break;
     default: break;
     }
 }

@@ -13,7 +13,8 @@
 
 namespace tmamd {
 
-static const int STEPS_PER_SORT = 100; // reference: cpp/src/nonbonded_all_pairs.cu:16
+static const int STEPS_PER_SORT = 100;       // reference: cpp/src/nonbonded_all_pairs.cu:16
+static const int STEPS_PER_SORT_GROUP = 200; // reference: cpp/src/nonbonded_interaction_group.cu:17
 
 // =============================================================================================================
 // Hilbert sort
@@ -380,8 +381,8 @@ template <typename Real>
 NonbondedAllPairs<Real>::NonbondedAllPairs(
     const int N, const double beta, const double cutoff, const std::optional<std::vector<int>> &atom_idxs,
     const bool disable_hilbert_sort, const double nblist_padding)
-    : N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding), disable_hilbert_(disable_hilbert_sort),
-      calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N) {
+    : steps_per_sort_(STEPS_PER_SORT), N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding),
+      disable_hilbert_(disable_hilbert_sort), calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N) {
     std::vector<int> idxs;
     if (atom_idxs) {
         idxs = *atom_idxs;
@@ -392,7 +393,20 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
         std::iota(idxs.begin(), idxs.end(), 0);
     }
     verify_atom_idxs(N_, idxs);
+    this->allocate();
+    this->set_atom_idxs(idxs);
+}
 
+template <typename Real>
+NonbondedAllPairs<Real>::NonbondedAllPairs(
+    const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, GroupTag)
+    : name_("NonbondedInteractionGroup"), steps_per_sort_(STEPS_PER_SORT_GROUP), N_(N), K_(N), beta_(beta), cutoff_(cutoff),
+      nblist_padding_(nblist_padding), disable_hilbert_(disable_hilbert_sort), calls_since_sort_(0), parity_(0), force_rebuild_(true),
+      nblist_(N) {
+    this->allocate();
+}
+
+template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     d_atom_idxs_.realloc(N_);
     d_perm_.realloc(N_);
     d_gathered_.realloc(static_cast<size_t>(N_ + 1) * 8); // + one all-zero sentinel record
@@ -414,7 +428,6 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
     if (!disable_hilbert_) {
         hilbert_.reset(new HilbertSort(N_));
     }
-    this->set_atom_idxs(idxs);
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::vector<int> &atom_idxs) {
@@ -432,7 +445,7 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
 
 template <typename Real>
 bool NonbondedAllPairs<Real>::piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) {
-    if (precision_bytes != static_cast<int>(sizeof(Real)) || piggyback_table_ != nullptr) {
+    if (precision_bytes != static_cast<int>(sizeof(Real)) || piggyback_table_ != nullptr || empty_) {
         return false;
     }
     piggyback_table_ = d_table;
@@ -458,6 +471,9 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
     DeferredForces &out) {
     this->check_sizes(N, P);
+    if (empty_) {
+        return false; // nothing to hand over; the caller falls back to execute_device (a no-op)
+    }
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream);
     out.g_du_dx = d_g_du_dx_.data;
     out.slot_of_atom = d_slot_of_atom_.data;
@@ -469,17 +485,20 @@ void NonbondedAllPairs<Real>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
     this->check_sizes(N, P);
+    if (empty_) {
+        return; // reference: nonbonded_interaction_group.cu:171-174 (outputs untouched, d_u left as the caller set it)
+    }
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, d_du_dp, d_u, true, stream);
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, const int P) const {
     if (N != N_) {
         throw std::runtime_error(
-            "NonbondedAllPairs::execute_device(): expected N == N_, got N=" + std::to_string(N) + ", N_=" + std::to_string(N_));
+            std::string(name_) + "::execute_device(): expected N == N_, got N=" + std::to_string(N) + ", N_=" + std::to_string(N_));
     }
     if (P != N_ * PARAMS_PER_ATOM) {
         throw std::runtime_error(
-            "NonbondedAllPairs::execute_device(): expected P == N_*" + std::to_string(PARAMS_PER_ATOM) + ", got P=" +
+            std::string(name_) + "::execute_device(): expected P == N_*" + std::to_string(PARAMS_PER_ATOM) + ", got P=" +
             std::to_string(P) + ", N_*" + std::to_string(PARAMS_PER_ATOM) + "=" + std::to_string(N_ * PARAMS_PER_ATOM));
     }
 }
@@ -492,8 +511,11 @@ void NonbondedAllPairs<Real>::run_pipeline(
 
     // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
     int force = force_rebuild_ ? 1 : 0;
-    if (calls_since_sort_ % STEPS_PER_SORT == 0) {
-        if (!disable_hilbert_) {
+    if (calls_since_sort_ % steps_per_sort_ == 0) {
+        if (!disable_hilbert_ && group_rows_ > 0) { // interaction group: each side keeps its own contiguous, sorted range
+            hilbert_->sort_device(group_rows_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
+            hilbert_->sort_device(K_ - group_rows_, d_atom_idxs_.data + group_rows_, d_x, d_box, d_perm_.data + group_rows_, stream);
+        } else if (!disable_hilbert_) {
             hilbert_->sort_device(K_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
         } else {
             HIP_CHECK(hipMemcpyAsync(d_perm_.data, d_atom_idxs_.data, K_ * sizeof(unsigned int), hipMemcpyDeviceToDevice, stream));
@@ -574,6 +596,84 @@ template class NonbondedAllPairs<float>;
 template class NonbondedAllPairs<double>;
 
 // =============================================================================================================
+// NonbondedInteractionGroup
+// =============================================================================================================
+template <typename Real>
+void NonbondedInteractionGroup<Real>::validate_idxs(
+    const int N, const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs, const bool allow_empty) {
+    if (!allow_empty) {
+        if (row_atom_idxs.size() == 0) {
+            throw std::runtime_error("row_atom_idxs must be nonempty");
+        }
+        if (col_atom_idxs.size() == 0) {
+            throw std::runtime_error("col_atom_idxs must be nonempty");
+        }
+        if (row_atom_idxs.size() == static_cast<size_t>(N)) {
+            throw std::runtime_error("must be less then N(" + std::to_string(N) + ") row indices");
+        }
+        if (col_atom_idxs.size() == static_cast<size_t>(N)) {
+            throw std::runtime_error("must be less then N(" + std::to_string(N) + ") col indices");
+        }
+    }
+    verify_atom_idxs(N, row_atom_idxs, allow_empty);
+    verify_atom_idxs(N, col_atom_idxs, allow_empty);
+    const std::set<int> rows(row_atom_idxs.begin(), row_atom_idxs.end());
+    for (int c : col_atom_idxs) {
+        if (rows.count(c)) {
+            throw std::runtime_error("row and col indices must be disjoint");
+        }
+    }
+}
+
+template <typename Real>
+NonbondedInteractionGroup<Real>::NonbondedInteractionGroup(
+    const int N, const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs, const double beta,
+    const double cutoff, const bool disable_hilbert_sort, const double nblist_padding)
+    : NonbondedAllPairs<Real>(N, beta, cutoff, disable_hilbert_sort, nblist_padding, typename NonbondedAllPairs<Real>::GroupTag{}) {
+    validate_idxs(N, row_atom_idxs, col_atom_idxs, false);
+    this->set_atom_idxs(row_atom_idxs, col_atom_idxs);
+}
+
+template <typename Real>
+void NonbondedInteractionGroup<Real>::set_atom_idxs(const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs) {
+    validate_idxs(this->N_, row_atom_idxs, col_atom_idxs, true);
+    const std::set<int> row_set(row_atom_idxs.begin(), row_atom_idxs.end());
+    std::vector<unsigned int> all(row_set.begin(), row_set.end());
+    const int NR = static_cast<int>(all.size());
+    const int NC = static_cast<int>(col_atom_idxs.size());
+    if (NR + NC > this->N_) {
+        throw std::runtime_error("number of idxs must be less than or equal to N");
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(this->d_slot_of_atom_.data, 0xff, this->d_slot_of_atom_.size()));
+    n_cols_ = NC;
+    this->group_rows_ = NR;
+    // reference quirk kept: an empty side, or every atom a row atom, turns the potential into a no-op
+    this->empty_ = NR == 0 || NC == 0 || NR == this->N_;
+    if (!this->empty_) {
+        all.insert(all.end(), col_atom_idxs.begin(), col_atom_idxs.end());
+        const int K = NR + NC;
+        this->d_atom_idxs_.copy_from(all.data(), K);
+        this->nblist_.resize(K);
+        // list positions: rows are [0, NR), columns [NR, K) of the sorted order
+        std::vector<unsigned int> rows(NR), cols(NC);
+        std::iota(rows.begin(), rows.end(), 0u);
+        std::iota(cols.begin(), cols.end(), static_cast<unsigned int>(NR));
+        DeviceBuffer<unsigned int> d_rows(NR), d_cols(NC);
+        d_rows.copy_from(rows.data());
+        d_cols.copy_from(cols.data());
+        this->nblist_.set_idxs_device(NC, NR, d_cols.data, d_rows.data, 0);
+        HIP_CHECK(hipStreamSynchronize(0));
+        this->K_ = K;
+    }
+    this->calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
+    this->force_rebuild_ = true;
+}
+
+template class NonbondedInteractionGroup<float>;
+template class NonbondedInteractionGroup<double>;
+
+// =============================================================================================================
 // NonbondedPairList
 // =============================================================================================================
 template <typename Real, bool Negated>
@@ -637,5 +737,68 @@ template class NonbondedPairList<float, true>;
 template class NonbondedPairList<float, false>;
 template class NonbondedPairList<double, true>;
 template class NonbondedPairList<double, false>;
+
+// =============================================================================================================
+// NonbondedPairListPrecomputed
+// =============================================================================================================
+template <typename Real>
+NonbondedPairListPrecomputed<Real>::NonbondedPairListPrecomputed(const std::vector<int> &pair_idxs, const double beta, const double cutoff)
+    : B_(pair_idxs.size() / 2), beta_(beta), cutoff_(cutoff) {
+    if (pair_idxs.size() % 2 != 0) {
+        throw std::runtime_error("idxs.size() must be exactly 2*B!");
+    }
+    for (int b = 0; b < B_; b++) {
+        const int src = pair_idxs[b * 2 + 0], dst = pair_idxs[b * 2 + 1];
+        if (src == dst) {
+            throw std::runtime_error("illegal pair with src == dst: " + std::to_string(src) + ", " + std::to_string(dst));
+        }
+    }
+    d_pair_idxs_.realloc(B_ * 2);
+    if (B_ > 0) {
+        d_pair_idxs_.copy_from(pair_idxs.data());
+    }
+    d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
+}
+
+template <typename Real> void NonbondedPairListPrecomputed<Real>::check_size(const int P) const {
+    if (P != PARAMS_PER_ATOM * B_) {
+        throw std::runtime_error(
+            "NonbondedPairListPrecomputed::execute_device(): expected P == " + std::to_string(PARAMS_PER_ATOM) + "*B, got P=" +
+            std::to_string(P) + ", " + std::to_string(PARAMS_PER_ATOM) + "*B=" + std::to_string(PARAMS_PER_ATOM * B_));
+    }
+}
+
+template <typename Real>
+void NonbondedPairListPrecomputed<Real>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    this->check_size(P);
+    if (B_ > 0) {
+        plan.add_segment(
+            sizeof(Real), FusedSegment{FUSED_PAIR_LIST_PRECOMPUTED, B_, d_pair_idxs_.data, d_p, nullptr, beta_, cutoff_, nullptr}, this, P, d_p);
+    }
+}
+
+template <typename Real>
+void NonbondedPairListPrecomputed<Real>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    this->check_size(P);
+    if (B_ > 0) {
+        const int blocks = ceil_divide(B_, 256);
+        k_nonbonded_precomputed<Real><<<blocks, 256, 0, stream>>>(
+            B_, d_x, d_p, d_box, d_pair_idxs_.data, beta_, cutoff_, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (d_u) {
+            reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+        }
+    }
+}
+
+template <typename Real>
+void NonbondedPairListPrecomputed<Real>::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) {
+    nb_du_dp_fixed_to_float(B_, du_dp, du_dp_float); // rows are pairs here, same per-column exponents
+}
+
+template class NonbondedPairListPrecomputed<float>;
+template class NonbondedPairListPrecomputed<double>;
 
 } // namespace tmamd

@@ -339,7 +339,64 @@ def _pair_list_ctor(negated):
     return ctor
 
 
+def _interaction_group_ctor(
+    cls, prec, num_atoms, row_atom_idxs_i, beta, cutoff, col_atom_idxs_i=None, disable_hilbert_sort=False, nblist_padding=0.1
+):
+    """NonbondedInteractionGroup_*(num_atoms, row_atom_idxs_i, beta, cutoff, col_atom_idxs_i=None,
+    disable_hilbert_sort=False, nblist_padding=0.1); wrap_kernels.cpp:1481-1561."""
+    rows = _i32(row_atom_idxs_i, "row_atom_idxs_i")
+    cols = None if col_atom_idxs_i is None else _i32(col_atom_idxs_i, "col_atom_idxs_i")
+    return _new_potential(
+        cls, _lib.tm_nonbonded_interaction_group_create, _c_int(prec), _c_int(int(num_atoms)), _ptr(rows), _c_int(rows.size),
+        _ptr(cols), _c_int(0 if cols is None else cols.size), _c_double(beta), _c_double(cutoff),
+        _c_int(1 if disable_hilbert_sort else 0), _c_double(nblist_padding))
+
+
+def _pair_list_precomputed_ctor(cls, prec, pair_idxs, beta, cutoff):
+    """NonbondedPairListPrecomputed_*(pair_idxs int32[B,2], beta, cutoff); wrap_kernels.cpp:1353-1364."""
+    idx = _i32(pair_idxs, "pair_idxs")
+    if idx.size % 2 != 0:
+        raise RuntimeError("idxs.size() must be exactly 2*B!")
+    return _new_potential(
+        cls, _lib.tm_nonbonded_pair_list_precomputed_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 2), _c_double(beta), _c_double(cutoff))
+
+
+def _chiral_atom_ctor(cls, prec, idxs):
+    """ChiralAtomRestraint_*(idxs int32[R,4]); wrap_kernels.cpp:1366-1378."""
+    idx = _i32(idxs, "idxs")
+    if idx.size % 4 != 0:
+        raise RuntimeError("idxs.size() must be exactly 4*k!")
+    return _new_potential(cls, _lib.tm_chiral_atom_restraint_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 4))
+
+
+def _chiral_bond_ctor(cls, prec, idxs, signs):
+    """ChiralBondRestraint_*(idxs int32[R,4], signs int32[R]); wrap_kernels.cpp:1380-1394."""
+    idx = _i32(idxs, "idxs")
+    sg = _i32(signs, "signs")
+    if idx.size % 4 != 0:
+        raise RuntimeError("idxs.size() must be exactly 4*R!")
+    return _new_potential(
+        cls, _lib.tm_chiral_bond_restraint_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 4), _ptr(sg), _c_int(sg.size))
+
+
 HarmonicBond_f32, HarmonicBond_f64 = _declare_precision_classes("HarmonicBond", _harmonic_bond_ctor)
+NonbondedInteractionGroup_f32, NonbondedInteractionGroup_f64 = _declare_precision_classes("NonbondedInteractionGroup", _interaction_group_ctor)
+NonbondedPairListPrecomputed_f32, NonbondedPairListPrecomputed_f64 = _declare_precision_classes(
+    "NonbondedPairListPrecomputed", _pair_list_precomputed_ctor)
+ChiralAtomRestraint_f32, ChiralAtomRestraint_f64 = _declare_precision_classes("ChiralAtomRestraint", _chiral_atom_ctor)
+ChiralBondRestraint_f32, ChiralBondRestraint_f64 = _declare_precision_classes("ChiralBondRestraint", _chiral_bond_ctor)
+
+
+def _interaction_group_set_atom_idxs(self, row_atom_idxs, col_atom_idxs):
+    """wrap_kernels.cpp:1485-1504"""
+    rows = _i32(np.asarray(row_atom_idxs, dtype=np.int32))
+    cols = _i32(np.asarray(col_atom_idxs, dtype=np.int32))
+    _check(_lib.tm_nonbonded_interaction_group_set_atom_idxs(self._h, _ptr(rows), _c_int(rows.size), _ptr(cols), _c_int(cols.size)))
+
+
+for _k in (NonbondedInteractionGroup_f32, NonbondedInteractionGroup_f64):
+    _k.set_atom_idxs = _interaction_group_set_atom_idxs
+
 HarmonicAngle_f32, HarmonicAngle_f64 = _declare_precision_classes("HarmonicAngle", _harmonic_angle_ctor)
 PeriodicTorsion_f32, PeriodicTorsion_f64 = _declare_precision_classes("PeriodicTorsion", _periodic_torsion_ctor)
 NonbondedAllPairs_f32, NonbondedAllPairs_f64 = _declare_precision_classes("NonbondedAllPairs", _nonbonded_all_pairs_ctor)
@@ -731,9 +788,7 @@ def _not_on_hot_path(name):
 
 
 for _name in (
-    "NonbondedInteractionGroup_f32", "NonbondedInteractionGroup_f64", "NonbondedPairListPrecomputed_f32",
-    "NonbondedPairListPrecomputed_f64", "ChiralAtomRestraint_f32", "ChiralAtomRestraint_f64", "ChiralBondRestraint_f32",
-    "ChiralBondRestraint_f64", "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
+    "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
     "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "MonteCarloBarostat", "VelocityVerletIntegrator", "BDExchangeMove_f32",
     "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
 ):

@@ -8,13 +8,17 @@ from .potential import (  # noqa: F401
     get_potential_by_type,
 )
 from .potentials import (  # noqa: F401
+    ChiralAtomRestraint,
+    ChiralBondRestraint,
     FanoutSummedPotential,
     HarmonicAngle,
     HarmonicBond,
     Nonbonded,
     NonbondedAllPairs,
     NonbondedExclusions,
+    NonbondedInteractionGroup,
     NonbondedPairList,
+    NonbondedPairListPrecomputed,
     PeriodicTorsion,
     SummedPotential,
     SummedPotentialGpuImplWrapper,

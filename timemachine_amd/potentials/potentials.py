@@ -95,6 +95,53 @@ class NonbondedAllPairs(Potential):
 
 
 @dataclass
+class NonbondedInteractionGroup(Potential):
+    """Row atoms x column atoms (reference: potentials.py:164-186).  ``col_atom_idxs=None``: all atoms not in the rows."""
+
+    num_atoms: int
+    row_atom_idxs: NDArray[np.int32]
+    beta: float
+    cutoff: float
+    col_atom_idxs: Optional[NDArray[np.int32]] = None
+    disable_hilbert_sort: bool = False
+    nblist_padding: float = 0.1
+
+    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
+        ctor = getattr(custom_ops, self._custom_ops_class_name(precision))
+        return GpuImplWrapper(
+            ctor(
+                self.num_atoms, self.row_atom_idxs, self.beta, self.cutoff, self.col_atom_idxs, self.disable_hilbert_sort,
+                self.nblist_padding,
+            )
+        )
+
+
+@dataclass
+class NonbondedPairListPrecomputed(Potential):
+    """Pair list whose params are per PAIR: (q_ij, sig_ij, eps_ij, w_offset_ij), combining rules and scale factors already
+    applied (reference: potentials.py:218-237)."""
+
+    idxs: NDArray[np.int32]
+    beta: float
+    cutoff: float
+
+
+@dataclass
+class ChiralAtomRestraint(Potential):
+    """reference: potentials.py:60-65; params [R] force constants"""
+
+    idxs: NDArray[np.int32]
+
+
+@dataclass
+class ChiralBondRestraint(Potential):
+    """reference: potentials.py:68-74; params [R] force constants"""
+
+    idxs: NDArray[np.int32]
+    signs: NDArray[np.int32]
+
+
+@dataclass
 class NonbondedPairList(Potential):
     idxs: NDArray[np.int32]
     rescale_mask: NDArray[np.float64]
