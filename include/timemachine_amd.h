@@ -155,6 +155,8 @@ int tm_bound_potential_execute_batch(tm_bound_potential_t bp, int coord_batch_si
  * Bound as <float> only, like the reference (wrap_kernels.cpp:700). */
 int tm_langevin_integrator_create(const double *masses, int N, double temperature, double dt, double friction, int seed,
                                   tm_integrator_t *out);
+/* VelocityVerletIntegrator(dt, cbs f64[N]) with cbs = -dt / mass      wrap_kernels.cpp:717-729; verlet_integrator.cu:10-111 */
+int tm_velocity_verlet_integrator_create(double dt, const double *cbs, int N, tm_integrator_t *out);
 int tm_integrator_destroy(tm_integrator_t intg);
 
 /* ---- Context(x0, v0, box, integrator, bps, movers=None)           wrap_kernels.cpp:296-689; context.cu ---------- */

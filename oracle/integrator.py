@@ -52,3 +52,19 @@ def baoab_step_device_model(x, v, du_dx_fixed, noise, ca, cb, cc, dt_r, real=np.
     # x += 0.5*dt*(v_mid + v_t): RealType * (RealType + double) -> evaluated in double
     new_x = x + np.float64(r(0.5) * dt_r) * (v_mid.astype(np.float64) + new_v)
     return new_x, new_v
+
+
+def velocity_verlet_device_model(x, v, force_fixed_fn, cbs, dt, n_steps):
+    """The reference's device Velocity Verlet (verlet_integrator.cu:22-111, k_integrator.cuh:64-130) in double:
+    initialize (half kick + drift), n_steps - 1 full (kick + drift) steps, finalize (half kick).  ``force_fixed_fn(x)``
+    returns the uint64 fixed-point du/dx; ``cbs`` = -dt / mass.  Equivalent schedule: integrator.py:169-199."""
+    from .fixed_point import fixed_to_float
+
+    x, v = x.copy(), v.copy()
+    v = v + (0.5 * cbs)[:, None] * fixed_to_float(force_fixed_fn(x))
+    x = x + dt * v
+    for _ in range(n_steps - 1):
+        v = v + cbs[:, None] * fixed_to_float(force_fixed_fn(x))
+        x = x + dt * v
+    v = v + (0.5 * cbs)[:, None] * fixed_to_float(force_fixed_fn(x))
+    return x, v

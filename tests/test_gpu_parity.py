@@ -264,6 +264,56 @@ def test_chiral_restraints_golden(co, P, precision):
 
 
 @pytest.mark.gpu
+def test_velocity_verlet_matches_device_model_and_reverses(co, P):
+    """VelocityVerletIntegrator: multiple_steps == initialize + (n-1) steps + finalize of the device
+    model with the GPU's own fixed-point forces; time reversal returns to the start (tests/test_velocity_verlet_integrator.py)."""
+    from oracle import integrator as oi
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import VelocityVerletIntegrator
+
+    s = _md_system()
+    N = s.num_atoms
+    rng = np.random.default_rng(5)
+    v0 = rng.normal(size=(N, 3)) * 0.2
+    dt, n_steps = 0.5e-3, 10
+    vv = VelocityVerletIntegrator(dt, s.masses)
+    np.testing.assert_array_equal(vv.cbs, -dt / s.masses)
+    bps = [bp.to_gpu(np.float64).bound_impl for bp in ts.bound_potentials(s)]
+    eval_bps = [bp.to_gpu(np.float64).bound_impl for bp in ts.bound_potentials(s)]
+
+    def force_fixed(x):
+        fixed = np.zeros((N, 3), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for bp in eval_bps:
+                dx, _ = bp.execute(x, s.box, True, False)
+                fixed += np.rint(dx * 2.0**36).astype(np.int64).view(np.uint64)
+        return fixed
+
+    ctxt = co.Context(s.coords, v0, s.box, vv.impl(), bps)
+    xs, _ = ctxt.multiple_steps(n_steps, 0)
+    # Context.multiple_steps(n) = initialize + n steps + finalize, i.e. n + 1 drifts: the reference's own test compares it
+    # with the Python integrator's multiple_steps(n + 1) (tests/test_velocity_verlet_integrator.py:128-136)
+    x_model, v_model = oi.velocity_verlet_device_model(s.coords, v0, force_fixed, vv.cbs, dt, n_steps + 1)
+    np.testing.assert_allclose(ctxt.get_x_t(), x_model, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ctxt.get_v_t(), v_model, rtol=0, atol=1e-10)
+    np.testing.assert_array_equal(xs[-1], ctxt.get_x_t())
+    # reversibility: flip the velocities, integrate the same number of steps, land on the start
+    x1, v1 = ctxt.get_x_t(), ctxt.get_v_t()
+    back = co.Context(x1, -v1, s.box, vv.impl(), bps)
+    back.multiple_steps(n_steps, 0)
+    np.testing.assert_allclose(back.get_x_t(), s.coords, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(back.get_v_t(), -v0, rtol=0, atol=1e-7)
+    # initialize / finalize bookkeeping (verlet_integrator.cu:52-54,88-90)
+    c2 = co.Context(s.coords, v0, s.box, vv.impl(), bps)
+    c2.initialize()
+    with pytest.raises(RuntimeError, match="initialized twice"):
+        c2.initialize()
+    c2.finalize()
+    with pytest.raises(RuntimeError, match="not initialized"):
+        c2.finalize()
+
+
+@pytest.mark.gpu
 def test_rbfe_shaped_state_runs_fused(co, P):
     """A HostGuestSystem-shaped state (fe/system.py:132-143): host-host Nonbonded(atom_idxs=host), ligand-environment
     interaction group, ligand-ligand precomputed pairs, chiral restraints, bonded terms -- as one SummedPotential in an

@@ -431,6 +431,12 @@ int tm_langevin_integrator_create(
     TM_CATCH
 }
 
+int tm_velocity_verlet_integrator_create(double dt, const double *cbs, int N, tm_integrator_t *out) {
+    TM_TRY
+    *out = new tm_integrator_s{std::make_shared<VelocityVerletIntegrator>(N, dt, cbs)};
+    TM_CATCH
+}
+
 int tm_integrator_destroy(tm_integrator_t intg) {
     TM_TRY
     delete intg;

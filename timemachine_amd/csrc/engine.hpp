@@ -464,6 +464,26 @@ private:
     std::vector<DeferredForces> deferred_;
 };
 
+// reference: cpp/src/verlet_integrator.{hpp,cu}; kernels/k_integrator.cuh:64-130.  Arithmetic in double, as the reference
+// instantiates its kernels.  cbs = -dt / mass (the Python dataclass flips the sign: lib/__init__.py:24-37).
+class VelocityVerletIntegrator : public Integrator {
+public:
+    VelocityVerletIntegrator(const int N, const double dt, const double *h_cbs);
+    void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
+    void initialize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
+    void finalize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
+private:
+    const int N_;
+    const double dt_;
+    bool initialized_;
+    DeviceBuffer<double> d_cbs_;
+    DeviceBuffer<u64> d_du_dx_;
+    ForcePlan plan_;
+    std::vector<DeferredForces> deferred_;
+    // mode 0: v += cb F, x += dt v;  1: v += cb/2 F, x += dt v;  2: v += cb/2 F
+    void forces_then_update(const int mode, std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream);
+};
+
 // reference: cpp/src/mover.hpp (interface only; no movers are implemented on this path yet)
 class Mover {
 public:

@@ -147,6 +147,107 @@ void LangevinIntegrator<Real>::step_fwd(
     step_++;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// reference: update_forward_velocity_verlet / half_step_velocity_verlet (k_integrator.cuh:64-130)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_velocity_verlet(
+    const int N, const unsigned int *__restrict__ idxs, const double *__restrict__ cbs, double *__restrict__ x_t, double *__restrict__ v_t,
+    u64 *__restrict__ du_dx, const double dt, const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1,
+    const int *__restrict__ slot1) {
+    const int kidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kidx >= N) {
+        return;
+    }
+    const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
+    if (atom >= N) {
+        if (idxs != nullptr) { // frozen slot: its accumulator still has to start the next evaluation from zero
+            du_dx[kidx * 3 + 0] = 0;
+            du_dx[kidx * 3 + 1] = 0;
+            du_dx[kidx * 3 + 2] = 0;
+        }
+        return;
+    }
+    const double cb = MODE == 0 ? cbs[atom] : 0.5 * cbs[atom];
+    const int s0 = g0 ? slot0[atom] : -1;
+    const int s1 = g1 ? slot1[atom] : -1;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        u64 f = du_dx[atom * 3 + d];
+        if (s0 >= 0) {
+            f += g0[static_cast<size_t>(s0) * 3 + d];
+        }
+        if (s1 >= 0) {
+            f += g1[static_cast<size_t>(s1) * 3 + d];
+        }
+        const double force = fixed_to_float<double>(f);
+        const double v = v_t[atom * 3 + d] + cb * force;
+        v_t[atom * 3 + d] = v;
+        if (MODE != 2) {
+            x_t[atom * 3 + d] += dt * v;
+        }
+        du_dx[atom * 3 + d] = 0;
+    }
+}
+
+VelocityVerletIntegrator::VelocityVerletIntegrator(const int N, const double dt, const double *h_cbs)
+    : N_(N), dt_(dt), initialized_(false), d_cbs_(N), d_du_dx_(static_cast<size_t>(N) * 3) {
+    d_cbs_.copy_from(h_cbs);
+    HIP_CHECK(hipMemset(d_du_dx_.data, 0, d_du_dx_.size()));
+}
+
+void VelocityVerletIntegrator::forces_then_update(
+    const int mode, std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t,
+    unsigned int *d_idxs, hipStream_t stream) {
+    plan_.clear();
+    for (auto &bp : bps) {
+        bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
+    }
+    deferred_.clear();
+    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2);
+    const DeferredForces none;
+    const DeferredForces &a = deferred_.size() > 0 ? deferred_[0] : none;
+    const DeferredForces &b = deferred_.size() > 1 ? deferred_[1] : none;
+    const int tpb = 256, blocks = ceil_divide(N_, tpb);
+#define TM_VV(MODE)                                                                                                    \
+    k_velocity_verlet<MODE><<<blocks, tpb, 0, stream>>>(                                                               \
+        N_, d_idxs, d_cbs_.data, d_x_t, d_v_t, d_du_dx_.data, dt_, a.g_du_dx, a.slot_of_atom, b.g_du_dx, b.slot_of_atom)
+    if (mode == 0) {
+        TM_VV(0);
+    } else if (mode == 1) {
+        TM_VV(1);
+    } else {
+        TM_VV(2);
+    }
+#undef TM_VV
+    HIP_CHECK(hipGetLastError());
+}
+
+void VelocityVerletIntegrator::step_fwd(
+    std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
+    hipStream_t stream) {
+    this->forces_then_update(0, bps, d_x_t, d_v_t, d_box_t, d_idxs, stream);
+}
+
+void VelocityVerletIntegrator::initialize(
+    std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
+    hipStream_t stream) {
+    if (initialized_) {
+        throw std::runtime_error("initialized twice");
+    }
+    this->forces_then_update(1, bps, d_x_t, d_v_t, d_box_t, d_idxs, stream);
+    initialized_ = true;
+}
+
+void VelocityVerletIntegrator::finalize(
+    std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
+    hipStream_t stream) {
+    if (!initialized_) {
+        throw std::runtime_error("not initialized");
+    }
+    this->forces_then_update(2, bps, d_x_t, d_v_t, d_box_t, d_idxs, stream);
+    initialized_ = false;
+}
+
 template class LangevinIntegrator<float>;
 template class LangevinIntegrator<double>;
 

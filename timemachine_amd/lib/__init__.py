@@ -1,5 +1,5 @@
 """Thin dataclasses whose ``.impl()`` constructs ``custom_ops`` objects (reference: timemachine/lib/__init__.py:12-62)."""
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 from numpy.typing import NDArray
@@ -19,3 +19,21 @@ class LangevinIntegrator:
 
     def impl(self):
         return custom_ops.LangevinIntegrator(self.masses, self.temperature, self.dt, self.friction, self.seed)
+
+
+@dataclass
+class VelocityVerletIntegrator:
+    """reference: timemachine/lib/__init__.py:24-37 (cbs = -dt / masses, computed in __post_init__)."""
+
+    dt: float
+    masses: NDArray[np.float64]
+
+    cbs: NDArray[np.float64] = field(init=False)
+
+    def __post_init__(self):
+        cb = self.dt / np.asarray(self.masses, dtype=np.float64)
+        cb *= -1
+        self.cbs = cb
+
+    def impl(self):
+        return custom_ops.VelocityVerletIntegrator(self.dt, self.cbs)

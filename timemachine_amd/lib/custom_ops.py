@@ -566,6 +566,15 @@ class LangevinIntegrator(Integrator):
             _ptr(m), _c_int(m.size), _c_double(temperature), _c_double(dt), _c_double(friction), _c_int(int(seed)), ctypes.byref(self._h)))
 
 
+class VelocityVerletIntegrator(Integrator):
+    """VelocityVerletIntegrator(dt, cbs f64[N]) with cbs = -dt / mass; wrap_kernels.cpp:717-729 (double arithmetic)."""
+
+    def __init__(self, dt, cbs):
+        c = _f64(cbs, "cbs")
+        self._h = _vp()
+        _check(_lib.tm_velocity_verlet_integrator_create(_c_double(dt), _ptr(c), _c_int(c.size), ctypes.byref(self._h)))
+
+
 class Mover:
     """Interface placeholder (wrap_kernels.cpp:1591-1617); no movers are implemented on this path yet."""
 
@@ -789,7 +798,7 @@ def _not_on_hot_path(name):
 
 for _name in (
     "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
-    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "MonteCarloBarostat", "VelocityVerletIntegrator", "BDExchangeMove_f32",
+    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "MonteCarloBarostat", "BDExchangeMove_f32",
     "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
 ):
     globals()[_name] = _not_on_hot_path(_name)
