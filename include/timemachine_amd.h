@@ -45,6 +45,7 @@ typedef struct tm_int128 { /* little-endian two's-complement, layout-identical t
 typedef struct tm_potential_s *tm_potential_t;
 typedef struct tm_bound_potential_s *tm_bound_potential_t;
 typedef struct tm_integrator_s *tm_integrator_t;
+typedef struct tm_mover_s *tm_mover_t;
 typedef struct tm_context_s *tm_context_t;
 typedef struct tm_neighborlist_s *tm_neighborlist_t;
 typedef struct tm_hilbert_sort_s *tm_hilbert_sort_t;
@@ -162,6 +163,31 @@ int tm_integrator_destroy(tm_integrator_t intg);
 /* ---- Context(x0, v0, box, integrator, bps, movers=None)           wrap_kernels.cpp:296-689; context.cu ---------- */
 int tm_context_create(const double *x0, const double *v0, const double *box, int N, tm_integrator_t intg,
                       const tm_bound_potential_t *bps, int num_bps, tm_context_t *out);
+/* Context(x0, v0, box, integrator, bps, movers)                          wrap_kernels.cpp:296-335; context.cu:28-50,262-277 */
+int tm_context_create_with_movers(const double *x0, const double *v0, const double *box, int N, tm_integrator_t intg,
+                                  const tm_bound_potential_t *bps, int num_bps, const tm_mover_t *movers, int num_movers,
+                                  tm_context_t *out);
+/* MonteCarloBarostat(N, pressure [bar], temperature [K], group_idxs, interval, bps, seed, adaptive_scaling_enabled,
+ * initial_volume_scale_factor)  -- <float> arithmetic as bound by the reference       wrap_kernels.cpp:1619-1659; barostat.cu:19-259
+ * group_idxs arrives flattened: atoms of group g are group_atom_idxs[group_offsets[g] .. group_offsets[g+1]). */
+int tm_monte_carlo_barostat_create(int N, double pressure, double temperature, const int32_t *group_atom_idxs,
+                                   const int32_t *group_offsets, int num_groups, int interval, const tm_bound_potential_t *bps,
+                                   int num_bps, int seed, int adaptive_scaling_enabled, double initial_volume_scale_factor,
+                                   tm_mover_t *out);
+/* Mover.set_interval / get_interval / set_step / move(coords, box)     wrap_kernels.cpp:1591-1617; mover.hpp:12-46, mover.cu:7-23 */
+int tm_mover_destroy(tm_mover_t mover);
+int tm_mover_set_interval(tm_mover_t mover, int interval);
+int tm_mover_get_interval(tm_mover_t mover, int *interval);
+int tm_mover_set_step(tm_mover_t mover, int step);
+int tm_mover_move(tm_mover_t mover, int N, const double *x, const double *box, double *x_out, double *box_out);
+/* MonteCarloBarostat accessors                                          wrap_kernels.cpp:1654-1658 */
+int tm_barostat_set_volume_scale_factor(tm_mover_t mover, double volume_scale_factor);
+int tm_barostat_get_volume_scale_factor(tm_mover_t mover, double *volume_scale_factor);
+int tm_barostat_set_adaptive_scaling(tm_mover_t mover, int enabled);
+int tm_barostat_get_adaptive_scaling(tm_mover_t mover, int *enabled);
+int tm_barostat_set_pressure(tm_mover_t mover, double pressure);
+/* diagnostic (not in the reference surface): acceptance counters since the last adaptive reset */
+int tm_barostat_get_counters(tm_mover_t mover, int *accepted, int *attempted);
 int tm_context_destroy(tm_context_t ctxt);
 int tm_context_num_atoms(tm_context_t ctxt, int *N);
 int tm_context_step(tm_context_t ctxt);

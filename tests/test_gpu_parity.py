@@ -264,6 +264,103 @@ def test_chiral_restraints_golden(co, P, precision):
 
 
 @pytest.mark.gpu
+def test_barostat_follows_model_attempt_by_attempt(co, P):
+    """MonteCarloBarostat: every attempt's proposal (molecular centroid scaling) and Metropolis
+    decision against oracle/barostat.py, fed with the same Philox uniforms and the GPU's own energies.
+    reference tests: tests/test_barostat.py (scaling keeps molecules rigid, interval / validation semantics)."""
+    from oracle import barostat as ob
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import MonteCarloBarostat
+
+    s = _md_system()  # waters first, then the 16-atom chain ligand
+    N = s.num_atoms
+    groups = [list(range(3 * k, 3 * k + 3)) for k in range((N - 16) // 3)] + [list(range(N - 16, N))]
+    assert sum(len(g) for g in groups) == N
+    bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+    eval_bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+    seed, T, pressure = 2024, 300.0, 1.0
+    baro = MonteCarloBarostat(N, pressure, T, groups, 1, seed, adaptive_scaling_enabled=False, initial_volume_scale_factor=0.0).impl(bps)
+    baro.set_volume_scale_factor(0.35)  # nm^3: large enough that some attempts are rejected
+    assert baro.get_volume_scale_factor() == 0.35 and baro.get_adaptive_scaling() is False and baro.get_interval() == 1
+
+    def energy(x, box):
+        return sum(bp.execute(x, box, False, True)[1] for bp in eval_bps)
+
+    x, box = s.coords.copy(), s.box.copy()
+    n_accept = 0
+    for attempt in range(8):
+        u1, u2 = ob.attempt_uniforms(seed, attempt)
+        x_prop, box_prop, (vol, delta, scale) = ob.propose(x, box, groups, 0.35, u1)
+        ok, w = ob.accept(energy(x, box), energy(x_prop, box_prop), vol, delta, len(groups), T, pressure, u2)
+        x_new, box_new = baro.move(x, box)
+        if abs(w) > 1e-2 * 2.5:  # decisions within rounding distance of the threshold are not compared
+            assert ok == (not np.array_equal(box_new, box)), (attempt, ok, w)
+        if not np.array_equal(box_new, box):
+            n_accept += 1
+            np.testing.assert_allclose(box_new, box_prop, rtol=1e-6)
+            np.testing.assert_allclose(x_new, x_prop, rtol=0, atol=2e-5)
+            for g in groups[:50] + groups[-1:]:  # molecules move rigidly
+                d_old = x[g][:, None, :] - x[g][None, :, :]
+                d_new = x_new[g][:, None, :] - x_new[g][None, :, :]
+                np.testing.assert_allclose(d_new, d_old, rtol=0, atol=1e-12)
+            cent = np.array([x_new[g].mean(0) for g in groups])
+            assert np.all(cent >= -1e-5) and np.all(cent <= np.diagonal(box_new) + 1e-5)  # centroids in the home box
+        else:
+            np.testing.assert_array_equal(x_new, x)
+        x, box = x_new, box_new
+    assert 0 < n_accept < 8, n_accept
+    assert sum(baro.get_counters()) > 0
+
+    # interval semantics (mover.hpp:23-40): acts on every 3rd call counted from set_interval
+    baro.set_interval(3)
+    moved = []
+    for _ in range(6):
+        x_new, box_new = baro.move(x, box)
+        moved.append(not np.array_equal(x_new, x) or not np.array_equal(box_new, box))
+    assert moved[0] is False and moved[1] is False and moved[3] is False and moved[4] is False
+    with pytest.raises(RuntimeError, match="interval must be greater than 0"):
+        baro.set_interval(0)
+    with pytest.raises(RuntimeError, match="step must be at least 0"):
+        baro.set_step(-1)
+    with pytest.raises(RuntimeError, match="All grouped indices must be unique"):
+        MonteCarloBarostat(N, 1.0, T, [[0, 1], [1, 2]], 1, 1).impl(bps)
+    with pytest.raises(RuntimeError, match="Grouped indices must be between 0 and N"):
+        MonteCarloBarostat(N, 1.0, T, [[0, N]], 1, 1).impl(bps)
+    # adaptive scaling: 0 means "1 % of the volume" on the first attempt
+    adaptive = MonteCarloBarostat(N, pressure, T, groups, 1, seed).impl(bps)
+    assert adaptive.get_adaptive_scaling() is True and adaptive.get_volume_scale_factor() == 0.0
+    adaptive.move(x, box)
+    np.testing.assert_allclose(adaptive.get_volume_scale_factor(), 0.01 * np.prod(np.diagonal(box)), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_npt_context_runs_with_barostat(co, P):
+    """Context with a barostat mover (fe/free_energy.py:695-708 shape): box fluctuates, density stays liquid-like,
+    get_barostat() finds the mover, adaptive scaling settles between 25 % and 75 % acceptance."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s = ts.small_solvated_ligand()  # liquid density: ~770 waters + a 20-atom ligand in 2.85 nm
+    N = s.num_atoms
+    groups = [list(range(3 * k, 3 * k + 3)) for k in range((N - 20) // 3)] + [list(range(N - 20, N))]
+    assert sum(len(g) for g in groups) == N
+    bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+    baro = MonteCarloBarostat(N, 1.0, 300.0, groups, 5, 7).impl(bps)
+    # relax the synthetic lattice start at constant volume first (it is far from equilibrium: the barostat would
+    # spend the whole test expanding the box)
+    nvt = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, s.masses, 1).impl(), bps)
+    nvt.multiple_steps(1500, 0)
+    ctxt = co.Context(nvt.get_x_t(), nvt.get_v_t(), s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 3).impl(), bps, movers=[baro])
+    assert ctxt.get_barostat() is baro and ctxt.get_movers() == [baro]
+    xs, boxes = ctxt.multiple_steps(600, 100)
+    vols = np.prod(np.diagonal(boxes, axis1=1, axis2=2), axis=1)
+    v0 = np.prod(np.diagonal(s.box))
+    assert np.all(np.isfinite(xs)) and len(np.unique(vols)) > 1
+    assert np.all(np.abs(vols / v0 - 1) < 0.25), vols / v0  # a sanity bound, not an equation of state
+    assert baro.get_volume_scale_factor() > 0
+
+
+@pytest.mark.gpu
 def test_velocity_verlet_matches_device_model_and_reverses(co, P):
     """VelocityVerletIntegrator: multiple_steps == initialize + (n-1) steps + finalize of the device
     model with the GPU's own fixed-point forces; time reversal returns to the start (tests/test_velocity_verlet_integrator.py)."""

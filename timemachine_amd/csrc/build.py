@@ -15,9 +15,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtimemachine_amd.so")
-SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "integrator.hip", "potential.hip", "c_api.cpp"]
+SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "potential.hip", "c_api.cpp"]
 HEADERS = [
-    "common.hpp", "engine.hpp", "fixed_point.cuh", "nb_pair.cuh", "kernels_nonbonded.cuh", "kernels_nblist.cuh", "kernels_bonded.cuh", "nb_math.cuh", "nb_math_coeffs.h",
+    "common.hpp", "engine.hpp", "fixed_point.cuh", "nb_pair.cuh", "kernels_nonbonded.cuh", "kernels_nblist.cuh", "kernels_bonded.cuh", "philox.cuh", "nb_math.cuh", "nb_math_coeffs.h",
     "profiler.hpp", "../../include/timemachine_amd.h",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -23,6 +23,9 @@ struct tm_integrator_s {
 struct tm_context_s {
     std::unique_ptr<Context> p;
 };
+struct tm_mover_s {
+    std::shared_ptr<Mover> p;
+};
 struct tm_neighborlist_s {
     int precision;
     std::unique_ptr<Neighborlist<float>> f32;
@@ -452,6 +455,102 @@ int tm_context_create(
         v.push_back(bps[i]->p);
     std::vector<std::shared_ptr<Mover>> movers;
     *out = new tm_context_s{std::make_unique<Context>(N, x0, v0, box, intg->p, v, movers)};
+    TM_CATCH
+}
+
+int tm_context_create_with_movers(
+    const double *x0, const double *v0, const double *box, int N, tm_integrator_t intg, const tm_bound_potential_t *bps, int num_bps,
+    const tm_mover_t *movers, int num_movers, tm_context_t *out) {
+    TM_TRY
+    std::vector<std::shared_ptr<BoundPotential>> v;
+    for (int i = 0; i < num_bps; i++)
+        v.push_back(bps[i]->p);
+    std::vector<std::shared_ptr<Mover>> mv;
+    for (int i = 0; i < num_movers; i++)
+        mv.push_back(movers[i]->p);
+    *out = new tm_context_s{std::make_unique<Context>(N, x0, v0, box, intg->p, v, mv)};
+    TM_CATCH
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static MonteCarloBarostat<float> &as_barostat(tm_mover_t m) {
+    auto b = std::dynamic_pointer_cast<MonteCarloBarostat<float>>(m->p);
+    if (!b) {
+        throw std::runtime_error("unable to cast mover to MonteCarloBarostat");
+    }
+    return *b;
+}
+
+int tm_monte_carlo_barostat_create(
+    int N, double pressure, double temperature, const int32_t *group_atom_idxs, const int32_t *group_offsets, int num_groups,
+    int interval, const tm_bound_potential_t *bps, int num_bps, int seed, int adaptive_scaling_enabled,
+    double initial_volume_scale_factor, tm_mover_t *out) {
+    TM_TRY
+    std::vector<std::vector<int>> groups(num_groups);
+    for (int g = 0; g < num_groups; g++) {
+        groups[g].assign(group_atom_idxs + group_offsets[g], group_atom_idxs + group_offsets[g + 1]);
+    }
+    std::vector<std::shared_ptr<BoundPotential>> v;
+    for (int i = 0; i < num_bps; i++)
+        v.push_back(bps[i]->p);
+    *out = new tm_mover_s{std::make_shared<MonteCarloBarostat<float>>(
+        N, pressure, temperature, groups, interval, v, seed, adaptive_scaling_enabled != 0, initial_volume_scale_factor)};
+    TM_CATCH
+}
+
+int tm_mover_destroy(tm_mover_t m) {
+    TM_TRY
+    delete m;
+    TM_CATCH
+}
+int tm_mover_set_interval(tm_mover_t m, int interval) {
+    TM_TRY
+    m->p->set_interval(interval);
+    TM_CATCH
+}
+int tm_mover_get_interval(tm_mover_t m, int *interval) {
+    TM_TRY
+    *interval = m->p->get_interval();
+    TM_CATCH
+}
+int tm_mover_set_step(tm_mover_t m, int step) {
+    TM_TRY
+    m->p->set_step(step);
+    TM_CATCH
+}
+int tm_mover_move(tm_mover_t m, int N, const double *x, const double *box, double *x_out, double *box_out) {
+    TM_TRY
+    m->p->move_host(N, x, box, x_out, box_out);
+    TM_CATCH
+}
+int tm_barostat_set_volume_scale_factor(tm_mover_t m, double f) {
+    TM_TRY
+    as_barostat(m).set_volume_scale_factor(f);
+    TM_CATCH
+}
+int tm_barostat_get_volume_scale_factor(tm_mover_t m, double *f) {
+    TM_TRY
+    *f = as_barostat(m).get_volume_scale_factor();
+    TM_CATCH
+}
+int tm_barostat_set_adaptive_scaling(tm_mover_t m, int enabled) {
+    TM_TRY
+    as_barostat(m).set_adaptive_scaling(enabled != 0);
+    TM_CATCH
+}
+int tm_barostat_get_adaptive_scaling(tm_mover_t m, int *enabled) {
+    TM_TRY
+    *enabled = as_barostat(m).get_adaptive_scaling() ? 1 : 0;
+    TM_CATCH
+}
+int tm_barostat_set_pressure(tm_mover_t m, double pressure) {
+    TM_TRY
+    as_barostat(m).set_pressure(pressure);
+    TM_CATCH
+}
+int tm_barostat_get_counters(tm_mover_t m, int *accepted, int *attempted) {
+    TM_TRY
+    as_barostat(m).get_counters(accepted, attempted);
     TM_CATCH
 }
 

@@ -484,17 +484,61 @@ private:
     void forces_then_update(const int mode, std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream);
 };
 
-// reference: cpp/src/mover.hpp (interface only; no movers are implemented on this path yet)
+// reference: cpp/src/mover.{hpp,cu}
 class Mover {
 public:
     virtual ~Mover() {}
     virtual void move(const int N, double *d_x, double *d_box, hipStream_t stream) = 0;
-    void set_interval(const int interval) { interval_ = interval; step_ = 0; }
+    void move_host(const int N, const double *h_x, const double *h_box, double *h_x_out, double *h_box_out);
+    void set_interval(const int interval) {
+        if (interval <= 0) {
+            throw std::runtime_error("interval must be greater than 0");
+        }
+        interval_ = interval;
+        step_ = 0; // in `interval` steps from now the mover triggers
+    }
     int get_interval() const { return interval_; }
-    void set_step(const int step) { step_ = step; }
+    void set_step(const int step) {
+        if (step < 0) {
+            throw std::runtime_error("step must be at least 0");
+        }
+        step_ = step;
+    }
 protected:
-    int interval_ = 1;
-    int step_ = 0;
+    explicit Mover(const int interval) : interval_(interval), step_(0) {}
+    int interval_;
+    int step_;
+};
+
+// reference: cpp/src/barostat.{hpp,cu}, kernels/k_barostat.cuh.  Molecular-scaling Monte Carlo barostat: every
+// `interval`-th call proposes a volume change, moves every molecule's centroid with the box, evaluates the bound
+// potentials' energy before / after (two energy-only force-field evaluations) and accepts by Metropolis.
+// Everything stays on the device; the two uniforms of an attempt come from Philox4x32-10 keyed on (seed; attempt).
+template <typename Real> class MonteCarloBarostat : public Mover {
+public:
+    MonteCarloBarostat(const int N, const double pressure, const double temperature, const std::vector<std::vector<int>> &group_idxs, const int interval, const std::vector<std::shared_ptr<BoundPotential>> &bps, const int seed, const bool adaptive_scaling_enabled, const double initial_volume_scale_factor);
+    void move(const int N, double *d_x, double *d_box, hipStream_t stream) override;
+    double get_volume_scale_factor();
+    void set_volume_scale_factor(const double volume_scale_factor);
+    bool get_adaptive_scaling() const { return adaptive_; }
+    void set_adaptive_scaling(const bool enabled) { adaptive_ = enabled; }
+    void set_pressure(const double pressure);
+    // diagnostics used by the parity tests: (accepted, attempted) counters and the uniforms of attempt k
+    void get_counters(int *accepted, int *attempted);
+private:
+    const int N_;
+    bool adaptive_;
+    std::vector<std::shared_ptr<BoundPotential>> bps_;
+    Real pressure_, temperature_;
+    const unsigned long long seed_;
+    int num_mols_, num_grouped_atoms_;
+    unsigned long long attempt_;
+    DeviceBuffer<double> d_x_proposed_, d_box_proposed_, d_volume_scale_;
+    DeviceBuffer<Real> d_move_; // {volume, volume_delta, length_scale, u2}
+    DeviceBuffer<i128> d_u_buffer_, d_u_init_, d_u_final_;
+    DeviceBuffer<u64> d_centroids_;
+    DeviceBuffer<int> d_atom_idxs_, d_mol_idxs_, d_mol_offsets_, d_counters_;
+    void reset_counters();
 };
 
 // reference: cpp/src/context.{hpp,cu}

@@ -1,5 +1,6 @@
 """Thin dataclasses whose ``.impl()`` constructs ``custom_ops`` objects (reference: timemachine/lib/__init__.py:12-62)."""
 from dataclasses import dataclass, field
+from typing import Any, Optional
 
 import numpy as np
 from numpy.typing import NDArray
@@ -37,3 +38,30 @@ class VelocityVerletIntegrator:
 
     def impl(self):
         return custom_ops.VelocityVerletIntegrator(self.dt, self.cbs)
+
+
+@dataclass
+class MonteCarloBarostat:
+    """reference: timemachine/lib/__init__.py:40-62 (same fields; impl(bound_potentials) takes custom_ops.BoundPotential objects)."""
+
+    N: int
+    pressure: float
+    temperature: float
+    group_idxs: Any
+    interval: int
+    seed: int
+    adaptive_scaling_enabled: bool = True
+    initial_volume_scale_factor: Optional[float] = None
+
+    def impl(self, bound_potentials):
+        return custom_ops.MonteCarloBarostat(
+            self.N,
+            self.pressure,
+            self.temperature,
+            self.group_idxs,
+            self.interval,
+            bound_potentials,
+            self.seed,
+            self.adaptive_scaling_enabled,
+            self.initial_volume_scale_factor or 0.0,  # 0.0 means "1 % of the initial box volume"
+        )

@@ -576,7 +576,79 @@ class VelocityVerletIntegrator(Integrator):
 
 
 class Mover:
-    """Interface placeholder (wrap_kernels.cpp:1591-1617); no movers are implemented on this path yet."""
+    """Mover base (wrap_kernels.cpp:1591-1617): set_interval / get_interval / set_step / move(coords, box)."""
+
+    _h = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and _lib is not None:
+            _lib.tm_mover_destroy(h)
+
+    def set_interval(self, interval):
+        _check(_lib.tm_mover_set_interval(self._h, _c_int(int(interval))))
+
+    def get_interval(self):
+        n = _c_int(0)
+        _check(_lib.tm_mover_get_interval(self._h, ctypes.byref(n)))
+        return n.value
+
+    def set_step(self, step):
+        _check(_lib.tm_mover_set_step(self._h, _c_int(int(step))))
+
+    def move(self, coords, box):
+        """-> (coords[N,3], box[3,3]) after one call of the mover (it acts on every interval-th call)."""
+        c, b = _f64(coords, "coords"), _f64(box, "box")
+        _verify_coords_and_box(c, b)
+        x_out, box_out = np.empty_like(c), np.empty_like(b)
+        _check(_lib.tm_mover_move(self._h, _c_int(c.shape[0]), _ptr(c), _ptr(b), _ptr(x_out), _ptr(box_out)))
+        return x_out, box_out
+
+
+class MonteCarloBarostat(Mover):
+    """MonteCarloBarostat(N, pressure [bar], temperature [K], group_idxs, interval, bps, seed, adaptive_scaling_enabled,
+    initial_volume_scale_factor); wrap_kernels.cpp:1619-1659 (<float> arithmetic)."""
+
+    def __init__(self, N, pressure, temperature, group_idxs, interval, bps, seed, adaptive_scaling_enabled, initial_volume_scale_factor):
+        groups = [np.asarray(g, dtype=np.int32).reshape(-1) for g in group_idxs]
+        flat = np.ascontiguousarray(np.concatenate(groups) if groups else np.zeros(0, np.int32), dtype=np.int32)
+        offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(g) for g in groups])]), dtype=np.int32)
+        bps = list(bps)
+        for bp in bps:
+            if not isinstance(bp, BoundPotential):
+                raise TypeError("bps must be custom_ops.BoundPotential instances")
+        self._bps = bps  # the barostat evaluates them: keep them alive
+        arr = (_vp * len(bps))(*[bp._h.value for bp in bps])
+        self._h = _vp()
+        _check(_lib.tm_monte_carlo_barostat_create(
+            _c_int(int(N)), _c_double(pressure), _c_double(temperature), _ptr(flat), _ptr(offsets), _c_int(len(groups)),
+            _c_int(int(interval)), arr, _c_int(len(bps)), _c_int(int(seed)), _c_int(1 if adaptive_scaling_enabled else 0),
+            _c_double(initial_volume_scale_factor), ctypes.byref(self._h)))
+
+    def set_volume_scale_factor(self, volume_scale_factor):
+        _check(_lib.tm_barostat_set_volume_scale_factor(self._h, _c_double(volume_scale_factor)))
+
+    def get_volume_scale_factor(self):
+        f = _c_double(0)
+        _check(_lib.tm_barostat_get_volume_scale_factor(self._h, ctypes.byref(f)))
+        return f.value
+
+    def set_adaptive_scaling(self, adaptive_scaling_enabled):
+        _check(_lib.tm_barostat_set_adaptive_scaling(self._h, _c_int(1 if adaptive_scaling_enabled else 0)))
+
+    def get_adaptive_scaling(self):
+        n = _c_int(0)
+        _check(_lib.tm_barostat_get_adaptive_scaling(self._h, ctypes.byref(n)))
+        return bool(n.value)
+
+    def set_pressure(self, pressure):
+        _check(_lib.tm_barostat_set_pressure(self._h, _c_double(pressure)))
+
+    def get_counters(self):
+        """(accepted, attempted) since the last adaptive reset -- diagnostic, not in the reference surface"""
+        a, b = _c_int(0), _c_int(0)
+        _check(_lib.tm_barostat_get_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
 
 class Context:
@@ -589,19 +661,24 @@ class Context:
             raise RuntimeError("v0 N != x0 N")
         if v0.ndim != 2 or x0.shape[1] != v0.shape[1]:
             raise RuntimeError("v0 D != x0 D")
-        if movers:
-            raise NotImplementedError("movers (barostat, exchange moves) are outside the MI355X hot path for now")
+        movers = list(movers) if movers else []
+        for mv in movers:
+            if not isinstance(mv, Mover):
+                raise TypeError("movers must be custom_ops.Mover instances")
         if not isinstance(integrator, Integrator):
             raise TypeError("integrator must be a custom_ops.Integrator")
         bps = list(bps)
         for bp in bps:
             if not isinstance(bp, BoundPotential):
                 raise TypeError("bps must be custom_ops.BoundPotential instances")
-        self._integrator, self._bps, self._movers = integrator, bps, []
+        self._integrator, self._bps, self._movers = integrator, bps, movers
         self._N = x0.shape[0]
         arr = (_vp * len(bps))(*[bp._h.value for bp in bps])
+        marr = (_vp * max(len(movers), 1))(*[mv._h.value for mv in movers])
         self._h = _vp()
-        _check(_lib.tm_context_create(_ptr(x0), _ptr(v0), _ptr(box), _c_int(self._N), integrator._h, arr, _c_int(len(bps)), ctypes.byref(self._h)))
+        _check(_lib.tm_context_create_with_movers(
+            _ptr(x0), _ptr(v0), _ptr(box), _c_int(self._N), integrator._h, arr, _c_int(len(bps)), marr, _c_int(len(movers)),
+            ctypes.byref(self._h)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -672,6 +749,10 @@ class Context:
         return list(self._movers)
 
     def get_barostat(self):
+        """The first MonteCarloBarostat among the movers, else None (wrap_kernels.cpp:671-680; context.cu:311-319)."""
+        for mv in self._movers:
+            if isinstance(mv, MonteCarloBarostat):
+                return mv
         return None
 
 
@@ -798,7 +879,7 @@ def _not_on_hot_path(name):
 
 for _name in (
     "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
-    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "MonteCarloBarostat", "BDExchangeMove_f32",
+    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "BDExchangeMove_f32",
     "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
 ):
     globals()[_name] = _not_on_hot_path(_name)
