@@ -5,8 +5,9 @@
 // known ranges (x = beta*d in [0, ~3], switch angle in [0, pi/2]), so fixed-degree polynomials evaluated with explicit
 // FMAs do the same job in ~90 instructions with no divergence and a fixed, reproducible instruction sequence
 // (the exclusion kernel must reproduce the tile kernel's bits).  Coefficients: tools/gen_math_coeffs.py (Chebyshev
-// interpolation at 60 digits); degrees chosen as the lowest with every piece <= 1e-13 relative (erfcx 8.5e-14, exp 4e-16,
-// sin / cos 3e-16; the script reports them) -- five orders of magnitude inside the 1e-8 contract on forces.
+// interpolation at 60 digits); degrees chosen so that every piece stays <= 3e-11 (erfcx 1.7e-11 relative, exp 1.1e-12,
+// sin 2.7e-11 / cos 7.5e-13 absolute; the script reports them) -- more than two orders of magnitude inside the 1e-8
+// contract on forces, and below the 4e-11 the rest of the f64 arithmetic (rsqrt Newton steps, summation order) leaves.
 #pragma once
 #include "nb_math_coeffs.h"
 
@@ -112,7 +113,7 @@ __device__ __forceinline__ double tm_exp_neg_f64(double t) {
     return __builtin_amdgcn_ldexp(p, static_cast<int>(n));
 }
 
-// exp(x^2) erfc(x) for x >= 0; accurate to 8.5e-14 on [0, 6]; for x > 6 the argument is clamped (erfc(6) = 2e-17: the
+// exp(x^2) erfc(x) for x >= 0; accurate to 1.7e-11 on [0, 6]; for x > 6 the argument is clamped (erfc(6) = 2e-17: the
 // product with exp(-x^2) is below 1e-17 in absolute terms whatever this returns there)
 __device__ __forceinline__ double tm_erfcx_f64(double x) {
     const double xc = x < 6.0 ? x : 6.0;
