@@ -113,7 +113,7 @@ static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB o
 static const int NBL_THREADS = TM_NBL_THREADS; // 16 waves per row block: the per-row-block critical path is what bounds this kernel
 
 template <typename Real, bool UPPER_TRIANGULAR>
-__global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
+__global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SIMD = 2 workgroups per CU: the register budget is 64
     const int K, const int NC, const int NR, const unsigned int *__restrict__ col_idxs, const unsigned int *__restrict__ row_idxs,
     const Real *__restrict__ col_ctr, const Real *__restrict__ col_ext, const Real *__restrict__ row_ctr,
     const Real *__restrict__ row_ext, const Real *__restrict__ gathered, const double *__restrict__ box, const double cutoff_d,
@@ -135,6 +135,14 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int rb = blockIdx.x;
+#ifdef TM_NBL_TIMING
+    unsigned long long tm_t[8];
+    int tm_n = 0;
+#define TM_NBL_STAMP() do { __syncthreads(); tm_t[tm_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TM_NBL_STAMP() do { } while (0)
+#endif
+    TM_NBL_STAMP();
     const int n_col_blocks = (NC + TILE - 1) / TILE;
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
@@ -183,6 +191,30 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         UPPER_TRIANGULAR ? static_cast<unsigned int>(rb) * ncp - static_cast<unsigned int>(TILE) * (static_cast<unsigned int>(rb) * (rb - 1) / 2)
                          : static_cast<unsigned int>(rb) * ncp;
 
+    // f32 copies of the row atoms relative to the first one (resolution independent of coordinate drift): the fine pass
+    // and the cost estimate run on these; only distances within rounding reach of the cutoff are re-tested in Real
+    const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
+    const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
+    const Real ox = s_rx[0], oy = s_ry[0], oz = s_rz[0];
+    if (tid < TILE) {
+        const bool valid = tid < nrow;
+        s_rf[0][tid] = valid ? static_cast<float>(min_image(s_rx[tid] - ox, bx.x, bx.inv_x)) : 0.0f;
+        s_rf[1][tid] = valid ? static_cast<float>(min_image(s_ry[tid] - oy, bx.y, bx.inv_y)) : 0.0f;
+        s_rf[2][tid] = valid ? static_cast<float>(min_image(s_rz[tid] - oz, bx.z, bx.inv_z)) : 0.0f;
+    }
+    __syncthreads();
+    // largest |row - origin| per dimension (every wave computes it for itself)
+    float rmx = lane < TILE ? fabsf(s_rf[0][lane]) : 0.0f, rmy = lane < TILE ? fabsf(s_rf[1][lane]) : 0.0f,
+          rmz = lane < TILE ? fabsf(s_rf[2][lane]) : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rmx = fmaxf(rmx, __shfl_xor(rmx, o, 64));
+        rmy = fmaxf(rmy, __shfl_xor(rmy, o, 64));
+        rmz = fmaxf(rmz, __shfl_xor(rmz, o, 64));
+    }
+    const float fcut2 = static_cast<float>(cutoff_d * cutoff_d);
+    const float fmargin = 2e-5f * (1.0f + fcut2); // >> the f32 rounding error of a squared distance of this size
+    TM_NBL_STAMP(); // rows loaded
     for (int chunk0 = cb_first; chunk0 < n_col_blocks; chunk0 += NBL_CHUNK) {
         // ---- pass 1: compact the passing column blocks of this chunk into s_list
         if (tid == 0) {
@@ -211,6 +243,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
 #if defined(TM_NBL_ABL) && TM_NBL_ABL == 4
         if (nlist >= 0) { continue; } // ablation: coarse passes only
 #endif
+        TM_NBL_STAMP(); // coarse list ready
         // ---- pass 2: two column blocks per wave iteration
         const int half_id = lane >> 5; // 0: lanes 0-31, 1: lanes 32-63
         const int sub = lane & 31;
@@ -257,14 +290,66 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
 #if defined(TM_NBL_ABL) && TM_NBL_ABL == 2
             interacts = live; // ablation: no fine pass (every atom of a passing column block is listed)
 #endif
-            while (__ballot(rows != 0 && live && !interacts)) {
-                if (rows != 0) {
-                    const int i = __builtin_ctz(rows);
-                    rows &= rows - 1;
-                    const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
-                    const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
-                    const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
-                    interacts = interacts || (live && (dx * dx + dy * dy + dz * dz) < cutoff2);
+            // f32 distances on origin-relative coordinates decide everything that is not within rounding reach of the
+            // cutoff; those few, and column atoms so far from the origin that row - col could need re-imaging, take the
+            // exact test in Real (so the listed set equals the brute-force Real set, tests/test_nblist.py:180-186)
+            const float cfx = static_cast<float>(min_image(xj - ox, bx.x, bx.inv_x));
+            const float cfy = static_cast<float>(min_image(yj - oy, bx.y, bx.inv_y));
+            const float cfz = static_cast<float>(min_image(zj - oz, bx.z, bx.inv_z));
+            const bool no_wrap = (fabsf(cfx) + rmx) * fibx < 0.49f && (fabsf(cfy) + rmy) * fiby < 0.49f && (fabsf(cfz) + rmz) * fibz < 0.49f;
+            if constexpr (sizeof(Real) == 4) {
+                // f32 lists: the exact test IS an f32 test; one row per trip measured fastest (78 vs 60 us per build)
+                while (__ballot(rows != 0 && live && !interacts)) {
+                    if (rows != 0) {
+                        const int i = __builtin_ctz(rows);
+                        rows &= rows - 1;
+                        const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
+                        const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
+                        const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
+                        interacts = interacts || (live && (dx * dx + dy * dy + dz * dz) < cutoff2);
+                    }
+                }
+            } else {
+                // Four rows per trip: the trip itself is a latency chain (LDS read -> distance -> compare -> ballot -> branch,
+                // ~200 cycles) and the whole wave waits for its slowest lane, so the number of trips is what costs.
+                while (__ballot(rows != 0 && live && !interacts)) {
+                    bool exact_needed = false;
+                    int ix[4] = {0, 0, 0, 0};
+                    bool borderline[4] = {false, false, false, false};
+                    if (rows != 0 && live && !interacts) {
+                        bool have[4];
+    #pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            have[q] = rows != 0;
+                            ix[q] = have[q] ? __builtin_ctz(rows) : 0;
+                            rows = have[q] ? (rows & (rows - 1)) : 0u;
+                        }
+                        float d2[4];
+    #pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float dx = s_rf[0][ix[q]] - cfx, dy = s_rf[1][ix[q]] - cfy, dz = s_rf[2][ix[q]] - cfz;
+                            d2[q] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        }
+    #pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            interacts = interacts || (have[q] && no_wrap && d2[q] < fcut2 - fmargin);
+                            borderline[q] = have[q] && (!no_wrap || (d2[q] >= fcut2 - fmargin && d2[q] < fcut2 + fmargin));
+                        }
+                        exact_needed = !interacts && (borderline[0] || borderline[1] || borderline[2] || borderline[3]);
+                    }
+                    if (__ballot(exact_needed)) {
+                        if (exact_needed) {
+    #pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (borderline[q]) {
+                                    const Real dx = min_image(s_rx[ix[q]] - xj, bx.x, bx.inv_x);
+                                    const Real dy = min_image(s_ry[ix[q]] - yj, bx.y, bx.inv_y);
+                                    const Real dz = min_image(s_rz[ix[q]] - zj, bx.z, bx.inv_z);
+                                    interacts = interacts || (dx * dx + dy * dy + dz * dz) < cutoff2;
+                                }
+                            }
+                        }
+                    }
                 }
             }
             const u64 hits = __ballot(interacts);
@@ -285,6 +370,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
 #if defined(TM_NBL_ABL) && TM_NBL_ABL >= 3
     if (tid >= 0) { return; } // ablation: nothing published
 #endif
+    TM_NBL_STAMP(); // pass 2 done
     // ---- publish the segment and its work items
     // Every item gets a cost estimate -- the number of (row, column) pairs inside `cost_cutoff` -- and is filed into
     // bucket (shard = row block % NB_SHARDS, cost class), class 0 = heaviest.  The tile kernel deals the buckets to its
@@ -307,16 +393,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         s_hist[tid] = 0;
     }
     // the estimate runs in f32 on coordinates relative to the first row atom
-    const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
-    const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
     const float cost_cutoff2 = static_cast<float>(cost_cutoff_d * cost_cutoff_d);
-    const Real ox = s_rx[0], oy = s_ry[0], oz = s_rz[0];
-    if (tid < TILE) {
-        s_rf[0][tid] = static_cast<float>(min_image(s_rx[tid] - ox, bx.x, bx.inv_x));
-        s_rf[1][tid] = static_cast<float>(min_image(s_ry[tid] - oy, bx.y, bx.inv_y));
-        s_rf[2][tid] = static_cast<float>(min_image(s_rz[tid] - oz, bx.z, bx.inv_z));
-    }
-    __syncthreads();
     for (unsigned int c = wave; c < n_chunks; c += NBL_THREADS / 64) {
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
@@ -365,6 +442,7 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
             }
         }
     }
+    TM_NBL_STAMP(); // costs done
     __syncthreads();
     if (tid < NB_CLASSES && s_hist[tid] != 0) {
         s_base[tid] = atomicAdd(&counters[NB_COUNTER_CLASS0 + shard * NB_CLASSES + tid], s_hist[tid]);
@@ -378,6 +456,13 @@ __global__ __launch_bounds__(NBL_THREADS) void k_find_ixns(
         items[static_cast<size_t>(shard * NB_CLASSES + cls) * items_cap + s_base[cls] + pos] =
             make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
     }
+#ifdef TM_NBL_TIMING
+    TM_NBL_STAMP();
+    if (tid == 0 && (rb % 97) == 0) {
+        printf("rb %d nlist %d count %u: rows %llu coarse %llu pass2 %llu cost %llu publish %llu (10 ns ticks), start %llu\n", rb, static_cast<int>(s_nlist), count,
+               tm_t[1] - tm_t[0], tm_t[2] - tm_t[1], tm_t[3] - tm_t[2], tm_t[4] - tm_t[3], tm_t[5] - tm_t[4], tm_t[0] % 1000000ull);
+    }
+#endif
 }
 
 } // namespace tmamd
