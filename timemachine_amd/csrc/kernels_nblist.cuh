@@ -315,33 +315,31 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                 while (__ballot(rows != 0 && live && !interacts)) {
                     bool exact_needed = false;
                     int ix[4] = {0, 0, 0, 0};
-                    bool borderline[4] = {false, false, false, false};
+                    bool have[4] = {false, false, false, false};
                     if (rows != 0 && live && !interacts) {
-                        bool have[4];
-    #pragma unroll
+#pragma unroll
                         for (int q = 0; q < 4; q++) {
                             have[q] = rows != 0;
                             ix[q] = have[q] ? __builtin_ctz(rows) : 0;
                             rows = have[q] ? (rows & (rows - 1)) : 0u;
                         }
-                        float d2[4];
-    #pragma unroll
+                        float dmin = 1e30f; // smallest f32 squared distance among this trip's rows
+#pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const float dx = s_rf[0][ix[q]] - cfx, dy = s_rf[1][ix[q]] - cfy, dz = s_rf[2][ix[q]] - cfz;
-                            d2[q] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                            dmin = fminf(dmin, have[q] ? d2 : 1e30f);
                         }
-    #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            interacts = interacts || (have[q] && no_wrap && d2[q] < fcut2 - fmargin);
-                            borderline[q] = have[q] && (!no_wrap || (d2[q] >= fcut2 - fmargin && d2[q] < fcut2 + fmargin));
-                        }
-                        exact_needed = !interacts && (borderline[0] || borderline[1] || borderline[2] || borderline[3]);
+                        interacts = no_wrap && dmin < fcut2 - fmargin;
+                        // nothing decided yet and something within rounding reach of the cutoff (or re-imaging possible):
+                        // the trip's rows take the exact test
+                        exact_needed = !interacts && (!no_wrap || dmin < fcut2 + fmargin);
                     }
                     if (__ballot(exact_needed)) {
                         if (exact_needed) {
-    #pragma unroll
+#pragma unroll
                             for (int q = 0; q < 4; q++) {
-                                if (borderline[q]) {
+                                if (have[q]) {
                                     const Real dx = min_image(s_rx[ix[q]] - xj, bx.x, bx.inv_x);
                                     const Real dy = min_image(s_ry[ix[q]] - yj, bx.y, bx.inv_y);
                                     const Real dz = min_image(s_rz[ix[q]] - zj, bx.z, bx.inv_z);
