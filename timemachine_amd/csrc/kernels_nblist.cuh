@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) void k_block_bounds(
 //           (k_neighborlist.cuh:349-365), here with one (row atom, column block) test per lane and two 32-bit row masks;
 //           every lane then walks only the set bits of its half's mask, and the wave leaves as soon as all of its
 //           lanes have found a partner.
+#ifndef TM_NBL_TRIP
+#define TM_NBL_TRIP 4
+#endif
+static const int NBL_TRIP = TM_NBL_TRIP; // rows tested per trip of the fine pass
 static const int NBL_COST_STRIDE = 4; // cost estimates sample every 4th row (lane-staggered start)
 static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
 #ifndef TM_NBL_THREADS
@@ -297,35 +301,28 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
             const float cfy = static_cast<float>(min_image(yj - oy, bx.y, bx.inv_y));
             const float cfz = static_cast<float>(min_image(zj - oz, bx.z, bx.inv_z));
             const bool no_wrap = (fabsf(cfx) + rmx) * fibx < 0.49f && (fabsf(cfy) + rmy) * fiby < 0.49f && (fabsf(cfz) + rmz) * fibz < 0.49f;
-            if constexpr (sizeof(Real) == 4) {
-                // f32 lists: the exact test IS an f32 test; one row per trip measured fastest (78 vs 60 us per build)
-                while (__ballot(rows != 0 && live && !interacts)) {
-                    if (rows != 0) {
-                        const int i = __builtin_ctz(rows);
-                        rows &= rows - 1;
-                        const Real dx = min_image(s_rx[i] - xj, bx.x, bx.inv_x);
-                        const Real dy = min_image(s_ry[i] - yj, bx.y, bx.inv_y);
-                        const Real dz = min_image(s_rz[i] - zj, bx.z, bx.inv_z);
-                        interacts = interacts || (live && (dx * dx + dy * dy + dz * dz) < cutoff2);
-                    }
-                }
-            } else {
-                // Four rows per trip: the trip itself is a latency chain (LDS read -> distance -> compare -> ballot -> branch,
+            {
+                // NBL_TRIP rows per trip: the trip itself is a latency chain (LDS read -> distance -> compare -> ballot -> branch,
                 // ~200 cycles) and the whole wave waits for its slowest lane, so the number of trips is what costs.
                 while (__ballot(rows != 0 && live && !interacts)) {
                     bool exact_needed = false;
-                    int ix[4] = {0, 0, 0, 0};
-                    bool have[4] = {false, false, false, false};
+                    int ix[NBL_TRIP];
+                    bool have[NBL_TRIP];
+#pragma unroll
+                    for (int q = 0; q < NBL_TRIP; q++) {
+                        ix[q] = 0;
+                        have[q] = false;
+                    }
                     if (rows != 0 && live && !interacts) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
+                        for (int q = 0; q < NBL_TRIP; q++) {
                             have[q] = rows != 0;
                             ix[q] = have[q] ? __builtin_ctz(rows) : 0;
                             rows = have[q] ? (rows & (rows - 1)) : 0u;
                         }
                         float dmin = 1e30f; // smallest f32 squared distance among this trip's rows
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
+                        for (int q = 0; q < NBL_TRIP; q++) {
                             const float dx = s_rf[0][ix[q]] - cfx, dy = s_rf[1][ix[q]] - cfy, dz = s_rf[2][ix[q]] - cfz;
                             const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                             dmin = fminf(dmin, have[q] ? d2 : 1e30f);
@@ -338,7 +335,7 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                     if (__ballot(exact_needed)) {
                         if (exact_needed) {
 #pragma unroll
-                            for (int q = 0; q < 4; q++) {
+                            for (int q = 0; q < NBL_TRIP; q++) {
                                 if (have[q]) {
                                     const Real dx = min_image(s_rx[ix[q]] - xj, bx.x, bx.inv_x);
                                     const Real dy = min_image(s_ry[ix[q]] - yj, bx.y, bx.inv_y);
