@@ -264,6 +264,54 @@ def test_chiral_restraints_golden(co, P, precision):
 
 
 @pytest.mark.gpu
+def test_hrex_energy_matrix_and_exchange_on_one_gpu(co, P):
+    """BASELINE config 5 shape on one GPU: 6 lambda windows of the solvated-ligand state.  The sparse (replica, state)
+    energy matrix equals the dense execute_batch wherever it is evaluated (fe/free_energy.py:1148-1200); an exchange step
+    re-assigns states, and a replica's Context then runs under its new parameters (states move, coordinates do not)."""
+    from timemachine_amd import hrex
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    n_states = 6
+    lambdas = np.linspace(0.0, 0.5, n_states)
+    systems = [ts.small_solvated_ligand(lamb=float(lam)) for lam in lambdas]
+    s0 = systems[0]
+    params_by_state = np.stack([s.nb_params for s in systems])  # windows differ only in the ligand's nonbonded params
+    assert not np.array_equal(params_by_state[0], params_by_state[-1])
+    nb = P.Nonbonded(s0.num_atoms, s0.exclusion_idxs, s0.scale_factors, s0.beta, s0.cutoff)
+    unbound = nb.to_gpu(np.float32).unbound_impl
+    # one short trajectory per replica so that the replicas differ
+    ctxts, bound_nb = [], []
+    for k in range(n_states):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(systems[k])]
+        bound_nb.append(bps[-1])
+        ctxt = co.Context(s0.coords, np.zeros_like(s0.coords), s0.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s0.masses, 20 + k).impl(), bps)
+        ctxt.multiple_steps(30, 0)
+        ctxts.append(ctxt)
+    coords = np.stack([c.get_x_t() for c in ctxts])
+    boxes = np.stack([c.get_box() for c in ctxts])
+    dh = hrex.DistributedHREX(n_states, 300.0, max_delta_states=1)
+    rows = hrex.compute_potential_matrix(unbound, coords, boxes, params_by_state, dh.replica_idx_by_state, dh.max_delta_states)
+    _, _, dense = unbound.execute_batch(coords, params_by_state, boxes, False, False, True)
+    evaluated = np.isfinite(rows)
+    assert evaluated.sum() == 3 * n_states - 2 and np.all(evaluated[np.arange(n_states), np.arange(n_states)])
+    np.testing.assert_array_equal(rows[evaluated], dense[evaluated])  # same kernels, same integer sums
+    # a rank's share of the rows (replicas 1, 3, 5 of a 2-rank job) is the same numbers
+    mine = [1, 3, 5]
+    part = hrex.compute_potential_matrix(unbound, coords[mine], boxes[mine], params_by_state, dh.replica_idx_by_state, 1, replicas=mine)
+    np.testing.assert_array_equal(part, rows[mine])
+    # exchange, then every replica adopts the parameters of its new state
+    new_states = dh.exchange(rows, seed=5)
+    assert sorted(new_states.tolist()) == list(range(n_states))
+    for r in range(n_states):
+        bound_nb[r].set_params(params_by_state[new_states[r]].reshape(-1))
+        _, u = bound_nb[r].execute(coords[r], boxes[r], False, True)
+        assert u == dense[r, new_states[r]]
+        ctxts[r].multiple_steps(5, 0)
+        assert np.all(np.isfinite(ctxts[r].get_x_t()))
+
+
+@pytest.mark.gpu
 def test_barostat_follows_model_attempt_by_attempt(co, P):
     """MonteCarloBarostat: every attempt's proposal (molecular centroid scaling) and Metropolis
     decision against oracle/barostat.py, fed with the same Philox uniforms and the GPU's own energies.
