@@ -93,6 +93,12 @@ int tm_nonbonded_interaction_group_set_atom_idxs(tm_potential_t pot, const int32
  *                                                                    wrap_kernels.cpp:1353-1364; nonbonded_precomputed.cu:12-87 */
 int tm_nonbonded_pair_list_precomputed_create(int precision, const int32_t *pair_idxs, int num_pairs, double beta, double cutoff,
                                               tm_potential_t *out);
+/* FlatBottomBond_*(bond_idxs int32[B,2]) (log_form = 0) / LogFlatBottomBond_*(bond_idxs, beta) (log_form = 1); params [B,3] =
+ * (k, r_min, r_max)                                 wrap_kernels.cpp:1324-1351; flat_bottom_bond.cu:12-89, log_flat_bottom_bond.cu:12-93 */
+int tm_flat_bottom_bond_create(int precision, int log_form, const int32_t *bond_idxs, int num_bonds, double beta, tm_potential_t *out);
+/* CentroidRestraint_*(group_a_idxs, group_b_idxs, kb, b0); no parameters                wrap_kernels.cpp:1410-1430; centroid_restraint.cu:8-76 */
+int tm_centroid_restraint_create(int precision, const int32_t *group_a_idxs, int num_a, const int32_t *group_b_idxs, int num_b,
+                                 double kb, double b0, tm_potential_t *out);
 /* ChiralAtomRestraint_*(idxs int32[R,4]); params [R]                 wrap_kernels.cpp:1366-1378; chiral_atom_restraint.cu:10-68 */
 int tm_chiral_atom_restraint_create(int precision, const int32_t *idxs, int num_restraints, tm_potential_t *out);
 /* ChiralBondRestraint_*(idxs int32[R,4], signs int32[R]); params [R] wrap_kernels.cpp:1380-1394; chiral_bond_restraint.cu:10-82 */

@@ -271,6 +271,38 @@ def chiral_bond_restraint_energy(conf, params, idxs, signs):
     return torch.where(vol * sgn > 0, params * vol * vol, torch.zeros_like(vol)).sum()
 
 
+def flat_bottom_bond_energies(conf, params, box, bond_idxs):
+    """_flat_bottom_bond_impl (bonded.py:219-232): per-bond (k/4) (r - r_max)^4 / (r - r_min)^4 outside [r_min, r_max]."""
+    bond_idxs = torch.as_tensor(np.asarray(bond_idxs, dtype=np.int64))
+    box_diag = None if box is None else torch.diagonal(box)
+    d = delta_r(conf[bond_idxs[:, 0]], conf[bond_idxs[:, 1]], box_diag)
+    r = torch.sqrt((d * d).sum(-1))
+    k, r_min, r_max = params[:, 0], params[:, 1], params[:, 2]
+    zero = torch.zeros_like(r)
+    return (k / 4) * (torch.where(r > r_max, (r - r_max) ** 4, zero) + torch.where(r < r_min, (r - r_min) ** 4, zero))
+
+
+def flat_bottom_bond_energy(conf, params, box, bond_idxs):
+    return flat_bottom_bond_energies(conf, params, box, bond_idxs).sum()
+
+
+def log_flat_bottom_bond_energy(conf, params, box, bond_idxs, beta):
+    """bonded.py:245-253"""
+    nrgs = flat_bottom_bond_energies(conf, params, box, bond_idxs)
+    return (-torch.log(1 - torch.exp(-beta * nrgs))).sum() / beta
+
+
+def centroid_restraint_energy(conf, group_a_idxs, group_b_idxs, kb, b0):
+    """bonded.py:8-31"""
+    a = torch.as_tensor(np.asarray(group_a_idxs, dtype=np.int64))
+    b = torch.as_tensor(np.asarray(group_b_idxs, dtype=np.int64))
+    dx = conf[a].mean(0) - conf[b].mean(0)
+    d2 = (dx * dx).sum()
+    if b0 == 0:
+        return kb * d2
+    return kb * (torch.sqrt(d2) - b0) ** 2
+
+
 def value_and_grads(energy_fn, conf, params, *args, **kwargs) -> Tuple[float, np.ndarray, np.ndarray]:
     """u, du/dx, du/dp of ``energy_fn(conf, params, *args)`` by autograd (mirrors jax.grad(ref,(0,1)))."""
     x = _t(conf, True)
@@ -344,3 +376,15 @@ def chiral_atom_restraint(conf, params, box, idxs):
 
 def chiral_bond_restraint(conf, params, box, idxs, signs):
     return value_and_grads(lambda x, p: chiral_bond_restraint_energy(x, p, idxs, signs), conf, params)
+
+
+def flat_bottom_bond(conf, params, box, idxs):
+    return value_and_grads(lambda x, p: flat_bottom_bond_energy(x, p, _t(box), idxs), conf, params)
+
+
+def log_flat_bottom_bond(conf, params, box, idxs, beta):
+    return value_and_grads(lambda x, p: log_flat_bottom_bond_energy(x, p, _t(box), idxs, beta), conf, params)
+
+
+def centroid_restraint(conf, params, box, group_a_idxs, group_b_idxs, kb, b0):
+    return value_and_grads(lambda x, p: centroid_restraint_energy(x, group_a_idxs, group_b_idxs, kb, b0), conf, np.zeros(0))

@@ -27,6 +27,7 @@ _tmp = tempfile.mkdtemp(prefix="jaxshim_")
 _jax_numpy_shim.materialise(_tmp)
 sys.path[:0] = [_tmp, REF]
 
+from timemachine.potentials import bonded as ref_bonded  # noqa: E402
 from timemachine.potentials import chiral_restraints as ref_chiral  # noqa: E402
 from timemachine.potentials import nonbonded as ref_nonbonded  # noqa: E402
 
@@ -142,6 +143,40 @@ def main():
     check_fd("chiral bond du_dx", lambda xx: float(ref_chiral.chiral_bond_restraint(xx, b_k, None, b_idxs, b_signs)), xc, gx, rng, h=1e-6, tol=5e-6)
     d.update(chiral_bond_idxs=b_idxs, chiral_bond_signs=b_signs, chiral_bond_params=b_k, chiral_bond_u=u_ref, chiral_bond_du_dx=gx, chiral_bond_du_dp=gp)
     print(f"  chiral bond: u={u_ref:.6f} ({int((gp > 0).sum())} of {R} active)")
+
+    # ---- flat-bottom / log flat-bottom bonds (PBC) and the centroid restraint
+    Bf = 60
+    fb_idxs = np.stack([rng.permutation(m)[:2] for _ in range(Bf)]).astype(np.int32)
+    fb_box = np.eye(3) * 1.2  # smaller than the coordinate spread: minimum-image distances matter
+    fb_p = np.stack([rng.uniform(50, 500, Bf), rng.uniform(0.2, 0.35, Bf), rng.uniform(0.4, 0.6, Bf)], 1)
+    u_ref = float(ref_bonded.flat_bottom_bond(xc, fb_p, fb_box, fb_idxs))
+    u, gx, gp = rp.flat_bottom_bond(xc, fb_p, fb_box, fb_idxs)
+    assert rel(u, u_ref) < 1e-12, (u, u_ref)
+    check_fd("flat bottom du_dx", lambda xx: float(ref_bonded.flat_bottom_bond(xx, fb_p, fb_box, fb_idxs)), xc, gx, rng, h=1e-6, tol=5e-6)
+    check_fd("flat bottom du_dp", lambda pp: float(ref_bonded.flat_bottom_bond(xc, pp, fb_box, fb_idxs)), fb_p, gp, rng, h=1e-6, tol=5e-6)
+    d.update(fb_idxs=fb_idxs, fb_box=fb_box, fb_params=fb_p, fb_u=u_ref, fb_du_dx=gx, fb_du_dp=gp)
+    print(f"  flat bottom: u={u_ref:.6f}")
+    lfb_beta = 0.4
+    # only bonds outside the flat region have a finite log energy (-log(1 - exp(0)) = inf inside): keep those
+    nrgs = np.asarray(ref_bonded._flat_bottom_bond_impl(xc, fb_p, fb_box, fb_idxs))
+    keep = nrgs > 1e-3
+    lfb_idxs, lfb_p = fb_idxs[keep], fb_p[keep]
+    u_ref = float(ref_bonded.log_flat_bottom_bond(xc, lfb_p, fb_box, lfb_idxs, lfb_beta))
+    u, gx, gp = rp.log_flat_bottom_bond(xc, lfb_p, fb_box, lfb_idxs, lfb_beta)
+    assert rel(u, u_ref) < 1e-12, (u, u_ref)
+    check_fd("log flat bottom du_dx", lambda xx: float(ref_bonded.log_flat_bottom_bond(xx, lfb_p, fb_box, lfb_idxs, lfb_beta)), xc, gx, rng, h=1e-7, tol=2e-5)
+    d.update(lfb_idxs=lfb_idxs, lfb_params=lfb_p, lfb_beta=lfb_beta, lfb_u=u_ref, lfb_du_dx=gx, lfb_du_dp=gp)
+    print(f"  log flat bottom: u={u_ref:.6f} ({int(keep.sum())} bonds)")
+    ga = rng.choice(m, 9, replace=False).astype(np.int32)
+    gb = rng.choice(np.setdiff1d(np.arange(m), ga), 14, replace=False).astype(np.int32)
+    for tag, kb, b0 in (("cr", 120.0, 0.25), ("cr0", 75.0, 0.0)):
+        u_ref = float(ref_bonded.centroid_restraint(xc, None, None, ga, gb, kb, b0))
+        u, gx, _ = rp.centroid_restraint(xc, None, None, ga, gb, kb, b0)
+        assert rel(u, u_ref) < 1e-12, (u, u_ref)
+        check_fd(tag + " du_dx", lambda xx, kb=kb, b0=b0: float(ref_bonded.centroid_restraint(xx, None, None, ga, gb, kb, b0)), xc, gx, rng, h=1e-6, tol=5e-6)
+        d.update({f"{tag}_kb": kb, f"{tag}_b0": b0, f"{tag}_u": u_ref, f"{tag}_du_dx": gx})
+        print(f"  centroid restraint b0={b0}: u={u_ref:.6f}")
+    d.update(cr_a=ga, cr_b=gb)
 
     np.savez_compressed(os.path.join(HERE, "groups.npz"), **d)
     shutil.rmtree(_tmp, ignore_errors=True)

@@ -79,7 +79,7 @@ def test_constructor_validation_messages_match_reference():
     with pytest.raises(TypeError):
         custom_ops.Potential()
     with pytest.raises(NotImplementedError):
-        custom_ops.CentroidRestraint_f32()  # SURVEY 8(f) rows not built yet fail loudly, by name
+        custom_ops.BDExchangeMove_f32()  # entries of the reference module that are not built fail loudly, by name
 
 
 def test_dataclass_field_order_is_constructor_order():

@@ -459,6 +459,42 @@ def test_velocity_verlet_matches_device_model_and_reverses(co, P):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_flat_bottom_and_centroid_restraints_golden(co, P, precision):
+    """reference tests: tests/test_bonded.py (flat_bottom_bond, log_flat_bottom_bond), tests/test_centroid_restraint.py"""
+    g = load("groups.npz")
+    x, box = g["chiral_x"], g["fb_box"]
+    brt = 1e-7 if precision == np.float64 else 2e-3
+    cases = (
+        ("fb", P.FlatBottomBond(g["fb_idxs"]), g["fb_params"]),
+        ("lfb", P.LogFlatBottomBond(g["lfb_idxs"], float(g["lfb_beta"])), g["lfb_params"]),
+    )
+    for key, pot, prm in cases:
+        impl = pot.to_gpu(precision).unbound_impl
+        for flags in itertools.product([False, True], repeat=3):
+            du_dx, du_dp, u = impl.execute(x, prm, box, *flags)
+            if flags[2]:
+                np.testing.assert_allclose(u, float(g[f"{key}_u"]), rtol=brt, atol=brt * 10)
+            if flags[0]:
+                assert_equal_vectors(g[f"{key}_du_dx"], du_dx, brt)
+            if flags[1]:
+                np.testing.assert_allclose(du_dp, g[f"{key}_du_dp"], rtol=brt * 10, atol=brt * 100)
+            again = impl.execute(x, prm, box, *flags)
+            for a, b in zip((du_dx, du_dp), again[:2]):
+                np.testing.assert_array_equal(a, b)
+            assert u == again[2]
+    for tag in ("cr", "cr0"):
+        impl = P.CentroidRestraint(g["cr_a"], g["cr_b"], float(g[f"{tag}_kb"]), float(g[f"{tag}_b0"])).to_gpu(precision).unbound_impl
+        du_dx, _, u = impl.execute(x, np.zeros(0), np.eye(3) * 100.0, True, False, True)
+        np.testing.assert_allclose(u, float(g[f"{tag}_u"]), rtol=brt, atol=brt * 10)
+        assert_equal_vectors(g[f"{tag}_du_dx"], du_dx, brt)
+    with pytest.raises(RuntimeError, match="beta must be positive"):
+        co.LogFlatBottomBond_f32(np.array([[0, 1]], np.int32), 0.0)
+    with pytest.raises(RuntimeError, match=r"FlatBottomBond::execute_device\(\): expected P == 3\*B"):
+        P.FlatBottomBond(g["fb_idxs"]).to_gpu(precision).unbound_impl.execute(x, g["fb_params"][:-1], box)
+
+
+@pytest.mark.gpu
 def test_rbfe_shaped_state_runs_fused(co, P):
     """A HostGuestSystem-shaped state (fe/system.py:132-143): host-host Nonbonded(atom_idxs=host), ligand-environment
     interaction group, ligand-ligand precomputed pairs, chiral restraints, bonded terms -- as one SummedPotential in an

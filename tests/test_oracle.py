@@ -188,3 +188,20 @@ def test_groups_precomputed_chiral_match_reference_golden():
     u, gx, gp = rp.chiral_bond_restraint(g["chiral_x"], g["chiral_bond_params"], None, g["chiral_bond_idxs"], g["chiral_bond_signs"])
     np.testing.assert_allclose(u, float(g["chiral_bond_u"]), rtol=1e-12)
     np.testing.assert_allclose(gx, g["chiral_bond_du_dx"], rtol=1e-10, atol=1e-10)
+
+
+def test_restraint_potentials_match_reference_golden():
+    """flat-bottom / log flat-bottom bonds and the centroid restraint (bonded.py:8-31,219-253)"""
+    g = load("groups.npz")
+    x = g["chiral_x"]
+    u, gx, gp = rp.flat_bottom_bond(x, g["fb_params"], g["fb_box"], g["fb_idxs"])
+    np.testing.assert_allclose(u, float(g["fb_u"]), rtol=1e-12)
+    np.testing.assert_allclose(gx, g["fb_du_dx"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gp, g["fb_du_dp"], rtol=1e-10, atol=1e-10)
+    u, gx, gp = rp.log_flat_bottom_bond(x, g["lfb_params"], g["fb_box"], g["lfb_idxs"], float(g["lfb_beta"]))
+    np.testing.assert_allclose(u, float(g["lfb_u"]), rtol=1e-12)
+    np.testing.assert_allclose(gx, g["lfb_du_dx"], rtol=1e-10, atol=1e-10)
+    for tag in ("cr", "cr0"):
+        u, gx, _ = rp.centroid_restraint(x, None, None, g["cr_a"], g["cr_b"], float(g[f"{tag}_kb"]), float(g[f"{tag}_b0"]))
+        np.testing.assert_allclose(u, float(g[f"{tag}_u"]), rtol=1e-12)
+        np.testing.assert_allclose(gx, g[f"{tag}_du_dx"], rtol=1e-10, atol=1e-10)

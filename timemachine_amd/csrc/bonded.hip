@@ -224,6 +224,94 @@ void ChiralBondRestraint<Real>::execute_device(
     }
 }
 
+// ---- flat-bottom restraints, centroid restraint -----------------------------------------------------------------
+template <typename Real, bool Log>
+FlatBottomBond<Real, Log>::FlatBottomBond(const std::vector<int> &bond_idxs, const double beta) : B_(bond_idxs.size() / 2), beta_(beta) {
+    if (Log && beta <= 0) {
+        throw std::runtime_error("beta must be positive");
+    }
+    if (bond_idxs.size() % 2 != 0) {
+        throw std::runtime_error("bond_idxs.size() must be exactly 2*k!");
+    }
+    for (int b = 0; b < B_; b++) {
+        const int src = bond_idxs[b * 2 + 0], dst = bond_idxs[b * 2 + 1];
+        if (src == dst) {
+            throw std::runtime_error("src == dst");
+        }
+        if (src < 0 || dst < 0) {
+            throw std::runtime_error("idxs must be non-negative");
+        }
+    }
+    d_idxs_.realloc(B_ * 2);
+    if (B_ > 0)
+        d_idxs_.copy_from(bond_idxs.data());
+    d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
+}
+
+template <typename Real, bool Log> void FlatBottomBond<Real, Log>::check_size(const int P) const {
+    if (P != 3 * B_) {
+        throw std::runtime_error(
+            std::string(Log ? "LogFlatBottomBond" : "FlatBottomBond") + "::execute_device(): expected P == 3*B, got P=" +
+            std::to_string(P) + ", 3*B=" + std::to_string(3 * B_));
+    }
+}
+
+template <typename Real, bool Log> void FlatBottomBond<Real, Log>::plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) {
+    this->check_size(P);
+    if (B_ > 0) {
+        plan.add_segment(
+            sizeof(Real), FusedSegment{Log ? FUSED_LOG_FLAT_BOTTOM_BOND : FUSED_FLAT_BOTTOM_BOND, B_, d_idxs_.data, d_p, nullptr, beta_, 0.0, nullptr},
+            this, P, d_p);
+    }
+}
+
+template <typename Real, bool Log>
+void FlatBottomBond<Real, Log>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    this->check_size(P);
+    if (B_ > 0) {
+        const int blocks = ceil_divide(B_, 256);
+        k_flat_bottom_bond<Real, Log><<<blocks, 256, 0, stream>>>(
+            B_, d_x, d_box, d_p, d_idxs_.data, beta_, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+        HIP_CHECK(hipGetLastError());
+        if (d_u)
+            reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+    }
+}
+
+template <typename Real>
+CentroidRestraint<Real>::CentroidRestraint(
+    const std::vector<int> &group_a_idxs, const std::vector<int> &group_b_idxs, const double kb, const double b0)
+    : NA_(group_a_idxs.size()), NB_(group_b_idxs.size()), kb_(kb), b0_(b0) {
+    d_a_.realloc(NA_);
+    d_b_.realloc(NB_);
+    if (NA_ > 0)
+        d_a_.copy_from(group_a_idxs.data());
+    if (NB_ > 0)
+        d_b_.copy_from(group_b_idxs.data());
+    d_sums_.realloc(6);
+}
+
+template <typename Real>
+void CentroidRestraint<Real>::execute_device(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
+    hipStream_t stream) {
+    if (NA_ + NB_ > 0) { // (no parameters: d_du_dp is left untouched, as in the reference)
+        const int blocks = ceil_divide(NA_ + NB_, 256);
+        d_sums_.zero_async(stream, 6);
+        k_centroid_sums<Real><<<blocks, 256, 0, stream>>>(NA_, NB_, d_x, d_a_.data, d_b_.data, d_sums_.data);
+        k_centroid_restraint<Real><<<blocks, 256, 0, stream>>>(NA_, NB_, d_a_.data, d_b_.data, d_sums_.data, kb_, b0_, d_du_dx, d_u);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+template class FlatBottomBond<float, false>;
+template class FlatBottomBond<double, false>;
+template class FlatBottomBond<float, true>;
+template class FlatBottomBond<double, true>;
+template class CentroidRestraint<float>;
+template class CentroidRestraint<double>;
 template class ChiralAtomRestraint<float>;
 template class ChiralAtomRestraint<double>;
 template class ChiralBondRestraint<float>;

@@ -238,6 +238,36 @@ int tm_nonbonded_pair_list_precomputed_create(
     TM_CATCH
 }
 
+int tm_flat_bottom_bond_create(int precision, int log_form, const int32_t *bond_idxs, int n, double beta, tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> v(bond_idxs, bond_idxs + static_cast<size_t>(n) * 2);
+    std::shared_ptr<Potential> pot;
+    if (precision == TM_F32) {
+        if (log_form)
+            pot = std::make_shared<FlatBottomBond<float, true>>(v, beta);
+        else
+            pot = std::make_shared<FlatBottomBond<float, false>>(v, beta);
+    } else if (precision == TM_F64) {
+        if (log_form)
+            pot = std::make_shared<FlatBottomBond<double, true>>(v, beta);
+        else
+            pot = std::make_shared<FlatBottomBond<double, false>>(v, beta);
+    } else {
+        throw std::runtime_error("invalid precision");
+    }
+    *out = new tm_potential_s{pot};
+    TM_CATCH
+}
+
+int tm_centroid_restraint_create(
+    int precision, const int32_t *group_a_idxs, int num_a, const int32_t *group_b_idxs, int num_b, double kb, double b0,
+    tm_potential_t *out) {
+    TM_TRY
+    std::vector<int> a(group_a_idxs, group_a_idxs + num_a), b(group_b_idxs, group_b_idxs + num_b);
+    *out = new tm_potential_s{make_by_precision<CentroidRestraint>(precision, a, b, kb, b0)};
+    TM_CATCH
+}
+
 int tm_chiral_atom_restraint_create(int precision, const int32_t *idxs, int n, tm_potential_t *out) {
     TM_TRY
     std::vector<int> v(idxs, idxs + static_cast<size_t>(n) * 4);

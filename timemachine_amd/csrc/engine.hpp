@@ -30,7 +30,9 @@ enum FusedKind : int {
     FUSED_PAIR_LIST_NEGATED = 4,
     FUSED_PAIR_LIST_PRECOMPUTED = 5,
     FUSED_CHIRAL_ATOM = 6,
-    FUSED_CHIRAL_BOND = 7
+    FUSED_CHIRAL_BOND = 7,
+    FUSED_FLAT_BOTTOM_BOND = 8,
+    FUSED_LOG_FLAT_BOTTOM_BOND = 9
 };
 static const int FUSED_MAX_SEGMENTS = 16;
 struct FusedSegment {
@@ -235,6 +237,32 @@ private:
     int T_;
     DeviceBuffer<int> d_idxs_;
     DeviceBuffer<i128> d_u_partials_;
+};
+
+// reference: cpp/src/flat_bottom_bond.{hpp,cu} (Log == false), log_flat_bottom_bond.{hpp,cu} (Log == true)
+template <typename Real, bool Log> class FlatBottomBond : public Potential {
+public:
+    FlatBottomBond(const std::vector<int> &bond_idxs, const double beta);
+    void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int B_;
+    double beta_;
+    DeviceBuffer<int> d_idxs_;
+    DeviceBuffer<i128> d_u_partials_;
+    void check_size(const int P) const;
+};
+
+// reference: cpp/src/centroid_restraint.{hpp,cu}
+template <typename Real> class CentroidRestraint : public Potential {
+public:
+    CentroidRestraint(const std::vector<int> &group_a_idxs, const std::vector<int> &group_b_idxs, const double kb, const double b0);
+    void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
+private:
+    int NA_, NB_;
+    double kb_, b0_;
+    DeviceBuffer<int> d_a_, d_b_;
+    DeviceBuffer<u64> d_sums_;
 };
 
 // reference: cpp/src/chiral_atom_restraint.{hpp,cu}, chiral_bond_restraint.{hpp,cu}

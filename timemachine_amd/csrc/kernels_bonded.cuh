@@ -415,4 +415,135 @@ __global__ __launch_bounds__(256) void k_chiral_bond_restraint(
     }
 }
 
+// ---- flat-bottom restraints -------------------------------------------------------------------------------------
+// reference: cpp/src/kernels/k_flat_bottom_bond.cuh:8-171, k_log_flat_bottom_bond.cuh:9-120; JAX: bonded.py:219-253
+//   U_fb(r) = k/4 (r - rmax)^4 for r > rmax, k/4 (r - rmin)^4 for r < rmin, else 0   (minimum-image distance)
+//   U_log   = -log(1 - exp(-beta U_fb)) / beta
+template <typename Real, bool LOG>
+__device__ __forceinline__ i128 flat_bottom_bond_term(
+    const int b, const double *__restrict__ coords, const double *__restrict__ box, const double *__restrict__ params,
+    const int *__restrict__ bond_idxs, const double beta_d, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    const int src = bond_idxs[b * 2 + 0], dst = bond_idxs[b * 2 + 1];
+    const Real k = static_cast<Real>(params[b * 3 + 0]);
+    const Real rmin = static_cast<Real>(params[b * 3 + 1]);
+    const Real rmax = static_cast<Real>(params[b * 3 + 2]);
+    Real dx[3];
+    Real r2 = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        // displacement and re-imaging in double, like the reference kernel (k_flat_bottom_bond.cuh:112-117)
+        double delta = coords[src * 3 + d] - coords[dst * 3 + d];
+        delta -= box[d * 4] * nearbyint(delta / box[d * 4]);
+        dx[d] = static_cast<Real>(delta);
+        r2 += dx[d] * dx[d];
+    }
+    const Real r = tm_sqrt<Real>(r2);
+    const Real above = r > rmax ? static_cast<Real>(1) : static_cast<Real>(0);
+    const Real below = r < rmin ? static_cast<Real>(1) : static_cast<Real>(0);
+    const Real dlo = r - rmin, dhi = r - rmax;
+    const Real dlo3 = dlo * dlo * dlo, dhi3 = dhi * dhi * dhi;
+    const Real quartic = above * (dhi3 * dhi) + below * (dlo3 * dlo);
+    const Real nrg = (k / 4) * quartic;
+    Real chain = 1; // dU/dU_fb
+    i128 energy = 0;
+    if constexpr (LOG) {
+        const Real beta = static_cast<Real>(beta_d);
+        const Real e = exp(-beta * nrg);
+        chain = -e / (1 - e);
+        if (want_u) {
+            const Real x = beta * nrg; // -log(1 - exp(-x)), evaluated stably on both sides of log 2
+            const Real l = x < static_cast<Real>(0.693147180559945309417232121) ? log(-expm1(-x)) : log1p(-exp(-x));
+            energy = float_to_fixed_energy<Real>(-l / beta);
+        }
+    } else {
+        if (want_u) {
+            energy = float_to_fixed_energy<Real>(nrg);
+        }
+    }
+    if (du_dp) {
+        atomicAdd(du_dp + b * 3 + 0, float_to_fixed<Real>(chain * (quartic / 4)));
+        atomicAdd(du_dp + b * 3 + 1, float_to_fixed<Real>(chain * (below * (-k * dlo3))));
+        atomicAdd(du_dp + b * 3 + 2, float_to_fixed<Real>(chain * (above * (-k * dhi3))));
+    }
+    if (du_dx) {
+        const Real du_dr = k * (above * dhi3 + below * dlo3);
+        const Real inv_r = 1 / r;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const Real g = chain * (du_dr * dx[d] * inv_r);
+            atomicAdd(du_dx + src * 3 + d, float_to_fixed<Real>(g));
+            atomicAdd(du_dx + dst * 3 + d, float_to_fixed<Real>(-g));
+        }
+    }
+    return energy;
+}
+
+template <typename Real, bool LOG>
+__global__ __launch_bounds__(256) void k_flat_bottom_bond(
+    const int B, const double *__restrict__ coords, const double *__restrict__ box, const double *__restrict__ params,
+    const int *__restrict__ bond_idxs, const double beta, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp,
+    i128 *__restrict__ u_partials) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    i128 energy = 0;
+    if (b < B) {
+        energy = flat_bottom_bond_term<Real, LOG>(b, coords, box, params, bond_idxs, beta, du_dx, du_dp, u_partials != nullptr);
+    }
+    if (u_partials) {
+        store_wave_energy<Real>(energy, u_partials);
+    }
+}
+
+// ---- centroid restraint --------------------------------------------------------------------------------------
+// reference: cpp/src/kernels/k_centroid_restraint.cuh:8-86; JAX: bonded.py:8-31.  U = kb (|<x_A> - <x_B>| - b0)^2
+// (geometric centroids, no periodic imaging, no parameters).  Pass 1 sums the coordinates of both groups in fixed
+// point (deterministic), pass 2 hands every group atom its share of the gradient.
+template <typename Real>
+__global__ __launch_bounds__(256) void k_centroid_sums(
+    const int NA, const int NB, const double *__restrict__ coords, const int *__restrict__ a_idxs, const int *__restrict__ b_idxs,
+    u64 *__restrict__ sums) { // [2][3], zeroed by the caller
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NA + NB) {
+        return;
+    }
+    const bool in_a = t < NA;
+    const int atom = in_a ? a_idxs[t] : b_idxs[t - NA];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        atomicAdd(sums + (in_a ? 0 : 3) + d, float_to_fixed<Real>(static_cast<Real>(coords[atom * 3 + d])));
+    }
+}
+
+template <typename Real>
+__global__ __launch_bounds__(256) void k_centroid_restraint(
+    const int NA, const int NB, const int *__restrict__ a_idxs, const int *__restrict__ b_idxs, const u64 *__restrict__ sums,
+    const double kb_d, const double b0_d, u64 *__restrict__ du_dx, i128 *__restrict__ u) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NA + NB) {
+        return;
+    }
+    const Real kb = static_cast<Real>(kb_d), b0 = static_cast<Real>(b0_d);
+    Real delta[3];
+    Real d2 = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        delta[d] = fixed_to_float<Real>(sums[d]) / NA - fixed_to_float<Real>(sums[3 + d]) / NB;
+        d2 += delta[d] * delta[d];
+    }
+    const Real dij = tm_sqrt<Real>(d2);
+    if (t == 0 && u) {
+        u[0] = float_to_fixed_energy<Real>(kb * (dij - b0) * (dij - b0));
+    }
+    if (du_dx) {
+        const bool in_a = t < NA;
+        const int atom = in_a ? a_idxs[t] : b_idxs[t - NA];
+        const Real share = (in_a ? static_cast<Real>(1) : static_cast<Real>(-1)) / static_cast<Real>(in_a ? NA : NB);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            // b0 == 0: the gradient 2 kb delta is well defined at dij == 0 as well (bonded.py:26-31)
+            const Real g = b0 != 0 ? 2 * kb * (dij - b0) * (delta[d] / dij) : 2 * kb * delta[d];
+            atomicAdd(du_dx + atom * 3 + d, float_to_fixed<Real>(share * g));
+        }
+    }
+}
+
 } // namespace tmamd

@@ -819,6 +819,8 @@ __device__ __forceinline__ void fused_dispatch(
         break;
     case FUSED_CHIRAL_ATOM: chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
     case FUSED_CHIRAL_BOND: chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, du_dx, nullptr, false); break;
+    case FUSED_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false); break;
+    case FUSED_LOG_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false); break;
     default: break;
     }
 }

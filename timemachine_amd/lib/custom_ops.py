@@ -379,7 +379,33 @@ def _chiral_bond_ctor(cls, prec, idxs, signs):
         cls, _lib.tm_chiral_bond_restraint_create, _c_int(prec), _ptr(idx), _c_int(idx.size // 4), _ptr(sg), _c_int(sg.size))
 
 
+def _flat_bottom_bond_ctor(cls, prec, bond_idxs):
+    """FlatBottomBond_*(bond_idxs int32[B,2]); wrap_kernels.cpp:1324-1336."""
+    idx = _i32(bond_idxs, "bond_idxs")
+    if idx.size % 2 != 0:
+        raise RuntimeError("bond_idxs.size() must be exactly 2*k!")
+    return _new_potential(cls, _lib.tm_flat_bottom_bond_create, _c_int(prec), _c_int(0), _ptr(idx), _c_int(idx.size // 2), _c_double(0.0))
+
+
+def _log_flat_bottom_bond_ctor(cls, prec, bond_idxs, beta):
+    """LogFlatBottomBond_*(bond_idxs int32[B,2], beta); wrap_kernels.cpp:1338-1351."""
+    idx = _i32(bond_idxs, "bond_idxs")
+    if idx.size % 2 != 0:
+        raise RuntimeError("bond_idxs.size() must be exactly 2*k!")
+    return _new_potential(cls, _lib.tm_flat_bottom_bond_create, _c_int(prec), _c_int(1), _ptr(idx), _c_int(idx.size // 2), _c_double(beta))
+
+
+def _centroid_restraint_ctor(cls, prec, group_a_idxs, group_b_idxs, kb, b0):
+    """CentroidRestraint_*(group_a_idxs, group_b_idxs, kb, b0); wrap_kernels.cpp:1410-1430."""
+    a, b = _i32(group_a_idxs, "group_a_idxs"), _i32(group_b_idxs, "group_b_idxs")
+    return _new_potential(
+        cls, _lib.tm_centroid_restraint_create, _c_int(prec), _ptr(a), _c_int(a.size), _ptr(b), _c_int(b.size), _c_double(kb), _c_double(b0))
+
+
 HarmonicBond_f32, HarmonicBond_f64 = _declare_precision_classes("HarmonicBond", _harmonic_bond_ctor)
+FlatBottomBond_f32, FlatBottomBond_f64 = _declare_precision_classes("FlatBottomBond", _flat_bottom_bond_ctor)
+LogFlatBottomBond_f32, LogFlatBottomBond_f64 = _declare_precision_classes("LogFlatBottomBond", _log_flat_bottom_bond_ctor)
+CentroidRestraint_f32, CentroidRestraint_f64 = _declare_precision_classes("CentroidRestraint", _centroid_restraint_ctor)
 NonbondedInteractionGroup_f32, NonbondedInteractionGroup_f64 = _declare_precision_classes("NonbondedInteractionGroup", _interaction_group_ctor)
 NonbondedPairListPrecomputed_f32, NonbondedPairListPrecomputed_f64 = _declare_precision_classes(
     "NonbondedPairListPrecomputed", _pair_list_precomputed_ctor)
@@ -878,8 +904,7 @@ def _not_on_hot_path(name):
 
 
 for _name in (
-    "CentroidRestraint_f32", "CentroidRestraint_f64", "FlatBottomBond_f32", "FlatBottomBond_f64",
-    "LogFlatBottomBond_f32", "LogFlatBottomBond_f64", "BDExchangeMove_f32",
+    "BDExchangeMove_f32",
     "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
 ):
     globals()[_name] = _not_on_hot_path(_name)

@@ -127,6 +127,31 @@ class NonbondedPairListPrecomputed(Potential):
 
 
 @dataclass
+class CentroidRestraint(Potential):
+    """reference: potentials.py:49-57; no parameters (params of size 0)"""
+
+    group_a_idxs: NDArray[np.int32]
+    group_b_idxs: NDArray[np.int32]
+    kb: float
+    b0: float
+
+
+@dataclass
+class FlatBottomBond(Potential):
+    """reference: potentials.py:77-82; params [B,3] = (k, r_min, r_max)"""
+
+    idxs: NDArray[np.int32]
+
+
+@dataclass
+class LogFlatBottomBond(Potential):
+    """reference: potentials.py:85-91"""
+
+    idxs: NDArray[np.int32]
+    beta: float
+
+
+@dataclass
 class ChiralAtomRestraint(Potential):
     """reference: potentials.py:60-65; params [R] force constants"""
 
