@@ -105,7 +105,7 @@ def cpu_baseline(system, x, cutoff):
     cores = min(os.cpu_count() or 1, 64)  # torch's elementwise kernels stop scaling long before 256 threads
     torch.set_num_threads(cores)
     N = system.num_atoms
-    rows = 512
+    rows = 3072  # ~13 s of CPU work on 64 threads (the contract asks for a 10-30 s sample)
     xt = torch.tensor(x, requires_grad=True)
     pt = torch.tensor(system.nb_params)
     bt = torch.tensor(system.box)
@@ -161,8 +161,8 @@ def find_nonbonded(bps):
     raise RuntimeError("no Nonbonded in the state")
 
 
-# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/r01_v6_pmc_f64.txt
-PMC_TRAFFIC_BYTES = {"f64": (16912 + 98207) * 1024, "f32": (8350 + 69963) * 1024}
+# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/r01_v7_pmc_f64.txt
+PMC_TRAFFIC_BYTES = {"f64": (14988 + 89289) * 1024, "f32": (8362 + 69723) * 1024}
 
 
 def main():
@@ -287,10 +287,10 @@ def main():
             "unit": "GB/s",
             "frac": bytes_alg / t_s / 1e9 / HBM_PEAK_GBS,
             # FETCH_SIZE + WRITE_SIZE per dispatch of this kernel from the committed PMC passes (separate rocprofv3 --pmc runs
-            # of this very command, scripts/gpu_pmc.sh -> profiles/r01_v6_pmc_f64.txt); counters uncalibrated for this
+            # of this very command, scripts/gpu_pmc.sh -> profiles/r01_v7_pmc_f64.txt); counters uncalibrated for this
             # access pattern (MI355X_MICROARCH.md, HBM section).  ~20x the algorithmic bytes: the flush's u64 atomics.
             "traffic": PMC_TRAFFIC_BYTES.get(args.precision),
-            "traffic_source": "profiles/r01_v6_pmc_f64.txt (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
+            "traffic_source": "profiles/r01_v7_pmc_f64.txt (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
             "bytes_per_launch": bytes_alg,
             "kernel_ms": prof["kernel_ms"],
             "launches_timed": prof["launches"],
