@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     }
     const unsigned int n_items_total = __shfl(bucket_end, 63, 64);
     unsigned int next_round = 0;
-    auto request_ticket = [&]() -> unsigned int {
+    auto next_position = [&]() -> unsigned int {
         // serpentine deal: even rounds left to right, odd rounds right to left, so the wave that drew the heaviest item of
         // one round draws the lightest of the next
         const unsigned int w = (next_round & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         next_round++;
         return t;
     };
-    auto resolve_ticket = [&](unsigned int g) -> unsigned int {
+    auto position_to_slot = [&](unsigned int g) -> unsigned int {
         if (g >= n_items_total) {
             return NO_ITEM;
         }
@@ -291,9 +291,9 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 #define TM_T(var)
 #endif
 
-    // prologue: first item fetched the slow way; the second ticket is already taken
-    unsigned int item = resolve_ticket(request_ticket());
-    unsigned int item_next = resolve_ticket(request_ticket());
+    // prologue: first item fetched the slow way; the position of the second one is already known
+    unsigned int item = position_to_slot(next_position());
+    unsigned int item_next = position_to_slot(next_position());
     TileRegs<Real> cur;
     if (item != NO_ITEM) {
         load_indices(items[item], cur);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         if (have_next) {
             it_next = items[item_next];
         }
-        const unsigned int item_after = resolve_ticket(request_ticket());
+        const unsigned int item_after = position_to_slot(next_position());
         TileRegs<Real> nxt;
         nxt.ja = uK;
         nxt.ra = uK;
