@@ -3,7 +3,9 @@
 #include "engine.hpp"
 #include "fixed_point.cuh"
 
+#include <algorithm>
 #include <numeric>
+#include <vector>
 
 namespace tmamd {
 
@@ -65,7 +67,13 @@ void Potential::execute_batch_device(
 void Potential::execute_batch_sparse_device(
     const int N, const int P, const int batch_size, const unsigned int *coords_batch_idxs, const unsigned int *params_batch_idxs,
     const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) {
-    for (int i = 0; i < batch_size; i++) {
+    // Entries are evaluated grouped by coordinate set (stable within a group) while every result still lands in its
+    // own batch slot: a stateful child (neighbor list) then rebuilds once per distinct frame however the caller ordered
+    // the pairs -- the HREX energy matrix asks for each replica's frame under ~9 neighbouring parameter sets.
+    std::vector<int> order(batch_size);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return coords_batch_idxs[a] < coords_batch_idxs[b]; });
+    for (const int i : order) {
         const size_t ic = coords_batch_idxs[i], ip = params_batch_idxs[i];
         this->execute_device(
             N, P, d_x + ic * N * D, P > 0 ? d_p + ip * P : nullptr, d_box + ic * D * D,
