@@ -250,7 +250,8 @@ template <typename Real> void MonteCarloBarostat<Real>::move(const int N, double
         throw std::runtime_error("N != N_");
     }
     this->step_++;
-    if (this->step_ % this->interval_ != 0) {
+    this->acted_ = this->step_ % this->interval_ == 0;
+    if (!this->acted_) {
         return;
     }
     const int tpb = DEFAULT_TPB;

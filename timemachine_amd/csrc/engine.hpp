@@ -52,11 +52,27 @@ struct FusedTable {
 // A force contribution left in a potential's own (sorted) accumulator instead of being scattered into du_dx: the
 // consumer adds g_du_dx[slot_of_atom[a] * 3 + d] for every atom a with slot_of_atom[a] >= 0.  Lets the integrator's
 // update kernel pick the nonbonded forces up directly (one launch and one pass over du_dx less per step).
+// What the consumer needs to leave the producer's NEXT gather already done while it moves the atoms (the integrator's
+// update kernel touches every atom anyway): the new position goes straight into the producer's sorted record, the
+// displacement-vs-snapshot test that decides on a neighbor-list rebuild is made on the spot, and the consumed accumulator
+// slot is zeroed.  The producer then skips its own check + gather launch on the next call (one launch and one pass over
+// the atoms less per MD step).  Plain data: passed to kernels by value.
+struct PregatherTarget {
+    void *gathered = nullptr; // Real[K + 1][8] records (x, y, z, w, q, sig, eps, 0); only x, y, z are rewritten
+    int real_bytes = 0;       // sizeof(Real) of the producer: 4 or 8
+    const double *snap_x = nullptr; // coordinates at the last list build, atom order
+    double pad2_quarter = 0;        // (padding / 2)^2
+    int *flag_set = nullptr;        // rebuild flag of the producer's next call
+    int *flag_clear = nullptr;      // flag of the call that has just been consumed
+    u64 *g_du_dx = nullptr;         // the accumulator handed over in DeferredForces (to be zeroed slot by slot)
+};
+class Potential;
 struct DeferredForces {
     const u64 *g_du_dx = nullptr;
     const int *slot_of_atom = nullptr;
+    PregatherTarget next;       // gathered == nullptr: the producer does not take pre-gathered positions
+    Potential *owner = nullptr; // to be told (pregather_committed) once a kernel filling `next` has been enqueued
 };
-class Potential;
 class ForcePlan {
 public:
     struct Rest {
@@ -97,6 +113,13 @@ public:
         DeferredForces &out) {
         return false;
     }
+
+    // The consumer of DeferredForces has enqueued (on the same stream) a kernel that filled `next` for the coordinates
+    // in d_x / d_box: the following execute_forces_deferred call with the same pointers may skip its gather.
+    virtual void pregather_committed(const double *d_x, const double *d_box) {}
+    // Anything a potential remembers about its inputs between calls (pre-gathered positions) is dropped.  Called when
+    // coordinates, box or parameters change behind an unchanged pointer (set_params, Context::set_x_t, movers).
+    virtual void invalidate_cached_inputs() {}
 
     // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
     virtual void execute_device(
@@ -173,6 +196,11 @@ public:
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
     const std::vector<int> &get_parameter_sizes() { return params_sizes_; }
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void invalidate_cached_inputs() override {
+        for (auto &pot : potentials_) {
+            pot->invalidate_cached_inputs();
+        }
+    }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
@@ -192,6 +220,11 @@ public:
     FanoutSummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const bool parallel);
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
+    void invalidate_cached_inputs() override {
+        for (auto &pot : potentials_) {
+            pot->invalidate_cached_inputs();
+        }
+    }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
@@ -375,6 +408,8 @@ public:
     int get_num_atom_idxs() const { return K_; }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
+    void pregather_committed(const double *d_x, const double *d_box) override;
+    void invalidate_cached_inputs() override { pre_valid_ = false; }
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
@@ -411,7 +446,11 @@ protected:
     DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
     DeviceBuffer<int> d_slot_of_atom_;            // [N]: position of each atom in the sorted order, -1 = not one of ours
     void check_sizes(const int N, const int P) const;
-    void run_pipeline(const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx, hipStream_t stream);
+    void run_pipeline(const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx, hipStream_t stream, const bool pregathered = false);
+    // positions pre-gathered by the consumer of the last deferred call (see PregatherTarget): valid for exactly these
+    // input pointers, dropped by any other call into the pipeline
+    bool pre_valid_ = false;
+    const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
 };
@@ -532,10 +571,14 @@ public:
         }
         step_ = step;
     }
+    // false only when the last move() call provably left coordinates and box untouched (off-interval call); the
+    // Context drops the potentials' pre-gathered inputs otherwise
+    bool acted_last_call() const { return acted_; }
 protected:
     explicit Mover(const int interval) : interval_(interval), step_(0) {}
     int interval_;
     int step_;
+    bool acted_ = true;
 };
 
 // reference: cpp/src/barostat.{hpp,cu}, kernels/k_barostat.cuh.  Molecular-scaling Monte Carlo barostat: every
@@ -601,6 +644,7 @@ private:
     std::vector<double> nb_cutoffs_with_padding_;
     hipStream_t stream_;
     void _step(hipStream_t stream);
+    void invalidate_potential_inputs();
     void _verify_coords_and_box(const double *coords, const double *box, hipStream_t stream);
 };
 

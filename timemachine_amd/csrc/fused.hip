@@ -68,7 +68,13 @@ void ForcePlan::run(
     // 3. the potentials that launch their own kernels
     for (const Rest &r : rest_) {
         DeferredForces df;
-        if (deferred != nullptr && static_cast<int>(deferred->size()) < max_deferred &&
+        // a potential bound more than once is never deferred: its other call would zero and reuse the accumulator this
+        // one hands over before the consumer has read it
+        bool shared = false;
+        for (const Rest &q : rest_) {
+            shared = shared || (&q != &r && q.pot == r.pot);
+        }
+        if (!shared && deferred != nullptr && static_cast<int>(deferred->size()) < max_deferred &&
             r.pot->execute_forces_deferred(N, r.P, d_x, r.d_p, d_box, d_du_dx, stream, df)) {
             deferred->push_back(df);
         } else {

@@ -40,6 +40,38 @@ __device__ __forceinline__ void normal3(unsigned long long seed, unsigned long l
     n[2] = rb * cosf(two_pi * u3);
 }
 
+// Leaves a force producer's next gather done (PregatherTarget): new position into its sorted record, rebuild test against
+// its snapshot with the arithmetic of k_check_gather (producer precision), consumed accumulator slot zeroed.
+template <typename GReal>
+__device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, const int slot, const int atom, const double xn, const double yn, const double zn) {
+    GReal *g = static_cast<GReal *>(t.gathered) + static_cast<size_t>(slot) * 8;
+    const GReal gx = static_cast<GReal>(xn), gy = static_cast<GReal>(yn), gz = static_cast<GReal>(zn);
+    g[0] = gx;
+    g[1] = gy;
+    g[2] = gz;
+    const GReal dx = static_cast<GReal>(t.snap_x[atom * 3 + 0]) - gx;
+    const GReal dy = static_cast<GReal>(t.snap_x[atom * 3 + 1]) - gy;
+    const GReal dz = static_cast<GReal>(t.snap_x[atom * 3 + 2]) - gz;
+    const GReal d2 = dx * dx + dy * dy + dz * dz;
+    if (static_cast<double>(d2) > t.pad2_quarter) {
+        *t.flag_set = 1; // benign race: every writer stores the same value
+    }
+    t.g_du_dx[static_cast<size_t>(slot) * 3 + 0] = 0;
+    t.g_du_dx[static_cast<size_t>(slot) * 3 + 1] = 0;
+    t.g_du_dx[static_cast<size_t>(slot) * 3 + 2] = 0;
+}
+
+__device__ __forceinline__ void pregather_atom(const PregatherTarget &t, const int slot, const int atom, const double xn, const double yn, const double zn) {
+    if (t.gathered == nullptr || slot < 0) {
+        return;
+    }
+    if (t.real_bytes == 8) {
+        pregather_atom_as<double>(t, slot, atom, xn, yn, zn);
+    } else {
+        pregather_atom_as<float>(t, slot, atom, xn, yn, zn);
+    }
+}
+
 // reference: k_update_forward_baoab (k_integrator.cuh:5-62).  x, v stored f64; arithmetic in Real with the same
 // promotion points: v_mid = Real(v + cb*F); v' = ca*v_mid + cc*noise (Real); x += Real(0.5*dt) * (v_mid + v') in f64.
 template <typename Real>
@@ -48,7 +80,17 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
     const unsigned long long seed, const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t,
     u64 *__restrict__ du_dx, const Real dt,
     // up to two force contributions picked up from their producers' sorted accumulators (DeferredForces); nullptr = none
-    const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1, const int *__restrict__ slot1) {
+    const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1, const int *__restrict__ slot1,
+    // where to leave the producers' next gather (gathered == nullptr: not wanted)
+    const PregatherTarget pg0, const PregatherTarget pg1) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (pg0.gathered) {
+            *pg0.flag_clear = 0; // the flag of the call just consumed becomes the one after next's
+        }
+        if (pg1.gathered) {
+            *pg1.flag_clear = 0;
+        }
+    }
     for (int kidx = blockIdx.x * blockDim.x + threadIdx.x; kidx < N; kidx += gridDim.x * blockDim.x) {
         const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
         if (atom < N) {
@@ -61,6 +103,7 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
             const Real half_dt = static_cast<Real>(0.5) * dt;
             const int s0 = g0 ? slot0[atom] : -1;
             const int s1 = g1 ? slot1[atom] : -1;
+            double xn[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 u64 f = du_dx[atom * 3 + d]; // wrapping integer sum: same bits as a scatter-add into du_dx would give
@@ -74,9 +117,12 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
                 const Real v_new = ca * v_mid + cc * static_cast<Real>(nz[d]);
                 v_t[atom * 3 + d] = static_cast<double>(v_new);
-                x_t[atom * 3 + d] += static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
+                xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
+                x_t[atom * 3 + d] = xn[d];
                 du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
             }
+            pregather_atom(pg0, s0, atom, xn[0], xn[1], xn[2]);
+            pregather_atom(pg1, s1, atom, xn[0], xn[1], xn[2]);
         } else if (idxs != nullptr) {
             du_dx[kidx * 3 + 0] = 0;
             du_dx[kidx * 3 + 1] = 0;
@@ -118,10 +164,20 @@ void LangevinIntegrator<Real>::step_fwd(
     const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
     const int tpb = 256;
+    // every atom moves (no local-MD index list): the update kernel can leave the producers' next gather done
+    const PregatherTarget no_target;
+    const bool pregather = d_idxs == nullptr;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
         N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_, df0.g_du_dx, df0.slot_of_atom,
-        df1.g_du_dx, df1.slot_of_atom);
+        df1.g_du_dx, df1.slot_of_atom, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
     HIP_CHECK(hipGetLastError());
+    if (pregather) {
+        for (const DeferredForces &df : deferred_) {
+            if (df.owner != nullptr && df.next.gathered != nullptr) {
+                df.owner->pregather_committed(d_x_t, d_box_t);
+            }
+        }
+    }
     step_++;
 }
 
@@ -270,8 +326,17 @@ void Context::_step(hipStream_t stream) {
     intg_->step_fwd(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
     for (auto &mover : movers_) {
         mover->move(N_, d_x_t_.data, d_box_t_.data, stream);
+        if (mover->acted_last_call()) {
+            this->invalidate_potential_inputs(); // coordinates / box may have changed behind the same pointers
+        }
     }
     step_ += 1;
+}
+
+void Context::invalidate_potential_inputs() {
+    for (auto &bp : bps_) {
+        bp->potential->invalidate_cached_inputs();
+    }
 }
 
 void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box) {
@@ -314,9 +379,15 @@ void Context::finalize() {
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-void Context::set_x_t(const double *in) { d_x_t_.copy_from(in); }
+void Context::set_x_t(const double *in) {
+    d_x_t_.copy_from(in);
+    this->invalidate_potential_inputs();
+}
 void Context::set_v_t(const double *in) { d_v_t_.copy_from(in); }
-void Context::set_box(const double *in) { d_box_t_.copy_from(in); }
+void Context::set_box(const double *in) {
+    d_box_t_.copy_from(in);
+    this->invalidate_potential_inputs();
+}
 void Context::get_x_t(double *out) const { d_x_t_.copy_to(out); }
 void Context::get_v_t(double *out) const { d_v_t_.copy_to(out); }
 void Context::get_box(double *out) const { d_box_t_.copy_to(out); }

@@ -1,8 +1,8 @@
 // Neighbor-list construction kernels for gfx950.  Included by nonbonded.hip only.
 //
 // What is built (all on device, no host round trip):
-//   block bounds   Real[nblocks][3] centre / extent per 32-atom block (PBC-aware running re-imaging, the
-//                  algorithm of reference k_find_block_bounds, cpp/src/kernels/k_neighborlist.cuh:11-116)
+//   block bounds   Real[nblocks][3] centre / extent per 32-atom block (PBC-aware; the reported boxes follow the
+//                  running re-imaging of reference k_find_block_bounds, cpp/src/kernels/k_neighborlist.cuh:11-116)
 //   CSR lists      per row block a contiguous segment in `col_atoms` holding every column atom that is
 //                  within `cutoff` (the list cutoff = cutoff + padding) of at least one row atom -- the same
 //                  set the reference compacts into 32-wide `ixn_atoms` tiles (k_neighborlist.cuh:199-458),
@@ -19,10 +19,15 @@
 namespace tmamd {
 
 // K2: block bounds (one wave per 32-atom block), coordinate snapshot and counter reset.
-// The running min/max fold is inherently sequential (each atom is re-imaged around the CURRENT centre), so every lane
-// of the wave runs the same fold on shuffled-in positions: lanes 0-31 load one atom each (coalesced), no LDS, no
-// divergence, and the 32 dependent global loads of a thread-per-block version collapse into one.
-template <typename Real>
+// REFERENCE_FOLD = true reproduces the reference's boxes (what Neighborlist.compute_block_bounds reports): its running
+// min/max fold is inherently sequential (each atom is re-imaged around the CURRENT centre), so every lane of the wave
+// runs the same fold on shuffled-in positions: lanes 0-31 load one atom each (coalesced), no LDS, no divergence.
+// REFERENCE_FOLD = false is what the list build uses: every atom is imaged next to the block's first atom and the
+// min / max are butterfly reductions -- 5 shuffle steps instead of a 33-step dependent chain (14 us -> launch latency).
+// Any box that contains an image of each of its atoms yields a valid (superset) list, and integer accumulation makes
+// the forces independent of which superset is used, so the two folds are interchangeable for everything but the
+// reported boxes themselves.
+template <typename Real, bool REFERENCE_FOLD>
 __global__ __launch_bounds__(256) void k_block_bounds(
     const int n_col_blocks, const int NC, const unsigned int *__restrict__ col_idxs, // nullptr => identity
     const int n_row_blocks, const int NR, const unsigned int *__restrict__ row_idxs, // only used when rows != cols
@@ -76,14 +81,30 @@ __global__ __launch_bounds__(256) void k_block_bounds(
         for (int d = 0; d < 3; d++) {
             lo[d] = hi[d] = __shfl(p[d], 0, 64);
         }
-        // visiting order of the reference's lane rotation: atoms 1, 2, ..., n-1, then atom 0 again
-        for (int k = 1; k <= n; k++) {
-            const int kk = k == n ? 0 : k;
+        if constexpr (REFERENCE_FOLD) {
+            // visiting order of the reference's lane rotation: atoms 1, 2, ..., n-1, then atom 0 again
+            for (int k = 1; k <= n; k++) {
+                const int kk = k == n ? 0 : k;
+                for (int d = 0; d < 3; d++) {
+                    const Real pd = __shfl(p[d], kk, 64);
+                    const Real img = pd - b[d] * nearbyint((pd - half * (hi[d] + lo[d])) * ib[d]);
+                    lo[d] = min(lo[d], img);
+                    hi[d] = max(hi[d], img);
+                }
+            }
+        } else {
             for (int d = 0; d < 3; d++) {
-                const Real pd = __shfl(p[d], kk, 64);
-                const Real img = pd - b[d] * nearbyint((pd - half * (hi[d] + lo[d])) * ib[d]);
-                lo[d] = min(lo[d], img);
-                hi[d] = max(hi[d], img);
+                const Real p0 = lo[d];
+                const Real img = lane < n ? p[d] - b[d] * nearbyint((p[d] - p0) * ib[d]) : p0;
+                Real l = img, h = img;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    l = min(l, __shfl_xor(l, o, 64));
+                    h = max(h, __shfl_xor(h, o, 64));
+                }
+                // lanes 32-63 hold p0 only; every lane ends with the reduction of its own half, use the lower one
+                lo[d] = __shfl(l, 0, 64);
+                hi[d] = __shfl(h, 0, 64);
             }
         }
         if (lane < 3) {

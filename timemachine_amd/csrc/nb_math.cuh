@@ -7,7 +7,7 @@
 // (the exclusion kernel must reproduce the tile kernel's bits).  Coefficients: tools/gen_math_coeffs.py (Chebyshev
 // interpolation at 60 digits); degrees chosen so that every piece stays <= 3e-11 (erfcx 1.7e-11 relative, exp 1.1e-12,
 // sin 2.7e-11 / cos 7.5e-13 absolute; the script reports them) -- more than two orders of magnitude inside the 1e-8
-// contract on forces, and below the 4e-11 the rest of the f64 arithmetic (rsqrt Newton steps, summation order) leaves.
+// contract on forces, and below the 4e-11 the rest of the f64 arithmetic (summation order, fixed-point rounding) leaves.
 #pragma once
 #include "nb_math_coeffs.h"
 
@@ -77,11 +77,19 @@ template <int N> __device__ __forceinline__ double tm_poly_eo(const double (&c)[
     return __builtin_fma(o, x, e);
 }
 
-// 1/sqrt(x): hardware estimate (~2^-23) + two Newton steps  y <- y + y (1/2 - x y^2 / 2)
+// Newton steps on top of the hardware rsq / rcp estimates.  v_rsq_f64 / v_rcp_f64 are good to ~2^-23 relative, so ONE
+// step lands at ~2e-14 (error squared, times 3/2 for rsqrt) -- three orders of magnitude below the 3e-11 the polynomials
+// leave; the second step bought nothing measurable (force error 3.94e-11 with one or two) and cost 6 f64 VALU
+// instructions per pair (-2 us on the tile kernel).
+#ifndef TM_NR_STEPS
+#define TM_NR_STEPS 1
+#endif
+
+// 1/sqrt(x): hardware estimate + Newton  y <- y + y (1/2 - x y^2 / 2)
 __device__ __forceinline__ double tm_rsqrt_f64(double x) {
     double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < TM_NR_STEPS; it++) {
         const double t = x * y;
         const double h = 0.5 * y;
         const double e = __builtin_fma(-t, h, 0.5);
@@ -90,11 +98,11 @@ __device__ __forceinline__ double tm_rsqrt_f64(double x) {
     return y;
 }
 
-// 1/x: hardware estimate + two Newton steps  y <- y + y (1 - x y)
+// 1/x: hardware estimate + Newton  y <- y + y (1 - x y)
 __device__ __forceinline__ double tm_rcp_f64(double x) {
     double y = __builtin_amdgcn_rcp(x);
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < TM_NR_STEPS; it++) {
         const double e = __builtin_fma(-x, y, 1.0);
         y = __builtin_fma(y, e, y);
     }

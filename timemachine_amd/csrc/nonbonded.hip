@@ -261,7 +261,7 @@ void Neighborlist<Real>::build_device(
     // one wave per block (4 per workgroup); the same threads also copy the coordinate snapshot grid-stride
     int grid = std::min(std::max(ceil_divide(total_blocks, tpb / 64), 1), 2048);
     const int dummy_flag_force = d_flag ? force : 1;
-    k_block_bounds<Real><<<grid, tpb, 0, stream>>>(
+    k_block_bounds<Real, false><<<grid, tpb, 0, stream>>>(
         ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
         d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
         d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
@@ -327,7 +327,7 @@ void Neighborlist<Real>::compute_block_bounds_host(
     const int ncb = this->num_column_blocks();
     const int nrb = this->num_row_blocks();
     const int total_blocks = ncb + (ut ? 0 : nrb);
-    k_block_bounds<Real><<<std::max(ceil_divide(total_blocks, DEFAULT_TPB / 64), 1), DEFAULT_TPB, 0, 0>>>(
+    k_block_bounds<Real, true><<<std::max(ceil_divide(total_blocks, DEFAULT_TPB / 64), 1), DEFAULT_TPB, 0, 0>>>(
         ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_scratch_gathered_.data,
         d_box.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, 0, nullptr, nullptr, nullptr,
         reinterpret_cast<const int *>(d_counters_.data), 1);
@@ -474,10 +474,30 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     if (empty_) {
         return false; // nothing to hand over; the caller falls back to execute_device (a no-op)
     }
-    this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream);
+    // positions pre-gathered by the consumer of the previous deferred call are usable iff they were made from exactly
+    // these inputs and the order they were written in still stands (no re-sort, no forced rebuild on this call)
+    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
+                             calls_since_sort_ % steps_per_sort_ != 0;
+    this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream, pregathered);
     out.g_du_dx = d_g_du_dx_.data;
     out.slot_of_atom = d_slot_of_atom_.data;
+    out.owner = this;
+    out.next.gathered = d_gathered_.data;
+    out.next.real_bytes = static_cast<int>(sizeof(Real));
+    out.next.snap_x = d_snap_x_.data;
+    out.next.pad2_quarter = 0.25 * nblist_padding_ * nblist_padding_;
+    out.next.flag_set = d_flags_.data + parity_; // run_pipeline has already advanced parity_: the NEXT call's pair
+    out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
+    out.next.g_du_dx = d_g_du_dx_.data;
+    offer_p_ = d_p;
     return true;
+}
+
+template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const double *d_x, const double *d_box) {
+    pre_valid_ = true;
+    pre_x_ = d_x;
+    pre_box_ = d_box;
+    pre_p_ = offer_p_;
 }
 
 template <typename Real>
@@ -506,8 +526,9 @@ template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, 
 template <typename Real>
 void NonbondedAllPairs<Real>::run_pipeline(
     const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx,
-    hipStream_t stream) {
+    hipStream_t stream, const bool pregathered) {
     const int tpb = DEFAULT_TPB;
+    pre_valid_ = false; // consumed by this call or stale after it
 
     // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
     int force = force_rebuild_ ? 1 : 0;
@@ -526,12 +547,16 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (b) K1: displacement check against the last build's snapshot + gather into Hilbert order.  The rebuild flag
     // lives on the device and is consumed on the device: the host never waits for it (the reference blocks on a
     // pinned-memory flag every call, nonbonded_all_pairs.cu:217-236).
+    // On MD steps K1 is not launched at all: the integrator's update kernel has already written the new positions into
+    // `gathered`, made the displacement test and zeroed the accumulator it consumed (PregatherTarget).
     int *flag_now = d_flags_.data + parity_;
     int *flag_next = d_flags_.data + (parity_ ^ 1);
-    k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
-        K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
-        flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_slot_of_atom_.data);
-    HIP_CHECK(hipGetLastError());
+    if (!pregathered) {
+        k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
+            K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
+            flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_slot_of_atom_.data);
+        HIP_CHECK(hipGetLastError());
+    }
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     nblist_.build_device(

@@ -188,6 +188,7 @@ void BoundPotential::set_params(const std::vector<double> &params) {
         d_p.copy_from(params.data());
     }
     this->size = params.size();
+    this->potential->invalidate_cached_inputs(); // new values behind the same device pointer
 }
 
 void BoundPotential::set_params_device(const int new_size, const double *d_new_params, hipStream_t stream) {
@@ -197,6 +198,7 @@ void BoundPotential::set_params_device(const int new_size, const double *d_new_p
     }
     HIP_CHECK(hipMemcpyAsync(d_p.data, d_new_params, new_size * sizeof(double), hipMemcpyDeviceToDevice, stream));
     this->size = new_size;
+    this->potential->invalidate_cached_inputs();
 }
 
 void BoundPotential::execute_device(
