@@ -41,6 +41,34 @@ template <typename Real> struct TileWaves {
 #endif
     static const int value = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : TM_TILE_WAVES_F32;
 };
+// Workgroup shape of the tile kernel.  f64: one workgroup owns a whole CU (12 waves = 3 per SIMD); f32: five 4-wave
+// workgroups per CU (one wave per SIMD each); registers and the per-wave LDS footprint admit exactly that many.  Its waves draw work items from a
+// pool that belongs to the workgroup through an LDS ticket counter: static, cost-sorted pools across CUs (sums over
+// ~48 items are even to ~2 %), dynamic within a CU (a wave that finishes early takes the next item instead of idling
+// while its three SIMD neighbours work on).  The du_dp variants need more LDS per wave: f32 runs them as one 16-wave
+// workgroup per CU.  -DTM_TILE_STATIC: one wave per workgroup = the purely static deal (kept for A/B measurements).
+template <typename Real, bool DU_DP> struct TileShape {
+#ifdef TM_TILE_STATIC
+    static const int waves = 1;
+    static const int wgs_per_cu = 4 * TileWaves<Real>::value;
+    static const int min_waves = TileWaves<Real>::value;
+#else
+    // a workgroup's waves are spread over the four SIMDs in dispatch order, so only multiples of four waves tile a CU
+    // exactly (two 10-wave workgroups do not fit: 3+3+2+2 twice overfills a SIMD's register file)
+    static const int waves = sizeof(Real) == 8 ? 4 * TM_TILE_WAVES_F64 : (DU_DP ? 16 : 4);
+    static const int wgs_per_cu = sizeof(Real) == 8 ? 1 : (DU_DP ? 1 : TM_TILE_WAVES_F32);
+    static const int min_waves = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : (DU_DP ? 4 : TM_TILE_WAVES_F32);
+#endif
+    static const int waves_per_cu = waves * wgs_per_cu;
+};
+// LDS traffic of the tile kernel is private to a wave: program order plus a compiler fence is all the synchronisation
+// there is (LDS serves one wave's requests in order).  Never a workgroup barrier -- the waves of a workgroup are at
+// unrelated points of unrelated items.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 static const int NB_CHUNK = 64;        // columns per work item == wave width
 static const int NB_SHARDS = 4;        // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
 static const int NB_CLASSES = 16;      // work items are bucketed by cost (estimated interacting pairs), heaviest first
@@ -171,7 +199,7 @@ template <typename Real> struct TileRegs {
 };
 
 template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP>
-__global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
+__global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (TileShape<Real, COMPUTE_DU_DP>::min_waves)) void k_nonbonded_tiles(
     const int K,                               // atoms in `gathered` (record K is an all-zero sentinel)
     const int NR,                              // number of row atoms
     const int upper_triangular,                // rows == cols == all: keep only row < col
@@ -186,17 +214,38 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
     long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
-    __shared__ Real s_row[7][TILE];
-    __shared__ Real s_col[7][NB_CHUNK];
-    __shared__ unsigned int s_rowatom[TILE];
-    __shared__ u64 s_fi[COMPUTE_DU_DX ? 3 : 1][TILE];
-    __shared__ u64 s_fj[COMPUTE_DU_DX ? 3 : 1][NB_CHUNK];
-    __shared__ u64 s_pi[COMPUTE_DU_DP ? 4 : 1][TILE];
-    __shared__ u64 s_pj[COMPUTE_DU_DP ? 4 : 1][NB_CHUNK];
-    __shared__ unsigned short s_queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // up to 4 rounds are appended between drains
-    __shared__ float4 s_rowf[TILE]; // phase-1 copy of the row atoms: (x, y, z, w) relative to the tile origin, f32
+    constexpr int WAVES = TileShape<Real, COMPUTE_DU_DP>::waves;
+    struct WaveLds { // one wave's private scratch
+        float4 rowf[TILE]; // phase-1 copy of the row atoms: (x, y, z, w) relative to the tile origin, f32
+        Real row[7][TILE];
+        Real col[7][NB_CHUNK];
+        u64 fi[COMPUTE_DU_DX ? 3 : 1][TILE];
+        u64 fj[COMPUTE_DU_DX ? 3 : 1][NB_CHUNK];
+        u64 pi[COMPUTE_DU_DP ? 4 : 1][TILE];
+        u64 pj[COMPUTE_DU_DP ? 4 : 1][NB_CHUNK];
+        unsigned int rowatom[TILE];
+        unsigned short queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // up to 4 rounds are appended between drains
+    };
+    __shared__ WaveLds s_wave[WAVES];
+    __shared__ unsigned int s_ticket; // next position of this workgroup's pool
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const unsigned int global_wave = blockIdx.x * WAVES + wave, total_waves = gridDim.x * WAVES;
+    WaveLds &lds = s_wave[wave];
+    auto &s_rowf = lds.rowf;
+    auto &s_row = lds.row;
+    auto &s_col = lds.col;
+    auto &s_fi = lds.fi;
+    auto &s_fj = lds.fj;
+    auto &s_pi = lds.pi;
+    auto &s_pj = lds.pj;
+    auto &s_rowatom = lds.rowatom;
+    auto &s_queue = lds.queue;
+    if (threadIdx.x == 0) {
+        s_ticket = 0;
+    }
+    __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
@@ -210,9 +259,15 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 
     // Work distribution.  Work items differ in cost by an order of magnitude (0..2048 interacting pairs) and a wave only
     // processes a handful.  The neighbor-list build files every item into bucket (shard, cost class); the cost-sorted order
-    // is the concatenation of the buckets, heaviest class first, and it is dealt to the (persistent, one-per-slot) waves
-    // statically.  Dynamic ticket counters were measured and rejected: a returning global atomic queues behind the wave's
-    // own flush atomics at the memory side and came back 10-40 us later, doubling the kernel's duration.
+    // is the concatenation of the buckets, heaviest class first.  It is dealt statically to the (persistent) workgroups
+    // -- one pool per CU -- and dynamically, heaviest first, to the waves of a workgroup (TileShape).  Device-wide dynamic
+    // ticket counters were measured and rejected: a returning global atomic queues behind the wave's own flush atomics at
+    // the memory side and came back 10-40 us later, doubling the kernel's duration.  A purely static deal to single waves
+    // (the previous scheme) left the waves ending anywhere between 55 % and 100 % of the launch, because every item also
+    // carries ~17k cycles of fixed cost and a wave only gets 3-5 of them; pools took the f64 launch from 93 to 90 us.
+    // (Also measured: the XCDs differ in speed by 8 % for f64 / up to 35 % for f32 tiles on a fixed frame, XCDs 3 and 5
+    // slowest on three boards; shares adapted from the workgroups' measured durations did not pay in MD, where the slow
+    // half of the chip changes every few hundred steps.)
     //
     // Software pipeline over items.  Fetching an item is a chain of dependent memory operations
     //   items[] -> col_atoms[] -> gathered[]
@@ -237,14 +292,18 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         bucket_end = v;
     }
     const unsigned int n_items_total = __shfl(bucket_end, 63, 64);
-    unsigned int next_round = 0;
     auto next_position = [&]() -> unsigned int {
-        // serpentine deal: even rounds left to right, odd rounds right to left, so the wave that drew the heaviest item of
-        // one round draws the lightest of the next
-        const unsigned int w = (next_round & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
-        const unsigned int t = next_round * gridDim.x + w;
-        next_round++;
-        return t;
+        // The pool of workgroup b: round r of the cost-sorted order contributes position r * G + (r even ? b : G-1-b)
+        // (serpentine deal over the G workgroups: the one that drew the heaviest item of a round draws the lightest of
+        // the next).  Rounds are handed to the waves in order, heaviest first, by an LDS ticket: a CU-local returning
+        // atomic (~100 cycles), unlike a global one, which queues behind the wave's own flush atomics (10-40 us).
+        unsigned int r = 0;
+        if (lane == 0) {
+            r = atomicAdd(&s_ticket, 1u);
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        const unsigned int w = (r & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        return r * gridDim.x + w;
     };
     auto position_to_slot = [&](unsigned int g) -> unsigned int {
         if (g >= n_items_total) {
@@ -291,9 +350,8 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 #define TM_T(var)
 #endif
 
-    // prologue: first item fetched the slow way; the position of the second one is already known
+    // prologue: first item fetched the slow way
     unsigned int item = position_to_slot(next_position());
-    unsigned int item_next = position_to_slot(next_position());
     TileRegs<Real> cur;
     if (item != NO_ITEM) {
         load_indices(items[item], cur);
@@ -307,7 +365,8 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
             // loads with little arithmetic) and the SIMD's other waves are computing.  Measured alternatives: at the
             // end of the wave, or in extra workgroups appended / prepended to the grid -- all slower (f32: this placement
             // costs nothing, the others 8-10 us per launch).
-            for (int t = static_cast<int>(gridDim.x - 1 - blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(gridDim.x)) {
+            // slice t goes to workgroup t % G, wave (t / G) % WAVES: every CU takes the same share
+            for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
                 fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx);
             }
         }
@@ -315,13 +374,14 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 
     while (item != NO_ITEM) {
         TM_T(t_a);
-        // ---- stage A
+        // ---- stage A: draw the next item now (one item of lookahead: a drained pool leaves every wave at most the item
+        // it has already drawn, and those are the lightest of the pool)
+        const unsigned int item_next = position_to_slot(next_position());
         const bool have_next = item_next != NO_ITEM;
         int4 it_next = make_int4(0, 0, 0, 0);
         if (have_next) {
             it_next = items[item_next];
         }
-        const unsigned int item_after = position_to_slot(next_position());
         TileRegs<Real> nxt;
         nxt.ja = uK;
         nxt.ra = uK;
@@ -329,7 +389,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
         // ---- current item: registers -> LDS
         const int rb = cur.rb;
         const unsigned int ja = cur.ja;
-        __syncthreads(); // previous item's flush has finished reading LDS
+        wave_lds_sync(); // previous item's flush has finished reading LDS
         float4 s_rowf_mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // lanes 0-31: this lane's row atom, as stored in s_rowf
         TM_T(t_a2);
         if (lane < TILE) {
@@ -397,7 +457,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
             s_pj[2][lane] = 0;
             s_pj[3][lane] = 0;
         }
-        __syncthreads();
+        wave_lds_sync();
 
         TM_T(t_b);
 #ifdef TM_TIMING
@@ -465,7 +525,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
                 TM_T(t_h0);
                 const int n = cnt < NB_CHUNK ? cnt : NB_CHUNK;
                 const int base = cnt - n;
-                __syncthreads();
+                wave_lds_sync();
                 if (lane < n) {
                     const unsigned int e = s_queue[base + lane];
                     const int pi = e >> 8, pj = e & 0xff;
@@ -518,7 +578,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
                 }
                 cnt = base;
 #ifdef TM_TIMING
-                __syncthreads();
+                wave_lds_sync();
                 tm_p2_item += clock64() - t_h0;
                 tm_batches++;
 #endif
@@ -532,7 +592,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
             load_indices(it_next, nxt);
             load_records(nxt);
         }
-        __syncthreads();
+        wave_lds_sync();
         TM_T(t_c);
 
         // ---- flush: one global atomic per touched (atom, component)
@@ -591,11 +651,10 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
 #endif
         cur = nxt;
         item = item_next;
-        item_next = item_after;
     }
 #ifdef TM_TIMING
     if (lane == 0 && timing) {
-        long long *t = timing + static_cast<size_t>(blockIdx.x) * 8;
+        long long *t = timing + static_cast<size_t>(global_wave) * 8;
         t[0] = tm_setup;
         t[1] = tm_p1;
         t[2] = tm_p2;
@@ -610,7 +669,7 @@ __global__ __launch_bounds__(64, TileWaves<Real>::value) void k_nonbonded_tiles(
     if constexpr (COMPUTE_U) {
         const i128 total = wave_sum_i128(energy);
         if (lane == 0) {
-            u_partials[blockIdx.x] = total;
+            u_partials[global_wave] = total;
         }
     }
 }

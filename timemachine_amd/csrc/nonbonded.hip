@@ -420,7 +420,8 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     HIP_CHECK(hipMemset(d_flags_.data, 0, d_flags_.size()));
     d_slot_of_atom_.realloc(N_);
     HIP_CHECK(hipMemset(d_slot_of_atom_.data, 0xff, d_slot_of_atom_.size())); // -1: no atom is ours until K1 says so
-    // persistent grid: one wave per workgroup, TileWaves<Real> waves per SIMD on every CU
+    // persistent grid: TileWaves<Real> waves per SIMD on every CU, grouped into one or two workgroups per CU
+    // (TileShape); grid_ = waves of the forces-only launch = the most any variant launches
     grid_ = device_cu_count() * 4 * TileWaves<Real>::value;
     d_timing_.realloc(static_cast<size_t>(grid_) * 8);
     HIP_CHECK(hipMemset(d_timing_.data, 0, d_timing_.size()));
@@ -565,11 +566,14 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
 #define TM_LAUNCH_TILES(U, X, PP)                                                                                      \
-    k_nonbonded_tiles<Real, U, X, PP><<<grid_, 64, 0, stream>>>(                                                      \
+    launched_waves = n_cus * TileShape<Real, PP>::waves_per_cu;                                                        \
+    k_nonbonded_tiles<Real, U, X, PP><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
         d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, d_u_partials_.data, pig_table, pig_blocks, d_x, d_du_dx,       \
         d_timing_.data)
+    const int n_cus = grid_ / (4 * TileWaves<Real>::value);
+    int launched_waves = 0; // waves of this launch = energy partials it writes
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
     // a ForcePlan table offered through piggyback_forces() rides on the forces-only launch; any other call drops it
     // back to its owner's stand-alone path by never having accepted it (the plan only offers it for forces-only calls)
@@ -605,7 +609,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
         HIP_CHECK(hipGetLastError());
     }
     if (d_u) {
-        reduce_i128_device(d_u_partials_.data, grid_, d_u, stream);
+        reduce_i128_device(d_u_partials_.data, launched_waves, d_u, stream);
     }
     calls_since_sort_++;
     parity_ ^= 1;
