@@ -163,7 +163,10 @@ void LangevinIntegrator<Real>::step_fwd(
     const DeferredForces none;
     const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
-    const int tpb = 256;
+#ifndef TM_BAOAB_TPB
+#define TM_BAOAB_TPB 64 // 368 small workgroups reach every CU: the kernel is a latency chain per atom, not a throughput problem
+#endif
+    const int tpb = TM_BAOAB_TPB;
     // every atom moves (no local-MD index list): the update kernel can leave the producers' next gather done
     const PregatherTarget no_target;
     const bool pregather = d_idxs == nullptr;
