@@ -965,6 +965,60 @@ def test_context_multiple_steps_semantics(co, P):
         co.Context(s.coords, v0[:-1], s.box, LangevinIntegrator(300.0, 1e-3, 1.0, s.masses, 1).impl(), [])
 
 
+@pytest.mark.parametrize("precision", [np.float32, np.float64])
+def test_pregathered_steps_are_bitwise_the_full_path(co, P, precision):
+    """On MD steps the integrator's update kernel leaves the nonbonded gather done (positions into the sorted records,
+    rebuild test, accumulator zeroed) and check+gather is not launched.  Everything that can make those inputs stale has
+    to drop them: over 330 steps (rebuilds every few steps, three Hilbert re-sorts) a context stepped in one go, a
+    context whose coordinates are re-set before every step (always the full path), one whose potentials are also
+    evaluated from outside between steps, and one whose parameters are swapped and swapped back must agree bit for bit."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    N = s.num_atoms
+    rng = np.random.default_rng(11)
+    v0 = rng.normal(size=(N, 3)) * 0.3
+
+    def make():
+        bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s)]
+        return co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.5e-3, 1.0, s.masses, 99).impl(), bps), bps
+
+    n_steps = 330
+    ref, _ = make()
+    xs_ref, _ = ref.multiple_steps(n_steps, 10)
+
+    full, _ = make()  # set_x_t invalidates the pre-gathered inputs: every step gathers itself
+    outside, bps_o = make()  # an external call into the shared potentials between steps
+    swapped, bps_s = make()  # parameters replaced behind the same device pointer, then restored
+    nb_idx = [i for i, bp in enumerate(ts.bound_potentials(s)) if type(bp.potential).__name__ == "Nonbonded"][0]
+    nb_params = np.asarray(ts.bound_potentials(s)[nb_idx].params)
+    for k in range(n_steps):
+        full.set_x_t(full.get_x_t())
+        full.step()
+        if k % 7 == 3:
+            bps_o[nb_idx].execute(s.coords + 0.01, s.box, True, True)
+        outside.step()
+        if k % 11 == 5:
+            bps_s[nb_idx].set_params(nb_params * 0.5)
+            bps_s[nb_idx].set_params(nb_params)
+        swapped.step()
+        if (k + 1) % 10 == 0:
+            frame = xs_ref[(k + 1) // 10 - 1]
+            np.testing.assert_array_equal(full.get_x_t(), frame)
+            np.testing.assert_array_equal(outside.get_x_t(), frame)
+            np.testing.assert_array_equal(swapped.get_x_t(), frame)
+    np.testing.assert_array_equal(full.get_v_t(), ref.get_v_t())
+    # a parameter change that is NOT undone must show (the stale gathered records would hide it)
+    changed, bps_c = make()
+    changed.multiple_steps(20, 0)
+    bps_c[nb_idx].set_params(nb_params * np.array([0.0, 1.0, 1.0, 1.0]))  # charges off
+    changed.multiple_steps(20, 0)
+    ref2, _ = make()
+    ref2.multiple_steps(40, 0)
+    assert not np.array_equal(changed.get_x_t(), ref2.get_x_t())
+
+
 def test_langevin_thermostat_statistics(co, P):
     """Statistical parity for the stochastic part (cuRAND streams cannot be matched): ideal gas (no potentials) with
     friction reaches kT per degree of freedom; the noise has zero mean, unit variance and no lag-1 correlation."""
