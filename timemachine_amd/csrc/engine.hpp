@@ -50,7 +50,7 @@ struct FusedTable {
     FusedSegment seg[FUSED_MAX_SEGMENTS];
 };
 // A force contribution left in a potential's own (sorted) accumulator instead of being scattered into du_dx: the
-// consumer adds g_du_dx[slot_of_atom[a] * 3 + d] for every atom a with slot_of_atom[a] >= 0.  Lets the integrator's
+// consumer adds g_du_dx[d * stride + slot_of_atom[a]] for every atom a with slot_of_atom[a] >= 0.  Lets the integrator's
 // update kernel pick the nonbonded forces up directly (one launch and one pass over du_dx less per step).
 // What the consumer needs to leave the producer's NEXT gather already done while it moves the atoms (the integrator's
 // update kernel touches every atom anyway): the new position goes straight into the producer's sorted record, the
@@ -65,10 +65,12 @@ struct PregatherTarget {
     int *flag_set = nullptr;        // rebuild flag of the producer's next call
     int *flag_clear = nullptr;      // flag of the call that has just been consumed
     u64 *g_du_dx = nullptr;         // the accumulator handed over in DeferredForces (to be zeroed slot by slot)
+    int stride = 0;                 // its component stride
 };
 class Potential;
 struct DeferredForces {
-    const u64 *g_du_dx = nullptr;
+    const u64 *g_du_dx = nullptr;       // component-major: component d of slot s at [d * stride + s]
+    int stride = 0;
     const int *slot_of_atom = nullptr;
     PregatherTarget next;       // gathered == nullptr: the producer does not take pre-gathered positions
     Potential *owner = nullptr; // to be told (pregather_committed) once a kernel filling `next` has been enqueued
@@ -439,7 +441,8 @@ protected:
     std::unique_ptr<HilbertSort> hilbert_;
     DeviceBuffer<unsigned int> d_atom_idxs_, d_perm_;
     DeviceBuffer<Real> d_gathered_;
-    DeviceBuffer<u64> d_g_du_dx_, d_g_du_dp_;
+    DeviceBuffer<u64> d_g_du_dx_, d_g_du_dp_; // sorted accumulators, component-major with stride acc_stride_
+    int acc_stride_ = 0;
     DeviceBuffer<double> d_snap_x_, d_snap_box_;
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;

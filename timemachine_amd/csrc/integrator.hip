@@ -56,9 +56,9 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
     if (static_cast<double>(d2) > t.pad2_quarter) {
         *t.flag_set = 1; // benign race: every writer stores the same value
     }
-    t.g_du_dx[static_cast<size_t>(slot) * 3 + 0] = 0;
-    t.g_du_dx[static_cast<size_t>(slot) * 3 + 1] = 0;
-    t.g_du_dx[static_cast<size_t>(slot) * 3 + 2] = 0;
+    t.g_du_dx[0 * static_cast<size_t>(t.stride) + slot] = 0;
+    t.g_du_dx[1 * static_cast<size_t>(t.stride) + slot] = 0;
+    t.g_du_dx[2 * static_cast<size_t>(t.stride) + slot] = 0;
 }
 
 __device__ __forceinline__ void pregather_atom(const PregatherTarget &t, const int slot, const int atom, const double xn, const double yn, const double zn) {
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
     const unsigned long long seed, const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t,
     u64 *__restrict__ du_dx, const Real dt,
     // up to two force contributions picked up from their producers' sorted accumulators (DeferredForces); nullptr = none
-    const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1, const int *__restrict__ slot1,
+    // (component-major: component d of slot s at g[d * stride + s])
+    const u64 *__restrict__ g0, const int *__restrict__ slot0, const int stride0, const u64 *__restrict__ g1,
+    const int *__restrict__ slot1, const int stride1,
     // where to leave the producers' next gather (gathered == nullptr: not wanted)
     const PregatherTarget pg0, const PregatherTarget pg1) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -108,10 +110,10 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
             for (int d = 0; d < 3; d++) {
                 u64 f = du_dx[atom * 3 + d]; // wrapping integer sum: same bits as a scatter-add into du_dx would give
                 if (s0 >= 0) {
-                    f += g0[static_cast<size_t>(s0) * 3 + d];
+                    f += g0[static_cast<size_t>(d) * stride0 + s0];
                 }
                 if (s1 >= 0) {
-                    f += g1[static_cast<size_t>(s1) * 3 + d];
+                    f += g1[static_cast<size_t>(d) * stride1 + s1];
                 }
                 const Real force = -fixed_to_float<Real>(f);
                 const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
@@ -172,7 +174,7 @@ void LangevinIntegrator<Real>::step_fwd(
     const bool pregather = d_idxs == nullptr;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
         N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_, df0.g_du_dx, df0.slot_of_atom,
-        df1.g_du_dx, df1.slot_of_atom, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
+        df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
     HIP_CHECK(hipGetLastError());
     if (pregather) {
         for (const DeferredForces &df : deferred_) {
@@ -189,8 +191,8 @@ void LangevinIntegrator<Real>::step_fwd(
 template <int MODE>
 __global__ __launch_bounds__(256) void k_velocity_verlet(
     const int N, const unsigned int *__restrict__ idxs, const double *__restrict__ cbs, double *__restrict__ x_t, double *__restrict__ v_t,
-    u64 *__restrict__ du_dx, const double dt, const u64 *__restrict__ g0, const int *__restrict__ slot0, const u64 *__restrict__ g1,
-    const int *__restrict__ slot1) {
+    u64 *__restrict__ du_dx, const double dt, const u64 *__restrict__ g0, const int *__restrict__ slot0, const int stride0,
+    const u64 *__restrict__ g1, const int *__restrict__ slot1, const int stride1) {
     const int kidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (kidx >= N) {
         return;
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(256) void k_velocity_verlet(
     for (int d = 0; d < 3; d++) {
         u64 f = du_dx[atom * 3 + d];
         if (s0 >= 0) {
-            f += g0[static_cast<size_t>(s0) * 3 + d];
+            f += g0[static_cast<size_t>(d) * stride0 + s0];
         }
         if (s1 >= 0) {
-            f += g1[static_cast<size_t>(s1) * 3 + d];
+            f += g1[static_cast<size_t>(d) * stride1 + s1];
         }
         const double force = fixed_to_float<double>(f);
         const double v = v_t[atom * 3 + d] + cb * force;
@@ -247,7 +249,7 @@ void VelocityVerletIntegrator::forces_then_update(
     const int tpb = 256, blocks = ceil_divide(N_, tpb);
 #define TM_VV(MODE)                                                                                                    \
     k_velocity_verlet<MODE><<<blocks, tpb, 0, stream>>>(                                                               \
-        N_, d_idxs, d_cbs_.data, d_x_t, d_v_t, d_du_dx_.data, dt_, a.g_du_dx, a.slot_of_atom, b.g_du_dx, b.slot_of_atom)
+        N_, d_idxs, d_cbs_.data, d_x_t, d_v_t, d_du_dx_.data, dt_, a.g_du_dx, a.slot_of_atom, a.stride, b.g_du_dx, b.slot_of_atom, b.stride)
     if (mode == 0) {
         TM_VV(0);
     } else if (mode == 1) {

@@ -111,7 +111,7 @@ __global__ void k_check_gather(
     const double *__restrict__ box, const double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double pad2_quarter, // 0.25 * padding^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp, int *__restrict__ slot_of_atom) {
+    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
@@ -147,28 +147,29 @@ __global__ void k_check_gather(
     g[5] = static_cast<Real>(p[a * 4 + 1]); // sig
     g[6] = static_cast<Real>(p[a * 4 + 2]); // eps
     g[7] = 0;
+    // sorted accumulators are component-major (component c of slot i at [c * acc_stride + i]): see the flush of the tile kernel
     if (g_du_dx) {
-        g_du_dx[idx * 3 + 0] = 0;
-        g_du_dx[idx * 3 + 1] = 0;
-        g_du_dx[idx * 3 + 2] = 0;
+        g_du_dx[0 * acc_stride + idx] = 0;
+        g_du_dx[1 * acc_stride + idx] = 0;
+        g_du_dx[2 * acc_stride + idx] = 0;
     }
     if (g_du_dp) {
-        g_du_dp[idx * 4 + 0] = 0;
-        g_du_dp[idx * 4 + 1] = 0;
-        g_du_dp[idx * 4 + 2] = 0;
-        g_du_dp[idx * 4 + 3] = 0;
+        g_du_dp[0 * acc_stride + idx] = 0;
+        g_du_dp[1 * acc_stride + idx] = 0;
+        g_du_dp[2 * acc_stride + idx] = 0;
+        g_du_dp[3 * acc_stride + idx] = 0;
     }
 }
 
 // ---- K5: un-permute (reference: k_scatter_accum, k_nonbonded.cuh:86-104) ------------------------------------
 template <int D>
-__global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ perm, const u64 *__restrict__ g, u64 *__restrict__ out) {
+__global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ perm, const u64 *__restrict__ g, const int acc_stride, u64 *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= K * D) {
         return;
     }
-    const int a = idx / D, d = idx - a * D;
-    const u64 v = g[idx];
+    const int d = idx / K, a = idx - d * K; // component-major source: consecutive threads read consecutive slots
+    const u64 v = g[static_cast<size_t>(d) * acc_stride + a];
     if (v != 0) {
         atomicAdd(out + static_cast<size_t>(perm[a]) * D + d, v);
     }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const unsigned int items_cap,                  // bucket capacity: bucket b lives at items[b * items_cap ...]
     const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, i128 *__restrict__ u_partials,
+    u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, const int acc_stride, i128 *__restrict__ u_partials,
     // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
     const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
@@ -599,13 +600,17 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #if defined(TM_ABLATE) && TM_ABLATE == 3
         if (false) // ablation: no global flush
 #endif
+        // The accumulators are component-major: a flush instruction's 64 lanes then touch 8 cache lines (8 consecutive u64
+        // each) instead of 24 with (x, y, z) interleaved per atom.  Global atomics are executed at the memory side one
+        // cache-line request at a time -- 3.5 M of them per launch took 66 us back to back interleaved, 28 us component-major
+        // (scripts/microbench/atomic_scope.hip); scattered atoms: 165 us.
         if constexpr (COMPUTE_DU_DX) {
             for (int t = lane; t < TILE * 3; t += 64) {
-                const int a = t / 3, c = t - a * 3;
+                const int c = t / TILE, a = t - c * TILE;
                 const u64 v = s_fi[c][a];
                 const unsigned int ra = s_rowatom[a];
                 if (v != 0 && ra < uK) {
-                    atomicAdd(g_du_dx + static_cast<size_t>(ra) * 3 + c, v);
+                    atomicAdd(g_du_dx + static_cast<size_t>(c) * acc_stride + ra, v);
                 }
             }
             if (ja < uK) {
@@ -613,18 +618,18 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 for (int c = 0; c < 3; c++) {
                     const u64 v = s_fj[c][lane];
                     if (v != 0) {
-                        atomicAdd(g_du_dx + static_cast<size_t>(ja) * 3 + c, v);
+                        atomicAdd(g_du_dx + static_cast<size_t>(c) * acc_stride + ja, v);
                     }
                 }
             }
         }
         if constexpr (COMPUTE_DU_DP) {
             for (int t = lane; t < TILE * 4; t += 64) {
-                const int a = t >> 2, c = t & 3;
+                const int c = t / TILE, a = t - c * TILE;
                 const u64 v = s_pi[c][a];
                 const unsigned int ra = s_rowatom[a];
                 if (v != 0 && ra < uK) {
-                    atomicAdd(g_du_dp + static_cast<size_t>(ra) * 4 + c, v);
+                    atomicAdd(g_du_dp + static_cast<size_t>(c) * acc_stride + ra, v);
                 }
             }
             if (ja < uK) {
@@ -632,7 +637,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 for (int c = 0; c < 4; c++) {
                     const u64 v = s_pj[c][lane];
                     if (v != 0) {
-                        atomicAdd(g_du_dp + static_cast<size_t>(ja) * 4 + c, v);
+                        atomicAdd(g_du_dp + static_cast<size_t>(c) * acc_stride + ja, v);
                     }
                 }
             }

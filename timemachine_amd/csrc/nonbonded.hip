@@ -410,8 +410,9 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     d_atom_idxs_.realloc(N_);
     d_perm_.realloc(N_);
     d_gathered_.realloc(static_cast<size_t>(N_ + 1) * 8); // + one all-zero sentinel record
-    d_g_du_dx_.realloc(static_cast<size_t>(N_) * 3);
-    d_g_du_dp_.realloc(static_cast<size_t>(N_) * 4);
+    acc_stride_ = (N_ + 7) & ~7; // every component array starts on a 64-byte line
+    d_g_du_dx_.realloc(static_cast<size_t>(acc_stride_) * 3);
+    d_g_du_dp_.realloc(static_cast<size_t>(acc_stride_) * 4);
     d_snap_x_.realloc(static_cast<size_t>(N_) * 3);
     d_snap_box_.realloc(9);
     HIP_CHECK(hipMemset(d_snap_x_.data, 0, d_snap_x_.size()));
@@ -481,6 +482,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
                              calls_since_sort_ % steps_per_sort_ != 0;
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream, pregathered);
     out.g_du_dx = d_g_du_dx_.data;
+    out.stride = acc_stride_;
     out.slot_of_atom = d_slot_of_atom_.data;
     out.owner = this;
     out.next.gathered = d_gathered_.data;
@@ -490,6 +492,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     out.next.flag_set = d_flags_.data + parity_; // run_pipeline has already advanced parity_: the NEXT call's pair
     out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
     out.next.g_du_dx = d_g_du_dx_.data;
+    out.next.stride = acc_stride_;
     offer_p_ = d_p;
     return true;
 }
@@ -555,7 +558,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     if (!pregathered) {
         k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
-            flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, d_slot_of_atom_.data);
+            flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
         HIP_CHECK(hipGetLastError());
     }
 
@@ -570,7 +573,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     k_nonbonded_tiles<Real, U, X, PP><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
-        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, d_u_partials_.data, pig_table, pig_blocks, d_x, d_du_dx,       \
+        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, d_du_dx, \
         d_timing_.data)
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
     int launched_waves = 0; // waves of this launch = energy partials it writes
@@ -601,11 +604,11 @@ void NonbondedAllPairs<Real>::run_pipeline(
 
     // (e) K5: back to the caller's atom order
     if (d_du_dx && scatter_du_dx) {
-        k_scatter_accum<3><<<ceil_divide(K_ * 3, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dx_.data, d_du_dx);
+        k_scatter_accum<3><<<ceil_divide(K_ * 3, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dx_.data, acc_stride_, d_du_dx);
         HIP_CHECK(hipGetLastError());
     }
     if (d_du_dp) {
-        k_scatter_accum<4><<<ceil_divide(K_ * 4, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dp_.data, d_du_dp);
+        k_scatter_accum<4><<<ceil_divide(K_ * 4, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dp_.data, acc_stride_, d_du_dp);
         HIP_CHECK(hipGetLastError());
     }
     if (d_u) {
