@@ -32,6 +32,20 @@ __global__ void k_flush(unsigned long long *acc, const int n_atoms, const int ro
     }
 }
 
+// lanes hit u64 words `stride_words` apart (8 = one word per 64-byte line), same count of atomics
+template <int STRIDE_WORDS>
+__global__ void k_stride(unsigned long long *acc, const int n_atoms, const int rounds, unsigned int *) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned int h = wave * 2654435761u + 12345u;
+    const unsigned int span = 64u * STRIDE_WORDS;
+    for (int r = 0; r < rounds * 3; r++) {
+        h = h * 1664525u + 1013904223u;
+        const unsigned int start = ((h >> 8) % (static_cast<unsigned int>(n_atoms) * 24u - span)) & ~15u; // 128-byte aligned
+        __hip_atomic_fetch_add(acc + start + lane * STRIDE_WORDS, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int main() {
     const int n_atoms = 23559, waves = 3072, rounds = 6; // 3072 * 6 * 64 * 3 = 3.5 M atomics
     unsigned long long *acc;
@@ -68,6 +82,12 @@ int main() {
     if (run("agent, component-major (SoA)", k_flush<__HIP_MEMORY_SCOPE_AGENT, false, true>)) return 1;
     if (run("agent, scattered atoms (AoS)", k_flush<__HIP_MEMORY_SCOPE_AGENT, false, false, true>)) return 1;
     if (run("agent, scattered atoms (SoA)", k_flush<__HIP_MEMORY_SCOPE_AGENT, false, true, true>)) return 1;
+    if (run("dense: 64 lanes x 8 B (512 B)", k_stride<1>)) return 1;
+    if (run("stride 16 B (1 KB)", k_stride<2>)) return 1;
+    if (run("stride 32 B (2 KB)", k_stride<4>)) return 1;
+    if (run("stride 64 B (4 KB)", k_stride<8>)) return 1;
+    if (run("stride 128 B (8 KB)", k_stride<16>)) return 1;
+    if (run("stride 256 B (16 KB)", k_stride<32>)) return 1;
     std::vector<unsigned int> hx(waves);
     CK(hipMemcpy(hx.data(), xcc, waves * 4, hipMemcpyDeviceToHost));
     int cnt[16] = {0};

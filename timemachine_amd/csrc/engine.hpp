@@ -87,8 +87,11 @@ public:
     void add_rest(Potential *pot, const int P, const double *d_p) { rest_.push_back({pot, P, d_p}); }
     // launches everything; accumulates into d_du_dx.  With `deferred` != nullptr, up to `max_deferred` contributions may
     // be handed back un-scattered instead (see DeferredForces).
+    // d_du_dx_cm != nullptr: a second, component-major accumulator (component d of atom a at [d * cm_stride + a]) that
+    // receives the table's terms; potentials that launch their own kernels keep adding to the [N, 3] array d_du_dx.
     void run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
-             std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0);
+             std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0, u64 *d_du_dx_cm = nullptr,
+             const int cm_stride = 0);
 
 private:
     FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
@@ -106,8 +109,12 @@ public:
     // Forces-only planning hook (see ForcePlan).  Default: not fusable, executed through execute_device.
     virtual void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) { plan.add_rest(this, P, d_p); }
     // Offer of a ForcePlan table to run inside this potential's own (long) force kernel during its NEXT forces-only
-    // execute_device call, accumulating into that call's d_du_dx.  true = accepted (the plan then skips its own launch).
-    virtual bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) { return false; }
+    // execute_device call.  true = accepted (the plan then skips its own launch).
+    // The table's forces go to `acc` (component d of atom a at acc[a * atom_stride + d * comp_stride]).
+    virtual bool piggyback_forces(
+        const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) {
+        return false;
+    }
     // Forces-only evaluation that leaves the result in the potential's own accumulator (see DeferredForces) instead of
     // adding it to a du_dx array.  A piggy-backed table still accumulates into d_du_dx.  false = not supported.
     virtual bool execute_forces_deferred(
@@ -408,7 +415,7 @@ public:
     void set_atom_idxs(const std::vector<int> &atom_idxs);
     std::vector<int> get_atom_idxs();
     int get_num_atom_idxs() const { return K_; }
-    bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
+    bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     void pregather_committed(const double *d_x, const double *d_box) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
@@ -456,6 +463,8 @@ protected:
     const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
+    u64 *piggyback_acc_ = nullptr; // where the piggy-backed table's forces go, and its layout
+    int piggyback_atom_stride_ = 3, piggyback_comp_stride_ = 1;
 };
 
 // reference: cpp/src/nonbonded_interaction_group.{hpp,cu}.  Row atoms x column atoms (disjoint sets); both groups are
@@ -529,7 +538,9 @@ private:
     unsigned long long seed_;
     unsigned long long step_;
     DeviceBuffer<Real> d_cbs_, d_ccs_;
-    DeviceBuffer<u64> d_du_dx_;
+    DeviceBuffer<u64> d_du_dx_;    // [N, 3]: what potentials that launch their own kernels add to
+    int cm_stride_;
+    DeviceBuffer<u64> d_du_dx_cm_; // component-major [3][cm_stride_]: what the fused table's terms add to
     ForcePlan plan_;
     std::vector<DeferredForces> deferred_;
 };
@@ -547,7 +558,9 @@ private:
     const double dt_;
     bool initialized_;
     DeviceBuffer<double> d_cbs_;
-    DeviceBuffer<u64> d_du_dx_;
+    DeviceBuffer<u64> d_du_dx_;    // [N, 3]: what potentials that launch their own kernels add to
+    int cm_stride_;
+    DeviceBuffer<u64> d_du_dx_cm_; // component-major [3][cm_stride_]: what the fused table's terms add to
     ForcePlan plan_;
     std::vector<DeferredForces> deferred_;
     // mode 0: v += cb F, x += dt v;  1: v += cb/2 F, x += dt v;  2: v += cb/2 F

@@ -11,8 +11,9 @@ namespace tmamd {
 
 template <typename Real>
 __global__ __launch_bounds__(256) void k_fused_forces(
-    const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx) {
-    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx);
+    const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx,
+    const ForceLayout fl) {
+    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl);
 }
 
 void ForcePlan::clear() {
@@ -35,7 +36,11 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
 
 void ForcePlan::run(
     const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
-    const int max_deferred) {
+    const int max_deferred, u64 *d_du_dx_cm, const int cm_stride) {
+    // the table's terms go to the caller's component-major accumulator when there is one (lanes working on neighbouring
+    // atoms then share cache lines: fewer line requests for the memory-side atomics), to the [N, 3] array otherwise
+    u64 *table_acc = d_du_dx_cm ? d_du_dx_cm : d_du_dx;
+    const ForceLayout table_fl = d_du_dx_cm ? ForceLayout{1, cm_stride} : ForceLayout{3, 1};
     // 1. tables to the device (only when they changed since the last step)
     bool pending[2] = {false, false};
     for (int prec = 0; prec < 2; prec++) {
@@ -60,7 +65,8 @@ void ForcePlan::run(
     // 2. a long-running force kernel of the same precision may take a table along (its early-finishing waves run it)
     for (const Rest &r : rest_) {
         for (int prec = 0; prec < 2; prec++) {
-            if (pending[prec] && r.pot->piggyback_forces(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4)) {
+            if (pending[prec] &&
+                r.pot->piggyback_forces(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4, table_acc, table_fl.atom, table_fl.comp)) {
                 pending[prec] = false;
             }
         }
@@ -89,9 +95,9 @@ void ForcePlan::run(
         const int blocks = host_[prec].block_end[host_[prec].n - 1];
         const int prof = Profiler::get().begin("fused_forces", stream);
         if (prec == 1) {
-            k_fused_forces<double><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_du_dx);
+            k_fused_forces<double><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, table_acc, table_fl);
         } else {
-            k_fused_forces<float><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_du_dx);
+            k_fused_forces<float><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, table_acc, table_fl);
         }
         HIP_CHECK(hipGetLastError());
         Profiler::get().end("fused_forces", prof, stream);

@@ -78,7 +78,8 @@ template <typename Real>
 __global__ __launch_bounds__(256) void k_update_forward_baoab(
     const int N, const Real ca, const unsigned int *__restrict__ idxs, const Real *__restrict__ cbs, const Real *__restrict__ ccs,
     const unsigned long long seed, const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t,
-    u64 *__restrict__ du_dx, const Real dt,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dx_cm, const int cm_stride, // [N, 3] and component-major force accumulators
+    const Real dt,
     // up to two force contributions picked up from their producers' sorted accumulators (DeferredForces); nullptr = none
     // (component-major: component d of slot s at g[d * stride + s])
     const u64 *__restrict__ g0, const int *__restrict__ slot0, const int stride0, const u64 *__restrict__ g1,
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
             double xn[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                u64 f = du_dx[atom * 3 + d]; // wrapping integer sum: same bits as a scatter-add into du_dx would give
+                // wrapping integer sum: same bits as a scatter-add of every contribution into one array would give
+                u64 f = du_dx[atom * 3 + d] + du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
                 if (s0 >= 0) {
                     f += g0[static_cast<size_t>(d) * stride0 + s0];
                 }
@@ -122,13 +124,16 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
                 x_t[atom * 3 + d] = xn[d];
                 du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
+                du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
             }
             pregather_atom(pg0, s0, atom, xn[0], xn[1], xn[2]);
             pregather_atom(pg1, s1, atom, xn[0], xn[1], xn[2]);
         } else if (idxs != nullptr) {
-            du_dx[kidx * 3 + 0] = 0;
-            du_dx[kidx * 3 + 1] = 0;
-            du_dx[kidx * 3 + 2] = 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                du_dx[kidx * 3 + d] = 0;
+                du_dx_cm[static_cast<size_t>(d) * cm_stride + kidx] = 0;
+            }
         }
     }
 }
@@ -137,7 +142,7 @@ template <typename Real>
 LangevinIntegrator<Real>::LangevinIntegrator(
     const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed)
     : N_(N), temperature_(temperature), dt_(static_cast<Real>(dt)), friction_(friction), seed_(static_cast<unsigned long long>(static_cast<long long>(seed))),
-      step_(0), d_cbs_(N), d_ccs_(N), d_du_dx_(static_cast<size_t>(N) * 3) {
+      step_(0), d_cbs_(N), d_ccs_(N), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7), d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
     ca_ = static_cast<Real>(std::exp(-friction * dt));
     const double kT = BOLTZ * temperature;
     const double ccs_adjustment = std::sqrt(1 - std::exp(-2 * friction * dt));
@@ -149,6 +154,7 @@ LangevinIntegrator<Real>::LangevinIntegrator(
     d_cbs_.copy_from(h_cbs.data());
     d_ccs_.copy_from(h_ccs.data());
     HIP_CHECK(hipMemset(d_du_dx_.data, 0, d_du_dx_.size()));
+    HIP_CHECK(hipMemset(d_du_dx_cm_.data, 0, d_du_dx_cm_.size()));
 }
 
 template <typename Real>
@@ -161,7 +167,7 @@ void LangevinIntegrator<Real>::step_fwd(
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
     }
     deferred_.clear();
-    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2);
+    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2, d_du_dx_cm_.data, cm_stride_);
     const DeferredForces none;
     const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
@@ -173,7 +179,7 @@ void LangevinIntegrator<Real>::step_fwd(
     const PregatherTarget no_target;
     const bool pregather = d_idxs == nullptr;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
-        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, dt_, df0.g_du_dx, df0.slot_of_atom,
+        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.slot_of_atom,
         df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
     HIP_CHECK(hipGetLastError());
     if (pregather) {
@@ -191,7 +197,8 @@ void LangevinIntegrator<Real>::step_fwd(
 template <int MODE>
 __global__ __launch_bounds__(256) void k_velocity_verlet(
     const int N, const unsigned int *__restrict__ idxs, const double *__restrict__ cbs, double *__restrict__ x_t, double *__restrict__ v_t,
-    u64 *__restrict__ du_dx, const double dt, const u64 *__restrict__ g0, const int *__restrict__ slot0, const int stride0,
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dx_cm, const int cm_stride, const double dt, const u64 *__restrict__ g0,
+    const int *__restrict__ slot0, const int stride0,
     const u64 *__restrict__ g1, const int *__restrict__ slot1, const int stride1) {
     const int kidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (kidx >= N) {
@@ -199,10 +206,12 @@ __global__ __launch_bounds__(256) void k_velocity_verlet(
     }
     const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
     if (atom >= N) {
-        if (idxs != nullptr) { // frozen slot: its accumulator still has to start the next evaluation from zero
-            du_dx[kidx * 3 + 0] = 0;
-            du_dx[kidx * 3 + 1] = 0;
-            du_dx[kidx * 3 + 2] = 0;
+        if (idxs != nullptr) { // frozen slot: its accumulators still have to start the next evaluation from zero
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                du_dx[kidx * 3 + d] = 0;
+                du_dx_cm[static_cast<size_t>(d) * cm_stride + kidx] = 0;
+            }
         }
         return;
     }
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256) void k_velocity_verlet(
     const int s1 = g1 ? slot1[atom] : -1;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        u64 f = du_dx[atom * 3 + d];
+        u64 f = du_dx[atom * 3 + d] + du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
         if (s0 >= 0) {
             f += g0[static_cast<size_t>(d) * stride0 + s0];
         }
@@ -225,13 +234,16 @@ __global__ __launch_bounds__(256) void k_velocity_verlet(
             x_t[atom * 3 + d] += dt * v;
         }
         du_dx[atom * 3 + d] = 0;
+        du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
     }
 }
 
 VelocityVerletIntegrator::VelocityVerletIntegrator(const int N, const double dt, const double *h_cbs)
-    : N_(N), dt_(dt), initialized_(false), d_cbs_(N), d_du_dx_(static_cast<size_t>(N) * 3) {
+    : N_(N), dt_(dt), initialized_(false), d_cbs_(N), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7),
+      d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
     d_cbs_.copy_from(h_cbs);
     HIP_CHECK(hipMemset(d_du_dx_.data, 0, d_du_dx_.size()));
+    HIP_CHECK(hipMemset(d_du_dx_cm_.data, 0, d_du_dx_cm_.size()));
 }
 
 void VelocityVerletIntegrator::forces_then_update(
@@ -242,14 +254,14 @@ void VelocityVerletIntegrator::forces_then_update(
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
     }
     deferred_.clear();
-    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2);
+    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2, d_du_dx_cm_.data, cm_stride_);
     const DeferredForces none;
     const DeferredForces &a = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &b = deferred_.size() > 1 ? deferred_[1] : none;
     const int tpb = 256, blocks = ceil_divide(N_, tpb);
 #define TM_VV(MODE)                                                                                                    \
     k_velocity_verlet<MODE><<<blocks, tpb, 0, stream>>>(                                                               \
-        N_, d_idxs, d_cbs_.data, d_x_t, d_v_t, d_du_dx_.data, dt_, a.g_du_dx, a.slot_of_atom, a.stride, b.g_du_dx, b.slot_of_atom, b.stride)
+        N_, d_idxs, d_cbs_.data, d_x_t, d_v_t, d_du_dx_.data, d_du_dx_cm_.data, cm_stride_, dt_, a.g_du_dx, a.slot_of_atom, a.stride, b.g_du_dx, b.slot_of_atom, b.stride)
     if (mode == 0) {
         TM_VV(0);
     } else if (mode == 1) {

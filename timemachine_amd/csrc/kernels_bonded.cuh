@@ -23,11 +23,23 @@ template <typename Real> __device__ __forceinline__ void store_wave_energy(i128 
     }
 }
 
+// Where a term's force goes: component d of atom a at du_dx[a * atom + d * comp].  {3, 1} is the [N, 3] array of the
+// Potential interface; the integrators' own accumulator is component-major {1, stride}: lanes working on neighbouring
+// atoms then share cache lines, and memory-side atomics are served one 64-byte line request at a time
+// (scripts/microbench/atomic_scope.hip: 64 lanes on 64 different lines cost 6.6x what 64 lanes on 8 lines cost).
+struct ForceLayout {
+    int atom, comp;
+};
+__device__ __forceinline__ void force_add(u64 *__restrict__ du_dx, const ForceLayout fl, const int atom, const int d, const u64 v) {
+    atomicAdd(du_dx + static_cast<size_t>(atom) * fl.atom + static_cast<size_t>(d) * fl.comp, v);
+}
+
 // term `b` of the list; returns its energy in fixed point (0 unless want_u)
 template <typename Real>
 __device__ __forceinline__ i128 harmonic_bond_term(
     const int b, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ bond_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     i128 energy = 0;
     const int src = bond_idxs[b * 2 + 0], dst = bond_idxs[b * 2 + 1];
     Real dx[3];
@@ -47,8 +59,8 @@ __device__ __forceinline__ i128 harmonic_bond_term(
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const Real g = b0 != 0 ? kb * db * dx[d] * inv_dij : kb * dx[d];
-            atomicAdd(du_dx + src * 3 + d, float_to_fixed<Real>(g));
-            atomicAdd(du_dx + dst * 3 + d, float_to_fixed<Real>(-g));
+            force_add(du_dx, fl, src, d, float_to_fixed<Real>(g));
+            force_add(du_dx, fl, dst, d, float_to_fixed<Real>(-g));
         }
     }
     if (du_dp) {
@@ -80,7 +92,8 @@ __global__ __launch_bounds__(256) void k_harmonic_bond(
 template <typename Real>
 __device__ __forceinline__ i128 harmonic_angle_term(
     const int a_idx, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ angle_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     i128 energy = 0;
     const int i = angle_idxs[a_idx * 3 + 0], j = angle_idxs[a_idx * 3 + 1], k = angle_idxs[a_idx * 3 + 2];
     const Real ka = static_cast<Real>(params[a_idx * 3 + 0]);
@@ -146,9 +159,9 @@ __device__ __forceinline__ i128 harmonic_angle_term(
         for (int d = 0; d < 3; d++) {
             const Real gi = coeff_i * ((aab_n == 0) ? static_cast<Real>(0) : aab[d] / aab_n);
             const Real gk = coeff_k * ((bba_n == 0) ? static_cast<Real>(0) : bba[d] / bba_n);
-            atomicAdd(du_dx + i * 3 + d, float_to_fixed<Real>(gi));
-            atomicAdd(du_dx + k * 3 + d, float_to_fixed<Real>(gk));
-            atomicAdd(du_dx + j * 3 + d, float_to_fixed<Real>(-gi - gk));
+            force_add(du_dx, fl, i, d, float_to_fixed<Real>(gi));
+            force_add(du_dx, fl, k, d, float_to_fixed<Real>(gk));
+            force_add(du_dx, fl, j, d, float_to_fixed<Real>(-gi - gk));
         }
     }
     if (du_dp) {
@@ -193,7 +206,8 @@ template <typename Real> __device__ __forceinline__ void cross3(const Real a[3],
 template <typename Real>
 __device__ __forceinline__ i128 periodic_torsion_term(
     const int t_idx, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ torsion_idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     i128 energy = 0;
     const int i = torsion_idxs[t_idx * 4 + 0], j = torsion_idxs[t_idx * 4 + 1];
     const int k = torsion_idxs[t_idx * 4 + 2], l = torsion_idxs[t_idx * 4 + 3];
@@ -238,10 +252,10 @@ __device__ __forceinline__ i128 periodic_torsion_term(
     if (du_dx) {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            atomicAdd(du_dx + i * 3 + d, float_to_fixed<Real>(dR0[d] * prefactor));
-            atomicAdd(du_dx + j * 3 + d, float_to_fixed<Real>(dR1[d] * prefactor));
-            atomicAdd(du_dx + k * 3 + d, float_to_fixed<Real>(dR2[d] * prefactor));
-            atomicAdd(du_dx + l * 3 + d, float_to_fixed<Real>(dR3[d] * prefactor));
+            force_add(du_dx, fl, i, d, float_to_fixed<Real>(dR0[d] * prefactor));
+            force_add(du_dx, fl, j, d, float_to_fixed<Real>(dR1[d] * prefactor));
+            force_add(du_dx, fl, k, d, float_to_fixed<Real>(dR2[d] * prefactor));
+            force_add(du_dx, fl, l, d, float_to_fixed<Real>(dR3[d] * prefactor));
         }
     }
     if (du_dp) {
@@ -299,17 +313,18 @@ template <typename Real> __device__ __forceinline__ Vec3<Real> v_unit_pullback(c
     const Real along = v_dot(uhat, g);
     return {(g.x - uhat.x * along) * inv_norm, (g.y - uhat.y * along) * inv_norm, (g.z - uhat.z * along) * inv_norm};
 }
-template <typename Real> __device__ __forceinline__ void v_atomic_add_scaled(u64 *__restrict__ du_dx, const int a, const Vec3<Real> g, const Real scale) {
-    atomicAdd(du_dx + a * 3 + 0, float_to_fixed<Real>(g.x * scale));
-    atomicAdd(du_dx + a * 3 + 1, float_to_fixed<Real>(g.y * scale));
-    atomicAdd(du_dx + a * 3 + 2, float_to_fixed<Real>(g.z * scale));
+template <typename Real> __device__ __forceinline__ void v_atomic_add_scaled(u64 *__restrict__ du_dx, const ForceLayout fl, const int a, const Vec3<Real> g, const Real scale) {
+    force_add(du_dx, fl, a, 0, float_to_fixed<Real>(g.x * scale));
+    force_add(du_dx, fl, a, 1, float_to_fixed<Real>(g.y * scale));
+    force_add(du_dx, fl, a, 2, float_to_fixed<Real>(g.z * scale));
 }
 
 // centre c with neighbours 1, 2, 3: vol = (a^ x b^) . c^ with a = x1 - xc, b = x2 - xc, c = x3 - xc; penalised when vol > 0
 template <typename Real>
 __device__ __forceinline__ i128 chiral_atom_term(
     const int r, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     const int ic = idxs[r * 4 + 0], i1 = idxs[r * 4 + 1], i2 = idxs[r * 4 + 2], i3 = idxs[r * 4 + 3];
     const Vec3<Real> xc = v_load<Real>(coords, ic);
     Real na, nb, nc;
@@ -334,10 +349,10 @@ __device__ __forceinline__ i128 chiral_atom_term(
         const Vec3<Real> gb = v_unit_pullback(b, nb, v_cross(c, a));
         const Vec3<Real> gc = v_unit_pullback(c, nc, ab);
         const Real pref = 2 * k * vol;
-        v_atomic_add_scaled(du_dx, ic, v_neg(v_add(v_add(ga, gb), gc)), pref);
-        v_atomic_add_scaled(du_dx, i1, ga, pref);
-        v_atomic_add_scaled(du_dx, i2, gb, pref);
-        v_atomic_add_scaled(du_dx, i3, gc, pref);
+        v_atomic_add_scaled(du_dx, fl, ic, v_neg(v_add(v_add(ga, gb), gc)), pref);
+        v_atomic_add_scaled(du_dx, fl, i1, ga, pref);
+        v_atomic_add_scaled(du_dx, fl, i2, gb, pref);
+        v_atomic_add_scaled(du_dx, fl, i3, gc, pref);
     }
     if (du_dp) {
         atomicAdd(du_dp + r, float_to_fixed<Real>(vol * vol));
@@ -350,7 +365,8 @@ __device__ __forceinline__ i128 chiral_atom_term(
 template <typename Real>
 __device__ __forceinline__ i128 chiral_bond_term(
     const int r, const double *__restrict__ coords, const double *__restrict__ params, const int *__restrict__ idxs,
-    const int *__restrict__ signs, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    const int *__restrict__ signs, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     const int ii = idxs[r * 4 + 0], ij = idxs[r * 4 + 1], ik = idxs[r * 4 + 2], il = idxs[r * 4 + 3];
     const Vec3<Real> xi = v_load<Real>(coords, ii), xj = v_load<Real>(coords, ij);
     const Vec3<Real> xk = v_load<Real>(coords, ik), xl = v_load<Real>(coords, il);
@@ -376,10 +392,10 @@ __device__ __forceinline__ i128 chiral_bond_term(
         const Vec3<Real> gb = v_unit_pullback(b, nb, v_add(v_cross(n2, a), v_cross(c, n1)));
         const Vec3<Real> gc = v_unit_pullback(c, nc, v_cross(n1, b));
         const Real pref = 2 * k * vol;
-        v_atomic_add_scaled(du_dx, ii, v_neg(ga), pref);
-        v_atomic_add_scaled(du_dx, ij, v_add(ga, gb), pref);
-        v_atomic_add_scaled(du_dx, ik, v_neg(v_add(gb, gc)), pref);
-        v_atomic_add_scaled(du_dx, il, gc, pref);
+        v_atomic_add_scaled(du_dx, fl, ii, v_neg(ga), pref);
+        v_atomic_add_scaled(du_dx, fl, ij, v_add(ga, gb), pref);
+        v_atomic_add_scaled(du_dx, fl, ik, v_neg(v_add(gb, gc)), pref);
+        v_atomic_add_scaled(du_dx, fl, il, gc, pref);
     }
     if (du_dp) {
         atomicAdd(du_dp + r, float_to_fixed<Real>(vol * vol));
@@ -422,7 +438,8 @@ __global__ __launch_bounds__(256) void k_chiral_bond_restraint(
 template <typename Real, bool LOG>
 __device__ __forceinline__ i128 flat_bottom_bond_term(
     const int b, const double *__restrict__ coords, const double *__restrict__ box, const double *__restrict__ params,
-    const int *__restrict__ bond_idxs, const double beta_d, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    const int *__restrict__ bond_idxs, const double beta_d, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1}) {
     const int src = bond_idxs[b * 2 + 0], dst = bond_idxs[b * 2 + 1];
     const Real k = static_cast<Real>(params[b * 3 + 0]);
     const Real rmin = static_cast<Real>(params[b * 3 + 1]);
@@ -471,8 +488,8 @@ __device__ __forceinline__ i128 flat_bottom_bond_term(
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const Real g = chain * (du_dr * dx[d] * inv_r);
-            atomicAdd(du_dx + src * 3 + d, float_to_fixed<Real>(g));
-            atomicAdd(du_dx + dst * 3 + d, float_to_fixed<Real>(-g));
+            force_add(du_dx, fl, src, d, float_to_fixed<Real>(g));
+            force_add(du_dx, fl, dst, d, float_to_fixed<Real>(-g));
         }
     }
     return energy;
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(256) void k_centroid_restraint(
         for (int d = 0; d < 3; d++) {
             // b0 == 0: the gradient 2 kb delta is well defined at dij == 0 as well (bonded.py:26-31)
             const Real g = b0 != 0 ? 2 * kb * (dij - b0) * (delta[d] / dij) : 2 * kb * delta[d];
-            atomicAdd(du_dx + atom * 3 + d, float_to_fixed<Real>(share * g));
+            force_add(du_dx, ForceLayout{3, 1}, atom, d, float_to_fixed<Real>(share * g));
         }
     }
 }

@@ -179,14 +179,14 @@ template <typename Real, bool NEGATED>
 __device__ __forceinline__ i128 nonbonded_pair_list_term(
     const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u);
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl = ForceLayout{3, 1});
 
 // One 256-term block of a ForcePlan table (engine.hpp): bonded terms and pair lists, forces only.  Defined at the end of
 // this header; called by k_fused_forces and by the tail of the tile kernel.
 template <typename Real>
 __device__ __forceinline__ void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx);
+    const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl);
 
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
 // Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
@@ -213,6 +213,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
     const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
+    const int out_atom_stride, const int out_comp_stride, // layout of out_du_dx (ForceLayout)
     long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
     constexpr int WAVES = TileShape<Real, COMPUTE_DU_DP>::waves;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             // costs nothing, the others 8-10 us per launch).
             // slice t goes to workgroup t % G, wave (t / G) % WAVES: every CU takes the same share
             for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
-                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx);
+                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride});
             }
         }
     }
@@ -686,7 +687,7 @@ template <typename Real, bool NEGATED>
 __device__ __forceinline__ i128 nonbonded_pair_list_term(
     const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl) {
     i128 energy = 0;
     const NbBox<Real> bx = load_box<Real>(box);
     const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
@@ -713,12 +714,12 @@ do {                                                                            
         if (du_dx) {
             u64 fx, fy, fz;
             pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
-            TM_ACC(du_dx + ia * 3 + 0, fx);
-            TM_ACC(du_dx + ia * 3 + 1, fy);
-            TM_ACC(du_dx + ia * 3 + 2, fz);
-            TM_ACC(du_dx + ja * 3 + 0, 0ull - fx);
-            TM_ACC(du_dx + ja * 3 + 1, 0ull - fy);
-            TM_ACC(du_dx + ja * 3 + 2, 0ull - fz);
+            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 0 * static_cast<size_t>(fl.comp), fx);
+            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 1 * static_cast<size_t>(fl.comp), fy);
+            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 2 * static_cast<size_t>(fl.comp), fz);
+            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 0 * static_cast<size_t>(fl.comp), 0ull - fx);
+            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 1 * static_cast<size_t>(fl.comp), 0ull - fy);
+            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 2 * static_cast<size_t>(fl.comp), 0ull - fz);
         }
         if (du_dp) {
             TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
@@ -774,7 +775,7 @@ template <typename Real>
 __device__ __forceinline__ i128 nonbonded_precomputed_term(
     const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double beta_d, const double cutoff_d, u64 *__restrict__ du_dx,
-    u64 *__restrict__ du_dp, const bool want_u) {
+    u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl = ForceLayout{3, 1}) {
     i128 energy = 0;
     const NbBox<Real> bx = load_box<Real>(box);
     const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
@@ -812,12 +813,12 @@ __device__ __forceinline__ i128 nonbonded_precomputed_term(
         if (du_dx) {
             u64 fx, fy, fz;
             pair_force_fixed(prefactor, dx, dy, dz, fx, fy, fz);
-            atomicAdd(du_dx + ia * 3 + 0, fx);
-            atomicAdd(du_dx + ia * 3 + 1, fy);
-            atomicAdd(du_dx + ia * 3 + 2, fz);
-            atomicAdd(du_dx + ja * 3 + 0, 0ull - fx);
-            atomicAdd(du_dx + ja * 3 + 1, 0ull - fy);
-            atomicAdd(du_dx + ja * 3 + 2, 0ull - fz);
+            force_add(du_dx, fl, ia, 0, fx);
+            force_add(du_dx, fl, ia, 1, fy);
+            force_add(du_dx, fl, ia, 2, fz);
+            force_add(du_dx, fl, ja, 0, 0ull - fx);
+            force_add(du_dx, fl, ja, 1, 0ull - fy);
+            force_add(du_dx, fl, ja, 2, 0ull - fz);
         }
         if (du_dp) {
             atomicAdd(du_dp + pair * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(g_q)));
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(256) void k_nonbonded_precomputed(
 template <typename Real>
 __device__ __forceinline__ void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx) {
+    const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl) {
     const int n = table->n;
     int s = 0, first = 0;
     for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
@@ -869,22 +870,22 @@ __device__ __forceinline__ void fused_dispatch(
         return;
     }
     switch (seg.kind) {
-    case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
+    case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
+    case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
+    case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
     case FUSED_PAIR_LIST:
-        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);
         break;
     case FUSED_PAIR_LIST_NEGATED:
-        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);
         break;
     case FUSED_PAIR_LIST_PRECOMPUTED:
-        nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, du_dx, nullptr, false);
+        nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);
         break;
-    case FUSED_CHIRAL_ATOM: chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false); break;
-    case FUSED_CHIRAL_BOND: chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, du_dx, nullptr, false); break;
-    case FUSED_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false); break;
-    case FUSED_LOG_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false); break;
+    case FUSED_CHIRAL_ATOM: chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
+    case FUSED_CHIRAL_BOND: chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, du_dx, nullptr, false, fl); break;
+    case FUSED_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false, fl); break;
+    case FUSED_LOG_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false, fl); break;
     default: break;
     }
 }

@@ -446,12 +446,16 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
 }
 
 template <typename Real>
-bool NonbondedAllPairs<Real>::piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes) {
+bool NonbondedAllPairs<Real>::piggyback_forces(
+    const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) {
     if (precision_bytes != static_cast<int>(sizeof(Real)) || piggyback_table_ != nullptr || empty_) {
         return false;
     }
     piggyback_table_ = d_table;
     piggyback_blocks_ = blocks;
+    piggyback_acc_ = acc;
+    piggyback_atom_stride_ = atom_stride;
+    piggyback_comp_stride_ = comp_stride;
     return true;
 }
 
@@ -573,7 +577,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     k_nonbonded_tiles<Real, U, X, PP><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
-        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, d_du_dx, \
+        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, piggyback_acc_, piggyback_atom_stride_, piggyback_comp_stride_, \
         d_timing_.data)
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
     int launched_waves = 0; // waves of this launch = energy partials it writes
