@@ -31,18 +31,20 @@ namespace tmamd {
 
 // Waves per SIMD the tile kernel is register-budgeted for (512 / waves VGPRs per lane).  f64: the pair math plus the
 // VGPR-resident erfcx coefficients need ~130 registers -- 3 waves without spills beats 4 waves with 60+ spilled
-// dwords (measured: 148 vs 167 us per launch at 23.5k atoms).  f32: ~80 registers -> 5 waves.
+// dwords (measured: 148 vs 167 us per launch at 23.5k atoms).  f32: ~100 registers -> 4 waves (5 fit with 96,
+// but only in a workgroup shape whose item pools are too small, see TileShape).
 template <typename Real> struct TileWaves {
 #ifndef TM_TILE_WAVES_F64
 #define TM_TILE_WAVES_F64 3
 #endif
 #ifndef TM_TILE_WAVES_F32
-#define TM_TILE_WAVES_F32 5
+#define TM_TILE_WAVES_F32 4
 #endif
     static const int value = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : TM_TILE_WAVES_F32;
 };
-// Workgroup shape of the tile kernel.  f64: one workgroup owns a whole CU (12 waves = 3 per SIMD); f32: five 4-wave
-// workgroups per CU (one wave per SIMD each); registers and the per-wave LDS footprint admit exactly that many.  Its waves draw work items from a
+// Workgroup shape of the tile kernel.  f64: one workgroup owns a whole CU (12 waves = 3 per SIMD).  f32: two 8-wave
+// workgroups per CU = 4 waves per SIMD -- the registers would admit 5, but 20 waves only tile a CU as five 4-wave
+// groups, and pools of ~10 items for 4 waves end 29 % apart (measured: 5 x 4 waves 2740 ns/day, 2 x 8 2920, 1 x 16 2905).  Its waves draw work items from a
 // pool that belongs to the workgroup through an LDS ticket counter: static, cost-sorted pools across CUs (sums over
 // ~48 items are even to ~2 %), dynamic within a CU (a wave that finishes early takes the next item instead of idling
 // while its three SIMD neighbours work on).  The du_dp variants need more LDS per wave: f32 runs them as one 16-wave
@@ -55,9 +57,13 @@ template <typename Real, bool DU_DP> struct TileShape {
 #else
     // a workgroup's waves are spread over the four SIMDs in dispatch order, so only multiples of four waves tile a CU
     // exactly (two 10-wave workgroups do not fit: 3+3+2+2 twice overfills a SIMD's register file)
-    static const int waves = sizeof(Real) == 8 ? 4 * TM_TILE_WAVES_F64 : (DU_DP ? 16 : 4);
-    static const int wgs_per_cu = sizeof(Real) == 8 ? 1 : (DU_DP ? 1 : TM_TILE_WAVES_F32);
-    static const int min_waves = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : (DU_DP ? 4 : TM_TILE_WAVES_F32);
+#ifndef TM_TILE_F32_WG_WAVES
+#define TM_TILE_F32_WG_WAVES 8
+#define TM_TILE_F32_WGS 2
+#endif
+    static const int waves = sizeof(Real) == 8 ? 4 * TM_TILE_WAVES_F64 : (DU_DP ? 16 : TM_TILE_F32_WG_WAVES);
+    static const int wgs_per_cu = sizeof(Real) == 8 ? 1 : (DU_DP ? 1 : TM_TILE_F32_WGS);
+    static const int min_waves = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : (DU_DP ? 4 : (TM_TILE_F32_WG_WAVES * TM_TILE_F32_WGS) / 4);
 #endif
     static const int waves_per_cu = waves * wgs_per_cu;
 };
