@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
 static const int NBL_TRIP = TM_NBL_TRIP; // rows tested per trip of the fine pass
 static const int NBL_COST_STRIDE = 4; // cost estimates sample every 4th row (lane-staggered start)
 static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
+static const int NBL_CAND_CAP = 3072; // accepted column atoms per row block staged in LDS (48 KB; a 1.3 nm list at water density holds ~2100)
 #ifndef TM_NBL_THREADS
 #define TM_NBL_THREADS 1024
 #endif
@@ -155,6 +156,9 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     __shared__ unsigned int s_nlist, s_count;
     __shared__ unsigned int s_hist[NB_CLASSES], s_base[NB_CLASSES];
     __shared__ float s_rf[3][TILE];
+    // accepted column atoms (origin-relative f32 position, atom index in .w) in list order: the cost estimate below
+    // reads them back from here instead of through two dependent global round trips (col_atoms, then gathered)
+    __shared__ float4 s_cand[NBL_CAND_CAP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -376,7 +380,11 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                 }
                 base = __shfl(base, 0, 64);
                 if (interacts) {
-                    col_atoms[seg_start + base + __popcll(hits & ((1ull << lane) - 1ull))] = ja;
+                    const unsigned int pos = base + __popcll(hits & ((1ull << lane) - 1ull));
+                    col_atoms[seg_start + pos] = ja;
+                    if (pos < static_cast<unsigned int>(NBL_CAND_CAP)) {
+                        s_cand[pos] = make_float4(cfx, cfy, cfz, __uint_as_float(ja));
+                    }
                 }
             }
         }
@@ -414,9 +422,22 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
         unsigned int ja = K;
+        float xj = 0.0f, yj = 0.0f, zj = 0.0f;
+        const bool staged = off + len <= static_cast<unsigned int>(NBL_CAND_CAP); // wave-uniform
         if (static_cast<unsigned int>(lane) < len) {
-            // written by other waves of this workgroup a barrier ago: read past the (non-coherent) vector L1
-            ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (staged) {
+                const float4 cand = s_cand[off + lane];
+                xj = cand.x;
+                yj = cand.y;
+                zj = cand.z;
+                ja = __float_as_uint(cand.w);
+            } else {
+                // written by other waves of this workgroup a barrier ago: read past the (non-coherent) vector L1
+                ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
+                yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
+                zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
+            }
         }
         unsigned int mine = 0;
 #if defined(TM_NBL_ABL) && TM_NBL_ABL == 1
@@ -424,9 +445,6 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
 #else
         if (ja < static_cast<unsigned int>(K)) {
 #endif
-            const float xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
-            const float yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
-            const float zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
             // every NBL_COST_STRIDE-th row only: the estimate feeds a 128-pair-wide cost class, a sampled count is plenty
             for (int i = (lane & (NBL_COST_STRIDE - 1)); i < nrow; i += NBL_COST_STRIDE) {
                 float dx = s_rf[0][i] - xj, dy = s_rf[1][i] - yj, dz = s_rf[2][i] - zj;
