@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--windows", type=int, default=8, help="lambda windows of the end-of-run u_kl gather")
     ap.add_argument("--equil-scale", type=float, default=1.0, help="scale the untimed equilibration (profiling runs)")
     ap.add_argument("--equil-precision", choices=["f64", "f32"], default="f32")
-    ap.add_argument("--parallel-children", action="store_true", help="SummedPotential(parallel=True): children on forked HIP streams")
+    ap.add_argument("--parallel-children", action="store_true", help="SummedPotential(parallel=True) (accepted for interface parity; children always run in sequence)")
     ap.add_argument("--separate-potentials", action="store_true", help="pass the potentials to Context one by one (serial) instead of one SummedPotential")
     return ap.parse_args()
 

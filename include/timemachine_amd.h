@@ -238,6 +238,8 @@ int tm_hilbert_lut(uint32_t *out);
 int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
+/* debug builds (-DTM_GUARD: guard zones around every device buffer): number of violated zones; -1 in product builds */
+int tm_debug_check_guards(int *violations);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,43 @@
+"""Out-of-bounds write detector: run with TM_AMD_LIB pointing at a -DTM_GUARD build (build.build_variant("guard", ["TM_GUARD=1"])).
+Every device buffer then sits between two guard zones; this drives MD in both precisions, energies / du_dp evaluations,
+the barostat and an interaction-group state, and reports the zones that were written to."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from timemachine_amd import potentials as P
+from timemachine_amd import testsystems as ts
+from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat, custom_ops as co
+
+
+def check(tag):
+    n = ctypes.c_int(0)
+    co._check(co._lib.tm_debug_check_guards(ctypes.byref(n)))
+    print(f"{tag}: guard violations = {n.value}", flush=True)
+    return n.value
+
+
+s = ts.dhfr_sized_water_box()
+total = 0
+for prec in (np.float32, np.float64):
+    bps = [bp.to_gpu(prec).bound_impl for bp in ts.bound_potentials(s)]
+    ctxt = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, s.masses, 1).impl(), bps)
+    ctxt.multiple_steps(400, 0)
+    total += check(f"md {prec.__name__}")
+    x = ctxt.get_x_t()
+    for bp in bps:
+        bp.execute(x, s.box, True, True)
+    nb = P.NonbondedAllPairs(s.num_atoms, s.beta, s.cutoff).to_gpu(prec).unbound_impl
+    nb.execute(x, s.nb_params, s.box, True, True, True)
+    nb.execute_batch(x[None], np.stack([s.nb_params, s.nb_params * 0.5]), s.box[None], True, True, True)
+    total += check(f"evaluations {prec.__name__}")
+small = ts.add_chain_ligand(ts.build_water_box(300, 3.0, seed=4), 16, lamb=0.3)
+bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(small)]
+ctxt = co.Context(small.coords, np.zeros_like(small.coords), small.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, small.masses, 3).impl(), bps)
+ctxt.multiple_steps(600, 0)
+total += check("small system md")
+print("TOTAL", total)
+sys.exit(1 if total else 0)

@@ -785,5 +785,14 @@ int tm_profile_reset(void) {
     Profiler::get().reset();
     TM_CATCH
 }
+int tm_debug_check_guards(int *violations) {
+    TM_TRY
+#ifdef TM_GUARD
+    *violations = GuardRegistry::get().check();
+#else
+    *violations = -1; // not a guard build
+#endif
+    TM_CATCH
+}
 
 } // extern "C"

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -41,6 +42,59 @@ inline void hip_check(hipError_t code, const char *file, int line) {
 template <typename T> inline T ceil_divide(T x, T y) { return (x + y - 1) / y; }
 
 // RAII hipMalloc. Grow-only `reserve` lets host entry points reuse scratch instead of malloc/free per call.
+#ifdef TM_GUARD
+// Debug builds (-DTM_GUARD): every device buffer sits between two 64 KiB guard zones filled with 0xA5; guard_check()
+// reports the zones that no longer are (out-of-bounds writes by any kernel).  tm_debug_check_guards() in the C ABI.
+struct GuardRegistry {
+    struct Zone {
+        char *base;
+        size_t bytes;
+    };
+    std::vector<Zone> zones;
+    static GuardRegistry &get() {
+        static GuardRegistry r;
+        return r;
+    }
+    static constexpr size_t GUARD = 65536;
+    void *alloc(size_t bytes) {
+        char *base = nullptr;
+        HIP_CHECK(hipMalloc(&base, bytes + 2 * GUARD));
+        HIP_CHECK(hipMemset(base, 0xA5, GUARD));
+        HIP_CHECK(hipMemset(base + GUARD + bytes, 0xA5, GUARD));
+        zones.push_back({base, bytes});
+        return base + GUARD;
+    }
+    void free(void *p) {
+        char *base = static_cast<char *>(p) - GUARD;
+        for (size_t i = 0; i < zones.size(); i++) {
+            if (zones[i].base == base) {
+                zones.erase(zones.begin() + i);
+                break;
+            }
+        }
+        (void)hipFree(base);
+    }
+    int check() {
+        int bad = 0;
+        std::vector<unsigned char> h(GUARD);
+        HIP_CHECK(hipDeviceSynchronize());
+        for (const Zone &z : zones) {
+            for (int side = 0; side < 2; side++) {
+                HIP_CHECK(hipMemcpy(h.data(), side ? z.base + GUARD + z.bytes : z.base, GUARD, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < GUARD; i++) {
+                    if (h[i] != 0xA5) {
+                        fprintf(stderr, "guard violated: buffer of %zu bytes, %s zone, offset %zu\n", z.bytes, side ? "upper" : "lower", i);
+                        bad++;
+                        break;
+                    }
+                }
+            }
+        }
+        return bad;
+    }
+};
+#endif
+
 template <typename T> struct DeviceBuffer {
     T *data = nullptr;
     size_t length = 0;
@@ -51,17 +105,28 @@ template <typename T> struct DeviceBuffer {
     DeviceBuffer &operator=(const DeviceBuffer &) = delete;
     ~DeviceBuffer() {
         if (data)
-            (void)hipFree(data);
+            release(data);
+    }
+    static void release(T *p) {
+#ifdef TM_GUARD
+        GuardRegistry::get().free(p);
+#else
+        (void)hipFree(p);
+#endif
     }
     size_t size() const { return length * sizeof(T); }
     void realloc(size_t n) {
         if (data) {
-            HIP_CHECK(hipFree(data));
+            release(data);
             data = nullptr;
         }
         length = n;
         // never hand back nullptr for an empty buffer: kernels take the pointer even when nothing is read
+#ifdef TM_GUARD
+        data = static_cast<T *>(GuardRegistry::get().alloc((n > 0 ? n : 1) * sizeof(T)));
+#else
         HIP_CHECK(hipMalloc(&data, (n > 0 ? n : 1) * sizeof(T)));
+#endif
     }
     void reserve(size_t n) {
         if (n > length || data == nullptr)

@@ -185,25 +185,19 @@ private:
     DeviceBuffer<i128> hs_u_;
 };
 
-// Lazily created side streams + events for running children concurrently (reference: stream_manager.cu:18-56).
-class StreamFork {
-public:
-    ~StreamFork();
-    hipStream_t stream(int i);
-    void fork_from(int i, hipStream_t parent); // side stream i waits for everything queued on parent
-    void join_to(int i, hipStream_t parent);   // parent waits for side stream i
-private:
-    std::vector<hipStream_t> streams_;
-    std::vector<hipEvent_t> events_;
-    void ensure(int i);
-};
 
 // reference: cpp/src/summed_potential.cu:33-97
+// `parallel` (reference: children on per-child streams joined by events, stream_manager.cu:18-56) is kept as a
+// constructor argument and otherwise ignored: results never depend on it (integer accumulation), forces-only calls go
+// through one fused ForcePlan anyway, and running children on forked non-blocking streams was both slower (~30 us per
+// MD step) and, on this stack, not safe: an AllPairs child whose Hilbert re-sort was due, overlapping the pair-list
+// child, hit an intermittent GPU memory fault (scripts/guard_check.py reproduces the scenario; serial children never did).
 class SummedPotential : public Potential {
 public:
     SummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel);
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
     const std::vector<int> &get_parameter_sizes() { return params_sizes_; }
+    bool get_parallel() const { return parallel_; }
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void invalidate_cached_inputs() override {
         for (auto &pot : potentials_) {
@@ -217,9 +211,8 @@ private:
     std::vector<std::shared_ptr<Potential>> potentials_;
     std::vector<int> params_sizes_;
     int P_;
-    bool parallel_;
+    bool parallel_; // accepted, not used: see SummedPotential
     DeviceBuffer<i128> d_u_buffer_;
-    StreamFork fork_;
     ForcePlan plan_;
 };
 
@@ -228,6 +221,7 @@ class FanoutSummedPotential : public Potential {
 public:
     FanoutSummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const bool parallel);
     const std::vector<std::shared_ptr<Potential>> &get_potentials() { return potentials_; }
+    bool get_parallel() const { return parallel_; }
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void invalidate_cached_inputs() override {
         for (auto &pot : potentials_) {
@@ -239,9 +233,8 @@ public:
 
 private:
     std::vector<std::shared_ptr<Potential>> potentials_;
-    bool parallel_;
+    bool parallel_; // accepted, not used: see SummedPotential
     DeviceBuffer<i128> d_u_buffer_;
-    StreamFork fork_;
     ForcePlan plan_;
 };
 

@@ -2,6 +2,8 @@
 // One translation unit on purpose: the tile kernel and the pair-list kernel must inline the same nb_pair() under
 // the same compiler flags (exact fixed-point cancellation of exclusions).
 #include "engine.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include "kernels_nblist.cuh"
 #include "profiler.hpp"
 
@@ -10,6 +12,22 @@
 #include <algorithm>
 #include <numeric>
 #include <set>
+
+#ifdef TM_GUARD
+// debug builds: name every launch of the nonbonded pipeline and wait for it, so that a faulting kernel is the last one named
+#define TM_DEBUG_SYNC(name, stream)                                                                                    \
+    do {                                                                                                               \
+        if (std::getenv("TM_DEBUG_SYNC")) {                                                                            \
+            fprintf(stderr, "[sync] %s\n", name);                                                                      \
+            fflush(stderr);                                                                                            \
+            HIP_CHECK(hipStreamSynchronize(stream));                                                                   \
+        }                                                                                                              \
+    } while (0)
+#else
+#define TM_DEBUG_SYNC(name, stream)                                                                                    \
+    do {                                                                                                               \
+    } while (0)
+#endif
 
 namespace tmamd {
 
@@ -75,9 +93,11 @@ __global__ void k_hilbert_keys(
         x -= bx * floor(x * inv_bx);
         y -= by * floor(y * inv_by);
         z -= bz * floor(z * inv_bz);
-        const unsigned int ix = static_cast<unsigned int>(x * inv_bin_width);
-        const unsigned int iy = static_cast<unsigned int>(y * inv_bin_width);
-        const unsigned int iz = static_cast<unsigned int>(z * inv_bin_width);
+        // clamped: non-finite coordinates (a diverged run, an unfinished copy) must produce a bin, not a wild address
+        const double top = HILBERT_GRID_DIM - 1.0;
+        const unsigned int ix = static_cast<unsigned int>(fmin(fmax(x * inv_bin_width, 0.0), top));
+        const unsigned int iy = static_cast<unsigned int>(fmin(fmax(y * inv_bin_width, 0.0), top));
+        const unsigned int iz = static_cast<unsigned int>(fmin(fmax(z * inv_bin_width, 0.0), top));
         keys[idx] = bin_to_idx[(ix * HILBERT_GRID_DIM + iy) * HILBERT_GRID_DIM + iz];
         vals[idx] = a;
     }
@@ -266,6 +286,7 @@ void Neighborlist<Real>::build_device(
         d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
         d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
     HIP_CHECK(hipGetLastError());
+    TM_DEBUG_SYNC("k_block_bounds", stream);
     const size_t lds = 0;
     if (ut) {
         k_find_ixns<Real, true><<<nrb, NBL_THREADS, lds, stream>>>(
@@ -550,6 +571,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
             HIP_CHECK(hipMemcpyAsync(d_perm_.data, d_atom_idxs_.data, K_ * sizeof(unsigned int), hipMemcpyDeviceToDevice, stream));
         }
         force = 1;
+        TM_DEBUG_SYNC("hilbert sort", stream);
     }
 
     // (b) K1: displacement check against the last build's snapshot + gather into Hilbert order.  The rebuild flag
@@ -564,12 +586,14 @@ void NonbondedAllPairs<Real>::run_pipeline(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
             flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
         HIP_CHECK(hipGetLastError());
+        TM_DEBUG_SYNC("k_check_gather", stream);
     }
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     nblist_.build_device(
         d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream);
 
+    TM_DEBUG_SYNC("list build", stream);
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
 #define TM_LAUNCH_TILES(U, X, PP)                                                                                      \
@@ -606,6 +630,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     Profiler::get().end("nonbonded_tiles", prof, stream);
     HIP_CHECK(hipGetLastError());
 
+    TM_DEBUG_SYNC("tile kernel", stream);
     // (e) K5: back to the caller's atom order
     if (d_du_dx && scatter_du_dx) {
         k_scatter_accum<3><<<ceil_divide(K_ * 3, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dx_.data, acc_stride_, d_du_dx);
@@ -618,6 +643,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     if (d_u) {
         reduce_i128_device(d_u_partials_.data, launched_waves, d_u, stream);
     }
+    TM_DEBUG_SYNC("scatter / reduce", stream);
     calls_since_sort_++;
     parity_ ^= 1;
     force_rebuild_ = false;

@@ -110,6 +110,11 @@ struct HostStage {
             u.reserve(n_u);
             u.zero_async(stream, n_u);
         }
+        // Inputs and zeroed outputs are in place before any kernel is enqueued: container potentials run their children
+        // on forked non-blocking streams, and an event recorded on the (null) staging stream was observed NOT to hold
+        // them back until a pageable host-to-device copy had landed -- a child then binned uninitialised coordinates
+        // along the Hilbert curve (intermittent GPU memory fault on the first host-API call after a re-sort was due).
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 };
 
@@ -238,41 +243,6 @@ void BoundPotential::execute_batch_host(
 }
 
 // ------------------------------------------------------------------------------------------------------------
-StreamFork::~StreamFork() {
-    for (auto s : streams_)
-        (void)hipStreamDestroy(s);
-    for (auto e : events_)
-        (void)hipEventDestroy(e);
-}
-
-void StreamFork::ensure(int i) {
-    while (static_cast<int>(streams_.size()) <= i) {
-        hipStream_t s;
-        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        streams_.push_back(s);
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        events_.push_back(e);
-    }
-}
-
-hipStream_t StreamFork::stream(int i) {
-    ensure(i);
-    return streams_[i];
-}
-
-void StreamFork::fork_from(int i, hipStream_t parent) {
-    ensure(i);
-    HIP_CHECK(hipEventRecord(events_[i], parent));
-    HIP_CHECK(hipStreamWaitEvent(streams_[i], events_[i], 0));
-}
-
-void StreamFork::join_to(int i, hipStream_t parent) {
-    ensure(i);
-    HIP_CHECK(hipEventRecord(events_[i], streams_[i]));
-    HIP_CHECK(hipStreamWaitEvent(parent, events_[i], 0));
-}
-
 // ------------------------------------------------------------------------------------------------------------
 SummedPotential::SummedPotential(
     const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel)
@@ -292,7 +262,6 @@ void SummedPotential::execute_device(
             "SummedPotential::execute_device(): expected " + std::to_string(P_) + " parameters, got " + std::to_string(P));
     }
     const int n = potentials_.size();
-    const bool par = parallel_ && n > 1;
     if (d_du_dx && !d_du_dp && !d_u) {
         // forces only (the MD path): fuse the short per-term kernels of all children into one launch
         plan_.clear();
@@ -303,19 +272,13 @@ void SummedPotential::execute_device(
     if (d_u) {
         d_u_buffer_.zero_async(stream, n);
     }
-    if (par) {
-        for (int i = 0; i < n; i++)
-            fork_.fork_from(i, stream);
-    }
+    // Children run one after the other on the caller's stream whatever `parallel` says (see engine.hpp).
     int offset = 0;
     for (int i = 0; i < n; i++) {
-        hipStream_t s = par ? fork_.stream(i) : stream;
         potentials_[i]->execute_device(
             N, params_sizes_[i], d_x, d_p + offset, d_box, d_du_dx, d_du_dp == nullptr ? nullptr : d_du_dp + offset,
-            d_u == nullptr ? nullptr : d_u_buffer_.data + i, s);
+            d_u == nullptr ? nullptr : d_u_buffer_.data + i, stream);
         offset += params_sizes_[i];
-        if (par)
-            fork_.join_to(i, stream);
     }
     if (d_u) {
         reduce_i128_device(d_u_buffer_.data, n, d_u, stream);
@@ -351,7 +314,6 @@ void FanoutSummedPotential::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
     const int n = potentials_.size();
-    const bool par = parallel_ && n > 1;
     if (d_du_dx && !d_du_dp && !d_u) {
         plan_.clear();
         this->plan_forces(N, P, d_p, plan_);
@@ -361,15 +323,8 @@ void FanoutSummedPotential::execute_device(
     if (d_u) {
         d_u_buffer_.zero_async(stream, n);
     }
-    if (par) {
-        for (int i = 0; i < n; i++)
-            fork_.fork_from(i, stream);
-    }
     for (int i = 0; i < n; i++) {
-        hipStream_t s = par ? fork_.stream(i) : stream;
-        potentials_[i]->execute_device(N, P, d_x, d_p, d_box, d_du_dx, d_du_dp, d_u == nullptr ? nullptr : d_u_buffer_.data + i, s);
-        if (par)
-            fork_.join_to(i, stream);
+        potentials_[i]->execute_device(N, P, d_x, d_p, d_box, d_du_dx, d_du_dp, d_u == nullptr ? nullptr : d_u_buffer_.data + i, stream);
     }
     if (d_u) {
         reduce_i128_device(d_u_buffer_.data, n, d_u, stream);
