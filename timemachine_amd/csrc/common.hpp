@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -62,6 +63,9 @@ struct GuardRegistry {
         HIP_CHECK(hipMemset(base, 0xA5, GUARD));
         HIP_CHECK(hipMemset(base + GUARD + bytes, 0xA5, GUARD));
         zones.push_back({base, bytes});
+        if (std::getenv("TM_GUARD_TRACE")) {
+            fprintf(stderr, "[alloc] %p .. %p  (%zu bytes)\n", static_cast<void *>(base + GUARD), static_cast<void *>(base + GUARD + bytes), bytes);
+        }
         return base + GUARD;
     }
     void free(void *p) {

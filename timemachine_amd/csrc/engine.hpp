@@ -189,9 +189,7 @@ private:
 // reference: cpp/src/summed_potential.cu:33-97
 // `parallel` (reference: children on per-child streams joined by events, stream_manager.cu:18-56) is kept as a
 // constructor argument and otherwise ignored: results never depend on it (integer accumulation), forces-only calls go
-// through one fused ForcePlan anyway, and running children on forked non-blocking streams was both slower (~30 us per
-// MD step) and, on this stack, not safe: an AllPairs child whose Hilbert re-sort was due, overlapping the pair-list
-// child, hit an intermittent GPU memory fault (scripts/guard_check.py reproduces the scenario; serial children never did).
+// through one fused ForcePlan anyway, and forked streams measured ~30 us per MD step slower than children in sequence.
 class SummedPotential : public Potential {
 public:
     SummedPotential(const std::vector<std::shared_ptr<Potential>> potentials, const std::vector<int> params_sizes, const bool parallel);

@@ -415,7 +415,13 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     }
     if (tid < NB_CLASSES) {
         s_hist[tid] = 0;
+        s_base[tid] = 0;
     }
+    // The histogram must be zero before ANY wave files its first chunk below.  Without this barrier a fast wave could
+    // count into s_hist before wave 0 had zeroed it; the count was then lost, the class looked empty, its s_base stayed
+    // uninitialised LDS, and the item went to a wild address (intermittent GPU memory faults once the cost estimate
+    // stopped waiting on global loads).
+    __syncthreads();
     // the estimate runs in f32 on coordinates relative to the first row atom
     const float cost_cutoff2 = static_cast<float>(cost_cutoff_d * cost_cutoff_d);
     for (unsigned int c = wave; c < n_chunks; c += NBL_THREADS / 64) {

@@ -110,10 +110,7 @@ struct HostStage {
             u.reserve(n_u);
             u.zero_async(stream, n_u);
         }
-        // Inputs and zeroed outputs are in place before any kernel is enqueued: container potentials run their children
-        // on forked non-blocking streams, and an event recorded on the (null) staging stream was observed NOT to hold
-        // them back until a pageable host-to-device copy had landed -- a child then binned uninitialised coordinates
-        // along the Hilbert curve (intermittent GPU memory fault on the first host-API call after a re-sort was due).
+        // inputs and zeroed outputs are in place before any kernel is enqueued (host entry points are not a hot path)
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 };
