@@ -161,8 +161,8 @@ def find_nonbonded(bps):
     raise RuntimeError("no Nonbonded in the state")
 
 
-# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/r01_v8_pmc_f64.txt
-PMC_TRAFFIC_BYTES = {"f64": (12302 + 75337) * 1024, "f32": (8813 + 69748) * 1024}
+# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/r01_v9_pmc_f64.txt
+PMC_TRAFFIC_BYTES = {"f64": (11652 + 44802) * 1024, "f32": (7215 + 33845) * 1024}
 
 
 def main():
@@ -287,10 +287,10 @@ def main():
             "unit": "GB/s",
             "frac": bytes_alg / t_s / 1e9 / HBM_PEAK_GBS,
             # FETCH_SIZE + WRITE_SIZE per dispatch of this kernel from the committed PMC passes (separate rocprofv3 --pmc runs
-            # of this very command, scripts/gpu_pmc.sh -> profiles/r01_v8_pmc_f64.txt); counters uncalibrated for this
+            # of this very command, scripts/gpu_pmc.sh -> profiles/r01_v9_pmc_f64.txt); counters uncalibrated for this
             # access pattern (MI355X_MICROARCH.md, HBM section).  ~20x the algorithmic bytes: the flush's u64 atomics.
             "traffic": PMC_TRAFFIC_BYTES.get(args.precision),
-            "traffic_source": "profiles/r01_v8_pmc_f64.txt (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
+            "traffic_source": "profiles/r01_v9_pmc_f64.txt (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
             "bytes_per_launch": bytes_alg,
             "kernel_ms": prof["kernel_ms"],
             "launches_timed": prof["launches"],

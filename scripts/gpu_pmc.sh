@@ -8,7 +8,7 @@ CMD="python $ROOT/bench.py --steps ${PMC_STEPS:-200} --warmup 10 --no-cpu-baseli
 cd /tmp
 pass() { # name, counters...
   name=$1; shift
-  timeout 900 rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc/$name -o $name -- $CMD > $ROOT/gpurun_out/pmc/$name.log 2>&1
+  timeout 150 rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc/$name -o $name -- $CMD > $ROOT/gpurun_out/pmc/$name.log 2>&1
   echo "pmc pass $name exit $?"
 }
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS
