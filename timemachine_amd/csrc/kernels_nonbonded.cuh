@@ -3,12 +3,12 @@
 // Data layout in HBM (K = number of interacting atoms, Hilbert order):
 //   gathered      Real[K][8]  = {x, y, z, w, q, sig, eps, 0}   one 64 B (f64) / 32 B (f32) record per atom,
 //                               cast to Real once at gather time (reference casts at load: k_nonbonded.cuh:134-151)
-//   g_du_dx       u64 [K][3]   fixed-point force accumulators in Hilbert order (contiguous per-tile flushes)
-//   g_du_dp       u64 [K][4]
+//   g_du_dx       u64 [3][S]   fixed-point force accumulators in Hilbert order, component-major (S = stride >= K):
+//   g_du_dp       u64 [4][S]   a flush instruction's lanes share cache lines (memory-side atomics are served per line)
 //   col_atoms     u32 pool     per row block a contiguous segment of interacting column atoms (CSR)
 //   items         int4         work items {row_block, col_start, col_count, 0}: 32 rows x <=64 columns each
 //
-// Tile kernel design (one wave = one 64-thread workgroup per work item, grid-stride):
+// Tile kernel design (one wave per work item; persistent workgroups of 8-12 waves drawing items from a per-CU pool):
 //   phase 1  every lane owns one column atom in registers; 32 rounds, lane l meets row (round + l) & 31
 //            (rotation => the rows, and the columns, hit in one round are all distinct).  All 32x64 slots get a CHEAP,
 //            CONSERVATIVE distance filter in f32 on coordinates taken relative to the tile's first row atom (so f32
