@@ -382,14 +382,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 
     while (item != NO_ITEM) {
         TM_T(t_a);
-        // ---- stage A: draw the next item now (one item of lookahead: a drained pool leaves every wave at most the item
-        // it has already drawn, and those are the lightest of the pool)
-        const unsigned int item_next = position_to_slot(next_position());
-        const bool have_next = item_next != NO_ITEM;
+        // ---- stage A happens late in this item (see the round loop): the later a wave draws its next item, the better
+        // the pool is balanced when it runs dry; the last filter iteration still hides the items[] load
+        unsigned int item_next = NO_ITEM;
+        bool have_next = false;
         int4 it_next = make_int4(0, 0, 0, 0);
-        if (have_next) {
-            it_next = items[item_next];
-        }
         TileRegs<Real> nxt;
         nxt.ja = uK;
         nxt.ra = uK;
@@ -472,7 +469,21 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         long long tm_p2_item = 0;
 #endif
         int cnt = 0; // wave-uniform number of queued pairs
+        // measured (ns/day, f64 / f32): drawn at round 0: 2145 / 2900; 16: 2175 / 2905; 24: 2190 / 2897; 28: 2207 / 2925;
+        // after the last round (descriptor load exposed): 2190 / 2965
+#ifdef TM_TICKET_ROUND
+        constexpr int TICKET_ROUND = TM_TICKET_ROUND;
+#else
+        constexpr int TICKET_ROUND = sizeof(Real) == 8 ? TILE - 4 : TILE;
+#endif
         for (int round0 = 0; round0 < TILE; round0 += 4) {
+            if (round0 == TICKET_ROUND) { // ---- stage A: draw the next item, request its descriptor
+                item_next = position_to_slot(next_position());
+                have_next = item_next != NO_ITEM;
+                if (have_next) {
+                    it_next = items[item_next];
+                }
+            }
             // ---- phase 1: four conservative f32 distance filters per lane (four independent LDS reads in flight)
             float4 rf[4];
             int ri[4];
@@ -590,6 +601,13 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 tm_p2_item += clock64() - t_h0;
                 tm_batches++;
 #endif
+            }
+        }
+        if (TICKET_ROUND >= TILE) { // f32: draw only now (the descriptor load is exposed, the balance pays for it)
+            item_next = position_to_slot(next_position());
+            have_next = item_next != NO_ITEM;
+            if (have_next) {
+                it_next = items[item_next];
             }
         }
         // ---- stages B + C: the next item's indices, then its atom records, enter the memory queue ahead of this item's
