@@ -186,7 +186,7 @@ def main():
     N = system.num_atoms
 
     def make_bps(prec):
-        # one SummedPotential for the whole state, children on forked streams -- how the reference packs a state
+        # one SummedPotential for the whole state -- how the reference packs a state
         # (fe/free_energy.py:614-657: make_summed_potential(...).to_gpu(np.float32) -> one BoundPotential)
         bps = ts.bound_potentials(system, prec)
         if args.separate_potentials:

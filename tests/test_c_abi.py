@@ -116,3 +116,29 @@ def test_filter_exclusions_matches_oracle():
     np.testing.assert_array_equal(b, d)
     e, f = filter_exclusions(np.array([0], dtype=np.int32), excl, scales)
     assert e.shape == (0, 2) and f.shape == (0, 2)
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The bench lines kept under profiles/ carry every field the driver and the judge read (metric, whole-job value,
+    roofline with live kernel time + PMC traffic, CPU baseline with its sample description)."""
+    import glob
+    import json
+
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_v*_bench.json")))
+    assert paths, "no committed bench line"
+    d = json.load(open(paths[-1]))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "ns/day" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port")
+    # value == steps / time: ns/day from ms per step at 2.5 fs
+    assert abs(d["value"] - d["n_gpus"] * 86400.0 * 2.5e-6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
