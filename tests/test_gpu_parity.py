@@ -1019,6 +1019,48 @@ def test_pregathered_steps_are_bitwise_the_full_path(co, P, precision):
     assert not np.array_equal(changed.get_x_t(), ref2.get_x_t())
 
 
+def test_pregather_with_atom_subset_and_interaction_group(co, P):
+    """The integrator's hand-over with potentials that own only part of the atoms: an all-pairs potential over a subset
+    (atoms outside it have no slot) next to an interaction group (rows | columns sorted separately) -- two producers of
+    deferred forces in one context.  Stepping in one go and re-setting the coordinates before every step (always the
+    full gather path) must agree bit for bit across two Hilbert re-sorts."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    N = s.num_atoms
+    rng = np.random.default_rng(3)
+    v0 = rng.normal(size=(N, 3)) * 0.1
+    ligand = np.arange(N - 16, N, dtype=np.int32)
+    env = np.arange(0, N - 16, dtype=np.int32)
+    subset = env[: (len(env) // 9) * 6]  # two thirds of the solvent (whole waters): the rest has no nonbonded partner at all
+    in_subset = np.isin(s.exclusion_idxs, subset).all(axis=1)
+    excl_idxs, excl_scales = s.exclusion_idxs[in_subset], s.scale_factors[in_subset]
+
+    def make():
+        pots = [
+            P.HarmonicBond(s.bond_idxs).bind(s.bond_params),
+            P.HarmonicAngle(s.angle_idxs).bind(s.angle_params),
+            P.NonbondedAllPairs(N, s.beta, s.cutoff, atom_idxs=subset).bind(s.nb_params),
+            P.NonbondedInteractionGroup(N, ligand, s.beta, s.cutoff, col_atom_idxs=subset).bind(s.nb_params),
+            P.NonbondedExclusions(excl_idxs, excl_scales, s.beta, s.cutoff).bind(s.nb_params),
+        ]
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in pots]
+        return co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 2.0e-4, 5.0, s.masses, 17).impl(), bps)
+
+    n_steps = 210
+    ref = make()
+    xs_ref, _ = ref.multiple_steps(n_steps, 15)
+    assert np.all(np.isfinite(xs_ref))
+    full = make()
+    for k in range(n_steps):
+        full.set_x_t(full.get_x_t())
+        full.step()
+        if (k + 1) % 15 == 0:
+            np.testing.assert_array_equal(full.get_x_t(), xs_ref[(k + 1) // 15 - 1])
+    np.testing.assert_array_equal(full.get_v_t(), ref.get_v_t())
+
+
 def test_langevin_thermostat_statistics(co, P):
     """Statistical parity for the stochastic part (cuRAND streams cannot be matched): ideal gas (no potentials) with
     friction reaches kT per degree of freedom; the noise has zero mean, unit variance and no lag-1 correlation."""
