@@ -582,6 +582,39 @@ def test_bitwise_invariances(co, P, precision):
     assert ap[2] + ex[2] == base[2]
 
 
+def test_large_box_decomposes_bitwise(co, P):
+    """69 696 atoms, cutoff 1.5 nm: more than 2048 column blocks (the list build walks them in two LDS chunks) and row
+    blocks that list more column atoms than the build stages in LDS (the cost estimate's global fallback).  The
+    all-pairs result must equal, bit for bit, the sum of the two halves and their interaction group -- which stay on the
+    single-chunk paths (the decomposition of the reference's tests/nonbonded/test_consistency.py, at a size that reaches
+    the code the small systems do not)."""
+    from timemachine_amd import testsystems as ts
+
+    s = ts.build_water_box(23232, 8.86, seed=9)
+    N = s.num_atoms
+    assert N > 65536
+    cutoff = 1.5
+    x, p, box = s.coords, s.nb_params, s.box
+    a_idxs = np.arange(0, (N // 6) * 3, dtype=np.int32)
+    b_idxs = np.arange((N // 6) * 3, N, dtype=np.int32)
+
+    def raw(pot):
+        return pot.to_gpu(np.float32).unbound_impl.execute_raw(x, p, box)
+
+    whole = raw(P.NonbondedAllPairs(N, s.beta, cutoff))
+    parts = [
+        raw(P.NonbondedAllPairs(N, s.beta, cutoff, atom_idxs=a_idxs)),
+        raw(P.NonbondedAllPairs(N, s.beta, cutoff, atom_idxs=b_idxs)),
+        raw(P.NonbondedInteractionGroup(N, a_idxs, s.beta, cutoff, col_atom_idxs=b_idxs)),
+    ]
+    with np.errstate(over="ignore"):
+        np.testing.assert_array_equal(parts[0][0] + parts[1][0] + parts[2][0], whole[0])
+        np.testing.assert_array_equal(parts[0][1] + parts[1][1] + parts[2][1], whole[1])
+        assert np.all(whole[0].sum(axis=0, dtype=np.uint64) == 0)
+    assert parts[0][2] + parts[1][2] + parts[2][2] == whole[2]
+    assert whole[2] != 0
+
+
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 def test_exclusions_cancel_exactly_with_clashing_atoms(co, P, precision):
     """10 mutually excluded atoms within 1e-3 nm of each other: the all-pairs terms are astronomically large and must
