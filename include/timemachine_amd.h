@@ -104,7 +104,8 @@ int tm_chiral_atom_restraint_create(int precision, const int32_t *idxs, int num_
 /* ChiralBondRestraint_*(idxs int32[R,4], signs int32[R]); params [R] wrap_kernels.cpp:1380-1394; chiral_bond_restraint.cu:10-82 */
 int tm_chiral_bond_restraint_create(int precision, const int32_t *idxs, int num_restraints, const int32_t *signs, int num_signs,
                                     tm_potential_t *out);
-/* SummedPotential(potentials, params_sizes, parallel=True)          wrap_kernels.cpp:1661-1676; summed_potential.cu:13-26 */
+/* SummedPotential(potentials, params_sizes, parallel=True)          wrap_kernels.cpp:1661-1676; summed_potential.cu:13-26
+   `parallel` is accepted for interface parity and ignored: children run in sequence, results cannot depend on it. */
 int tm_summed_potential_create(const tm_potential_t *potentials, int num_potentials, const int32_t *params_sizes,
                                int num_params_sizes, int parallel, tm_potential_t *out);
 /* FanoutSummedPotential(potentials, parallel=True)                  wrap_kernels.cpp:1678-1691; fanout_summed_potential.cu:9-16 */
