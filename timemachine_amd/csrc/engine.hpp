@@ -89,7 +89,9 @@ public:
     // be handed back un-scattered instead (see DeferredForces).
     // d_du_dx_cm != nullptr: a second, component-major accumulator (component d of atom a at [d * cm_stride + a]) that
     // receives the table's terms; potentials that launch their own kernels keep adding to the [N, 3] array d_du_dx.
-    void run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
+    // Returns whether anything was (or may have been) added to d_du_dx -- a consumer that owns both arrays can skip
+    // reading and re-zeroing an untouched [N, 3] array.
+    bool run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
              std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0, u64 *d_du_dx_cm = nullptr,
              const int cm_stride = 0);
 

@@ -34,9 +34,10 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
     t.n++;
 }
 
-void ForcePlan::run(
+bool ForcePlan::run(
     const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
     const int max_deferred, u64 *d_du_dx_cm, const int cm_stride) {
+    bool wrote_du_dx = false; // did anything add to the [N, 3] array?
     // the table's terms go to the caller's component-major accumulator when there is one (lanes working on neighbouring
     // atoms then share cache lines: fewer line requests for the memory-side atomics), to the [N, 3] array otherwise
     u64 *table_acc = d_du_dx_cm ? d_du_dx_cm : d_du_dx;
@@ -85,6 +86,7 @@ void ForcePlan::run(
             deferred->push_back(df);
         } else {
             r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
+            wrote_du_dx = true;
         }
     }
     // 4. tables nobody took
@@ -102,6 +104,8 @@ void ForcePlan::run(
         HIP_CHECK(hipGetLastError());
         Profiler::get().end("fused_forces", prof, stream);
     }
+    // the table's terms (piggy-backed or launched above) went to table_acc
+    return wrote_du_dx || table_acc == d_du_dx;
 }
 
 } // namespace tmamd

@@ -110,7 +110,11 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 // wrapping integer sum: same bits as a scatter-add of every contribution into one array would give
-                u64 f = du_dx[atom * 3 + d] + du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+                u64 f = du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+                if (du_dx != nullptr) { // nullptr: nothing was added to the [N, 3] array this step (it stays zero)
+                    f += du_dx[atom * 3 + d];
+                    du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
+                }
                 if (s0 >= 0) {
                     f += g0[static_cast<size_t>(d) * stride0 + s0];
                 }
@@ -123,7 +127,6 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 v_t[atom * 3 + d] = static_cast<double>(v_new);
                 xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
                 x_t[atom * 3 + d] = xn[d];
-                du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
                 du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
             }
             pregather_atom(pg0, s0, atom, xn[0], xn[1], xn[2]);
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
         } else if (idxs != nullptr) {
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                du_dx[kidx * 3 + d] = 0;
+                if (du_dx != nullptr) {
+                    du_dx[kidx * 3 + d] = 0;
+                }
                 du_dx_cm[static_cast<size_t>(d) * cm_stride + kidx] = 0;
             }
         }
@@ -167,7 +172,7 @@ void LangevinIntegrator<Real>::step_fwd(
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
     }
     deferred_.clear();
-    plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2, d_du_dx_cm_.data, cm_stride_);
+    const bool wrote_du_dx = plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2, d_du_dx_cm_.data, cm_stride_);
     const DeferredForces none;
     const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
@@ -179,8 +184,8 @@ void LangevinIntegrator<Real>::step_fwd(
     const PregatherTarget no_target;
     const bool pregather = d_idxs == nullptr;
     k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
-        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, d_du_dx_.data, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.slot_of_atom,
-        df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
+        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, d_du_dx_cm_.data, cm_stride_, dt_,
+        df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
     HIP_CHECK(hipGetLastError());
     if (pregather) {
         for (const DeferredForces &df : deferred_) {
