@@ -120,6 +120,8 @@ int tm_nonbonded_all_pairs_get_num_atom_idxs(tm_potential_t pot, int *count);
 int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int cap);
 /* tiles (32 rows x 32 columns) in the current interaction list; diagnostic used by bench.py */
 int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count);
+/* diagnostic: neighbor-list builds since construction (rebuild period of an MD run = calls / builds) */
+int tm_nonbonded_all_pairs_get_build_count(tm_potential_t pot, unsigned int *count);
 /* per-wave cycle counters of the last tile-kernel launch: [waves][8] = {setup, phase1, phase2, flush, items, batches, total, 0};
  * all zero unless the library was built with -DTM_TIMING (development aid, see scripts/ablate.py) */
 int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n);
@@ -239,6 +241,14 @@ int tm_hilbert_lut(uint32_t *out);
 int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
+/* debug: run the DEVICE fixed-point conversions (the functions the kernels inline) on caller-supplied values.
+ *   kind 0: FLOAT_TO_FIXED (2^36; forces of bonded terms, du/dq, du/dw)      k_fixed_point.cuh:56-71
+ *   kind 1 / 2: FLOAT_TO_FIXED_DU_DP with 2^37 (du/dsig) / 2^38 (du/deps)    fixed_point.hpp:8-11
+ *   kind 3: the nonbonded force form FIX(prefactor * delta); `in` holds n (prefactor, delta) pairs   k_nonbonded.cuh:244-252
+ * values are cast to the precision's Real first (f32: to float).  tm_debug_float_to_fixed_energy: FLOAT_TO_FIXED_ENERGY
+ * (k_fixed_point.cuh:88-98: non-finite / beyond the int64 range -> LLONG_MAX). */
+int tm_debug_float_to_fixed(int precision, int kind, const double *in, int n, uint64_t *out);
+int tm_debug_float_to_fixed_energy(int precision, const double *in, int n, tm_int128 *out);
 /* debug builds (-DTM_GUARD: guard zones around every device buffer): number of violated zones; -1 in product builds */
 int tm_debug_check_guards(int *violations);
 

@@ -1,6 +1,7 @@
 """Numpy-backed stand-in for the tiny part of the `jax` namespace that the reference's
 ``timemachine/potentials/{nonbonded,bonded,jax_utils}.py`` and ``timemachine/integrator.py``
-touch at import time and when evaluating *energies*.
+touch at import time and when evaluating *energies*; plus what ``timemachine/md/hrex.py`` (lax.scan / lax.cond in
+_run_neighbor_swaps) and ``timemachine/md/barostat/moves.py`` (jax.ops.segment_sum in CentroidRescaler) need.
 
 TEST INFRASTRUCTURE ONLY. jax/jaxlib are not installable in the build container (no network), so
 the golden-vector generator (generate_golden.py) materialises this shim in a temporary directory
@@ -20,7 +21,7 @@ def materialise(root: str) -> None:
     files = {
         "jax/__init__.py": '''
             import numpy as _np
-            from . import numpy, scipy, typing, core, random, config as _cfgmod
+            from . import numpy, scipy, typing, core, random, ops, config as _cfgmod
             Array = _np.ndarray
             class _Config:
                 def update(self, *a, **k):
@@ -62,9 +63,39 @@ def materialise(root: str) -> None:
                 raise NotImplementedError("jax.grad is not available in the numpy shim")
             value_and_grad = grad
             class lax:
-                pass
+                @staticmethod
+                def cond(pred, true_fun, false_fun, *operands):
+                    return true_fun(*operands) if bool(pred) else false_fun(*operands)
+                @staticmethod
+                def scan(f, init, xs, length=None):
+                    # xs: an array or a tuple of arrays scanned along axis 0; ys are stacked unless every one is None
+                    carry = init
+                    n = len(xs[0]) if isinstance(xs, tuple) else len(xs)
+                    ys = []
+                    for i in range(n):
+                        x = tuple(a[i] for a in xs) if isinstance(xs, tuple) else xs[i]
+                        carry, y = f(carry, x)
+                        ys.append(y)
+                    if all(y is None for y in ys):
+                        return carry, None
+                    return carry, _np.stack(ys)
+                @staticmethod
+                def fori_loop(lo, hi, body, val):
+                    for i in range(lo, hi):
+                        val = body(i, val)
+                    return val
         ''',
         "jax/config.py": "",
+        "jax/ops.py": '''
+            import numpy as _np
+            def segment_sum(data, segment_ids, num_segments=None):
+                data = _np.asarray(data)
+                segment_ids = _np.asarray(segment_ids)
+                n = int(segment_ids.max()) + 1 if num_segments is None else num_segments
+                out = _np.zeros((n,) + data.shape[1:], dtype=data.dtype)
+                _np.add.at(out, segment_ids, data)
+                return out
+        ''',
         "jax/core.py": "class Tracer: pass\n",
         "jax/typing.py": "from typing import Any\nArrayLike = Any\n",
         "jax/random.py": "def PRNGKey(*a, **k):\n    raise NotImplementedError\n",

@@ -102,20 +102,29 @@ def test_dataclass_field_order_is_constructor_order():
         P.HarmonicBond._custom_ops_class_name(np.float16)
 
 
-def test_filter_exclusions_matches_oracle():
+def test_filter_exclusions_matches_reference_fixture():
+    """filter_exclusions against the outputs of the reference's own function (timemachine/potentials/nonbonded.py:176-218),
+    recorded by tests/golden/generate_golden_next.py: three atom sets (a shuffled subset, everything, a single atom =>
+    empty result with the reference's shapes) x update_idxs in {False, True}; and against the oracle's restatement."""
+    import os
+
     from oracle import ref_potentials as rp
     from timemachine_amd.potentials import filter_exclusions
 
-    rng = np.random.default_rng(1)
-    excl = np.stack([rng.permutation(50)[:2] for _ in range(40)]).astype(np.int32)
-    scales = rng.uniform(size=(40, 2))
-    atom_idxs = np.sort(rng.choice(50, 30, replace=False)).astype(np.int32)
-    a, b = filter_exclusions(atom_idxs, excl, scales)
-    c, d = rp.filter_exclusions(atom_idxs, excl, scales)
-    np.testing.assert_array_equal(a, c)
-    np.testing.assert_array_equal(b, d)
-    e, f = filter_exclusions(np.array([0], dtype=np.int32), excl, scales)
-    assert e.shape == (0, 2) and f.shape == (0, 2)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filter_exclusions.npz"))
+    excl, scales = g["exclusion_idxs"], g["scale_factors"]
+    for k in range(3):
+        atom_idxs = g[f"atom_idxs_{k}"]
+        for upd in (False, True):
+            idxs, sc = filter_exclusions(atom_idxs, excl, scales, update_idxs=upd)
+            assert idxs.dtype == np.int32 and idxs.shape == g[f"idxs_{k}_{int(upd)}"].shape
+            np.testing.assert_array_equal(idxs, g[f"idxs_{k}_{int(upd)}"])
+            np.testing.assert_array_equal(sc, g[f"scales_{k}_{int(upd)}"])
+        c, d = rp.filter_exclusions(atom_idxs, excl, scales)
+        np.testing.assert_array_equal(c, g[f"idxs_{k}_0"].reshape(-1, 2))
+        np.testing.assert_array_equal(d, g[f"scales_{k}_0"])
+    e, f = filter_exclusions(g["atom_idxs_2"], excl, scales)
+    assert e.size == 0 and f.shape == (0, 2)
 
 
 def test_committed_bench_lines_follow_the_contract():

@@ -205,3 +205,88 @@ def test_restraint_potentials_match_reference_golden():
         u, gx, _ = rp.centroid_restraint(x, None, None, g["cr_a"], g["cr_b"], float(g[f"{tag}_kb"]), float(g[f"{tag}_b0"]))
         np.testing.assert_allclose(u, float(g[f"{tag}_u"]), rtol=1e-12)
         np.testing.assert_allclose(gx, g[f"{tag}_du_dx"], rtol=1e-10, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The "next" rows: oracles pinned to fixtures made by the reference's own Python
+# (tests/golden/generate_golden_next.py imports timemachine/integrator.py, md/barostat/moves.py, md/hrex.py)
+# ----------------------------------------------------------------------------------------------------------------
+def test_velocity_verlet_oracle_matches_reference_fixture():
+    """oracle/integrator.py:velocity_verlet_device_model (double state, k_integrator.cuh:64-130) against the trajectory of
+    the reference's Python VelocityVerletIntegrator.multiple_steps (fixed-point state, timemachine/integrator.py:169-199).
+    The two differ by the 2^-36 quantisation of the reference's state only."""
+    from oracle import integrator as oi
+    from oracle import ref_potentials as rp
+    from oracle.fixed_point import float_to_fixed
+
+    g = load("vv.npz")
+    box = g["box"]
+
+    def grad_fixed(x):
+        gb = rp.harmonic_bond(x, g["bond_params"], box, g["bond_idxs"])[1]
+        ga = rp.harmonic_angle(x, g["angle_params"], box, g["angle_idxs"])[1]
+        return float_to_fixed(gb + ga)
+
+    dt, n_steps = float(g["dt"]), int(g["n_steps"])
+    x, v = oi.velocity_verlet_device_model(g["x0"], g["v0"], grad_fixed, -dt / g["masses"], dt, n_steps + 1)
+    np.testing.assert_allclose(x, g["ref_xs"][-1], rtol=0, atol=5e-10)
+    np.testing.assert_allclose(v, g["ref_vs"][-1], rtol=0, atol=5e-8)
+    np.testing.assert_allclose(g["ref_xs"][0], g["x0"], rtol=0, atol=2.0**-36)  # zs[0] is the start, quantised (integrator.py:179-181)
+    # frame by frame: the reference stores x after k + 1 drifts in xs[k] (k >= 1; "xs[1] = x_2", integrator.py:171-177)
+    for k in (2, 5, n_steps + 1):
+        xk, _ = oi.velocity_verlet_device_model(g["x0"], g["v0"], grad_fixed, -dt / g["masses"], dt, k)
+        np.testing.assert_allclose(xk, g["ref_xs"][k - 1], rtol=0, atol=5e-10)
+
+
+def test_barostat_oracle_matches_reference_centroid_rescaler():
+    """oracle/barostat.py:propose against the reference's CentroidRescaler.scale_centroids (md/barostat/moves.py:39-83)
+    evaluated at the oracle's own f32 length scales: equal modulo the wrap into the scaled home box that the device adds
+    (whole molecules shifted by whole box edges), to f32 accuracy; the f64 form is asserted to 1e-9 by the generator."""
+    from oracle import barostat as ob
+
+    g = load("barostat.npz")
+    x, box = g["x"], g["box"]
+    bounds = np.concatenate([[0], np.cumsum(g["group_sizes"])])
+    groups = [np.arange(bounds[k], bounds[k + 1]) for k in range(len(bounds) - 1)]
+    for attempt in range(len(g["scales"])):
+        u1, _ = ob.attempt_uniforms(int(g["seed"]), attempt)
+        x_p, box_p, (_, _, scale) = ob.propose(x, box, groups, float(g["volume_scale"]), u1, real=np.float32)
+        assert scale == g["scales"][attempt]
+        shift = (x_p - g["x_scaled"][attempt]) / np.diagonal(box_p)
+        resid = (shift - np.rint(shift)) * np.diagonal(box_p)
+        assert np.abs(resid).max() < 5e-6, (attempt, np.abs(resid).max())
+        for grp in groups:
+            assert np.all(np.rint(shift[grp]) == np.rint(shift[grp][0]))
+
+
+def test_hrex_swap_chain_matches_reference_fixture():
+    """timemachine_amd.hrex.run_neighbor_swaps and oracle/hrex.py against the reference's _run_neighbor_swaps
+    (timemachine/md/hrex.py:50-130) on recorded pair indices / uniforms, incl. -inf (unevaluated) entries: bitwise."""
+    from oracle import hrex as oh
+    from timemachine_amd import hrex as th
+
+    g = load("hrex.npz")
+    for tag in ("a", "b"):
+        args = (g[f"{tag}_perm0"], g[f"{tag}_pairs"], g[f"{tag}_log_q"], g[f"{tag}_pair_idxs"], g[f"{tag}_uniforms"])
+        perm, proposed, accepted = th.run_neighbor_swaps(*args)
+        np.testing.assert_array_equal(perm, g[f"{tag}_perm"])
+        np.testing.assert_array_equal(proposed, g[f"{tag}_proposed"])
+        np.testing.assert_array_equal(accepted, g[f"{tag}_accepted"])
+        p2, pr2, ac2 = oh.run_moves(list(args[0]), [tuple(p) for p in args[1]], args[2], args[3], args[4])
+        np.testing.assert_array_equal(p2, g[f"{tag}_perm"])
+        np.testing.assert_array_equal(ac2, g[f"{tag}_accepted"])
+        assert int(g[f"{tag}_accepted"].sum()) > 0
+
+
+def test_edge_case_goldens_against_oracle():
+    """orthorhombic box / whole-box drifts / config 1 in both boxes: the oracle reproduces the recorded reference energies
+    (so GPU tests that compare with these fixtures and with the oracle on the fly are comparing with the same thing)."""
+    from oracle import ref_potentials as rp
+
+    for name in ("edge_ortho", "edge_drift", "config1_vacuum", "config1_pbc"):
+        g = load(name + ".npz")
+        u, gx, _ = rp.nonbonded(g["x"], g["params"], g["box"], g["exclusion_idxs"], g["scale_factors"], float(g["beta"]), float(g["cutoff"]))
+        assert abs(u - float(g["u"])) <= 1e-11 * max(1.0, abs(u))
+        np.testing.assert_allclose(gx, g["du_dx"], rtol=0, atol=1e-9)
+    a, b = load("edge_ortho.npz"), load("edge_drift.npz")
+    assert abs(float(a["u"]) - float(b["u"])) < 1e-9 * abs(float(a["u"]))

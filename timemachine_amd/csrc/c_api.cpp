@@ -363,6 +363,12 @@ int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *coun
     TM_CATCH
 }
 
+int tm_nonbonded_all_pairs_get_build_count(tm_potential_t pot, unsigned int *count) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { *count = p.num_builds(); });
+    TM_CATCH
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int tm_potential_execute(
     tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, uint64_t *du_dx, uint64_t *du_dp,
@@ -783,6 +789,18 @@ int tm_profile_read(const char *kernel_name, double *total_ms, long long *launch
 int tm_profile_reset(void) {
     TM_TRY
     Profiler::get().reset();
+    TM_CATCH
+}
+int tm_debug_float_to_fixed(int precision, int kind, const double *in, int n, uint64_t *out) {
+    TM_TRY
+    require(precision == TM_F32 || precision == TM_F64, "invalid precision");
+    debug_float_to_fixed(precision == TM_F64 ? 8 : 4, kind, n, in, reinterpret_cast<u64 *>(out));
+    TM_CATCH
+}
+int tm_debug_float_to_fixed_energy(int precision, const double *in, int n, tm_int128 *out) {
+    TM_TRY
+    require(precision == TM_F32 || precision == TM_F64, "invalid precision");
+    debug_float_to_fixed_energy(precision == TM_F64 ? 8 : 4, n, in, as_i128(out));
     TM_CATCH
 }
 int tm_debug_check_guards(int *violations) {

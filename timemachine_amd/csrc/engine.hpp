@@ -353,6 +353,7 @@ public:
     void set_idxs_device(const int NC, const int NR, const unsigned int *d_col_idxs, const unsigned int *d_row_idxs, hipStream_t stream);
 
     unsigned int num_tile_ixns();
+    unsigned int num_builds(); // list builds since construction (diagnostic)
     std::vector<std::vector<int>> get_nblist_host(const int N, const double *h_coords, const double *h_box, const double cutoff);
     void compute_block_bounds_host(const int N, const double *h_coords, const double *h_box, double *h_bb_ctrs, double *h_bb_exts);
 
@@ -415,6 +416,7 @@ public:
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
+    unsigned int num_builds() { return nblist_.num_builds(); }
     std::vector<long long> debug_timing(); // [grid][8] raw counters of the last tile-kernel launch (TM_TIMING builds)
 
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
@@ -474,6 +476,9 @@ private:
 };
 
 void nb_du_dp_fixed_to_float(const int N, const u64 *du_dp, double *out);
+// debug: the device fixed-point conversions applied to host-supplied values (nonbonded.hip)
+void debug_float_to_fixed(const int precision_bytes, const int kind, const int n, const double *h_in, u64 *h_out);
+void debug_float_to_fixed_energy(const int precision_bytes, const int n, const double *h_in, i128 *h_out);
 
 // reference: cpp/src/nonbonded_pair_list.{hpp,cu}; Negated == true is bound as NonbondedExclusions_*
 template <typename Real, bool Negated> class NonbondedPairList : public Potential {

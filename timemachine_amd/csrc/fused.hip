@@ -57,9 +57,12 @@ bool ForcePlan::run(
         }
         if (!uploaded_valid_[prec] || std::memcmp(&uploaded_[prec], &t, sizeof(FusedTable)) != 0) {
             d_table_[prec].reserve(1);
-            // pageable source: the runtime stages the bytes before returning, so host_ may change right away
-            HIP_CHECK(hipMemcpyAsync(d_table_[prec].data, &t, sizeof(FusedTable), hipMemcpyHostToDevice, stream));
+            // uploads happen only when the table changed (potentials added / re-bound), never on a plain MD step: copy
+            // from the snapshot, in stream order, and wait -- host_ is rewritten by the next clear()/add_segment, and
+            // whether an async copy from pageable memory has been staged by the time the call returns is not guaranteed
             std::memcpy(&uploaded_[prec], &t, sizeof(FusedTable));
+            HIP_CHECK(hipMemcpyAsync(d_table_[prec].data, &uploaded_[prec], sizeof(FusedTable), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
             uploaded_valid_[prec] = true;
         }
     }

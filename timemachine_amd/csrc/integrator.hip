@@ -20,15 +20,18 @@ namespace tmamd {
 
 static const double BOLTZ = 0.008314462618; // kJ/mol/K, cpp/src/constants.hpp:5
 
-// three N(0,1) variates for (atom, step) by Box-Muller on Philox output
+// three N(0,1) variates for (atom, step) by Box-Muller on Philox output, in the integrator's own precision (the
+// reference draws RealType normals: curandGenerateNormal / curandGenerateNormalDouble, langevin_integrator.cu:74-79).
+// float: the radial uniforms use all 32 random bits, (r + 1/2) 2^-32 in (0, 1]: exact for the small values that make the
+// tails, which reach sqrt(-2 ln 2^-33) = 6.8 sigma.  double: 53-bit uniforms from a second Philox block; tails to 8.6 sigma.
 __device__ __forceinline__ void normal3(unsigned long long seed, unsigned long long step, unsigned int atom, float n[3]) {
     unsigned int r[4];
     philox4x32_10(atom, static_cast<unsigned int>(step), static_cast<unsigned int>(step >> 32), 0x54494d45u,
                   static_cast<unsigned int>(seed), static_cast<unsigned int>(seed >> 32), r);
     const float two_pow_m32 = 2.3283064365386963e-10f;
-    const float u0 = (static_cast<float>(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0,1), never 0
+    const float u0 = fminf((static_cast<float>(r[0]) + 0.5f) * two_pow_m32, 1.0f); // (0, 1]: never 0
     const float u1 = static_cast<float>(r[1]) * two_pow_m32;
-    const float u2 = (static_cast<float>(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = fminf((static_cast<float>(r[2]) + 0.5f) * two_pow_m32, 1.0f);
     const float u3 = static_cast<float>(r[3]) * two_pow_m32;
     const float two_pi = 6.2831853071795864769f;
     const float ra = sqrtf(-2.0f * logf(u0));
@@ -38,6 +41,27 @@ __device__ __forceinline__ void normal3(unsigned long long seed, unsigned long l
     n[0] = ra * c;
     n[1] = ra * s;
     n[2] = rb * cosf(two_pi * u3);
+}
+__device__ __forceinline__ void normal3(unsigned long long seed, unsigned long long step, unsigned int atom, double n[3]) {
+    unsigned int r[4], q[4];
+    philox4x32_10(atom, static_cast<unsigned int>(step), static_cast<unsigned int>(step >> 32), 0x54494d45u,
+                  static_cast<unsigned int>(seed), static_cast<unsigned int>(seed >> 32), r);
+    philox4x32_10(atom, static_cast<unsigned int>(step), static_cast<unsigned int>(step >> 32), 0x54494d46u,
+                  static_cast<unsigned int>(seed), static_cast<unsigned int>(seed >> 32), q);
+    const double two_pow_m53 = 1.1102230246251565e-16;
+    auto u53 = [&](unsigned int hi, unsigned int lo) { // (0, 1)
+        const unsigned long long bits = (static_cast<unsigned long long>(hi) << 21) | (lo >> 11);
+        return (static_cast<double>(bits) + 0.5) * two_pow_m53;
+    };
+    const double u0 = u53(r[0], q[0]), u1 = u53(r[1], q[1]), u2 = u53(r[2], q[2]), u3 = u53(r[3], q[3]);
+    const double two_pi = 6.2831853071795864769;
+    const double ra = sqrt(-2.0 * log(u0));
+    const double rb = sqrt(-2.0 * log(u2));
+    double s, c;
+    sincos(two_pi * u1, &s, &c);
+    n[0] = ra * c;
+    n[1] = ra * s;
+    n[2] = rb * cos(two_pi * u3);
 }
 
 // Leaves a force producer's next gather done (PregatherTarget): new position into its sorted record, rebuild test against
@@ -99,7 +123,7 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
         if (atom < N) {
             const Real cb = cbs[atom];
             const Real cc = ccs[atom];
-            float nz[3] = {0.f, 0.f, 0.f};
+            Real nz[3] = {0, 0, 0};
             if (cc != 0) {
                 normal3(seed, step, static_cast<unsigned int>(atom), nz);
             }
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 }
                 const Real force = -fixed_to_float<Real>(f);
                 const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
-                const Real v_new = ca * v_mid + cc * static_cast<Real>(nz[d]);
+                const Real v_new = ca * v_mid + cc * nz[d];
                 v_t[atom * 3 + d] = static_cast<double>(v_new);
                 xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
                 x_t[atom * 3 + d] = xn[d];
@@ -166,6 +190,11 @@ template <typename Real>
 void LangevinIntegrator<Real>::step_fwd(
     std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
     hipStream_t stream) {
+    if (d_idxs != nullptr) {
+        // the kernels carry the reference's index-list branches (k_integrator.cuh:12-22), but no local-MD driver exists
+        // here to exercise them: refuse rather than run untested code
+        throw std::runtime_error("LangevinIntegrator: local MD (an atom index list) is not built in timemachine_amd");
+    }
     // forces only: every bound potential describes itself to one plan, so short per-term kernels share a launch
     plan_.clear();
     for (auto &bp : bps) {
@@ -254,6 +283,9 @@ VelocityVerletIntegrator::VelocityVerletIntegrator(const int N, const double dt,
 void VelocityVerletIntegrator::forces_then_update(
     const int mode, std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t,
     unsigned int *d_idxs, hipStream_t stream) {
+    if (d_idxs != nullptr) {
+        throw std::runtime_error("VelocityVerletIntegrator: local MD (an atom index list) is not built in timemachine_amd");
+    }
     plan_.clear();
     for (auto &bp : bps) {
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);

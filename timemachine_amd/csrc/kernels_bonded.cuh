@@ -46,7 +46,9 @@ __device__ __forceinline__ i128 harmonic_bond_term(
     Real d2 = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const Real delta = static_cast<Real>(coords[src * 3 + d]) - static_cast<Real>(coords[dst * 3 + d]);
+        // the displacement is formed in double and rounded once (k_harmonic_bond.cuh:27): the f32 kernels then keep
+        // ~1e-8 nm of resolution however far the unwrapped coordinates have drifted
+        const Real delta = static_cast<Real>(coords[src * 3 + d] - coords[dst * 3 + d]);
         dx[d] = delta;
         d2 += delta * delta;
     }
@@ -105,9 +107,9 @@ __device__ __forceinline__ i128 harmonic_angle_term(
     Real nji = 0, njk = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const Real cj = static_cast<Real>(coords[j * 3 + d]);
-        rji[d] = static_cast<Real>(coords[i * 3 + d]) - cj;
-        rjk[d] = static_cast<Real>(coords[k * 3 + d]) - cj;
+        const double cj = coords[j * 3 + d]; // differences in double, rounded once (k_harmonic_angle.cuh:44-45)
+        rji[d] = static_cast<Real>(coords[i * 3 + d] - cj);
+        rjk[d] = static_cast<Real>(coords[k * 3 + d] - cj);
         nji += rji[d] * rji[d];
         njk += rjk[d] * rjk[d];
     }
@@ -215,11 +217,11 @@ __device__ __forceinline__ i128 periodic_torsion_term(
     Real rkj_n2 = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const Real ci = static_cast<Real>(coords[i * 3 + d]), cj = static_cast<Real>(coords[j * 3 + d]);
-        const Real ck = static_cast<Real>(coords[k * 3 + d]), cl = static_cast<Real>(coords[l * 3 + d]);
-        rij[d] = cj - ci;
-        rkj[d] = cj - ck;
-        rkl[d] = cl - ck;
+        const double ci = coords[i * 3 + d], cj = coords[j * 3 + d]; // differences in double, rounded once
+        const double ck = coords[k * 3 + d], cl = coords[l * 3 + d]; // (k_periodic_torsion.cuh:49-51)
+        rij[d] = static_cast<Real>(cj - ci);
+        rkj[d] = static_cast<Real>(cj - ck);
+        rkl[d] = static_cast<Real>(cl - ck);
         rkj_n2 += rkj[d] * rkj[d];
     }
     const Real rkj_norm = tm_sqrt<Real>(rkj_n2);

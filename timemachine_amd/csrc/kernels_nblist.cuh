@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     const int n_row_blocks, const int NR, const unsigned int *__restrict__ row_idxs, // only used when rows != cols
     const int rows_equal_cols, const Real *__restrict__ gathered, const double *__restrict__ box,
     Real *__restrict__ col_ctr, Real *__restrict__ col_ext, Real *__restrict__ row_ctr, Real *__restrict__ row_ext,
-    unsigned int *__restrict__ counters, // [0]=unused [1]=n_items [2]=tile count [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
+    unsigned int *__restrict__ counters, // [0]=unused [1]=n_items [2]=tile count [3]=builds so far [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
     const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
     const int *__restrict__ flag, const int force) {
     if (!force && *flag == 0) {
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
         counters[0] = 0;
         counters[1] = 0;
         counters[2] = 0;
+        counters[3] += 1; // list builds since construction (diagnostic: rebuild period of an MD run)
     }
     if (tid < NB_SHARDS * NB_CLASSES) {
         counters[NB_COUNTER_CLASS0 + tid] = 0;

@@ -179,10 +179,25 @@ __device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, do
         }
     }
 }
-// f32 kernels: the products are formed in f64 from the f32 prefactor and displacement (exact widening), which is
-// cheaper on gfx950 than rounding each product to f32 first and then widening it for the 64-bit conversion.
+// f32 kernels: each product is rounded to f32 first, exactly as the reference forms it (RealType prefactor * RealType delta,
+// k_nonbonded.cuh:248-254, then FLOAT_TO_FIXED_NONBONDED<float>, k_fixed_point.cuh:65-67); the scaling by 2^36 that follows
+// is exact in either precision, so it is done after the (exact) widening.  FIX(-v) == -FIX(v) still holds.
 __device__ __forceinline__ void pair_force_fixed(float prefactor, float dx, float dy, float dz, u64 &fx, u64 &fy, u64 &fz) {
-    pair_force_fixed(static_cast<double>(prefactor), static_cast<double>(dx), static_cast<double>(dy), static_cast<double>(dz), fx, fy, fz);
+    const double a = static_cast<double>(prefactor * dx) * static_cast<double>(TM_FIXED_EXPONENT);
+    const double b = static_cast<double>(prefactor * dy) * static_cast<double>(TM_FIXED_EXPONENT);
+    const double c = static_cast<double>(prefactor * dz) * static_cast<double>(TM_FIXED_EXPONENT);
+    fx = static_cast<u64>(real_to_int64_fast(a));
+    fy = static_cast<u64>(real_to_int64_fast(b));
+    fz = static_cast<u64>(real_to_int64_fast(c));
+    const bool big = !(__builtin_fabs(a) < TM_FIXED_FAST_LIMIT && __builtin_fabs(b) < TM_FIXED_FAST_LIMIT &&
+                       __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
+    if (__ballot(big) != 0ull) {
+        if (big) {
+            fx = static_cast<u64>(llrint(a));
+            fy = static_cast<u64>(llrint(b));
+            fz = static_cast<u64>(llrint(c));
+        }
+    }
 }
 
 } // namespace tmamd

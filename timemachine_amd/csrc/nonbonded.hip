@@ -273,6 +273,12 @@ template <typename Real> unsigned int Neighborlist<Real>::num_tile_ixns() {
     return h[2];
 }
 
+template <typename Real> unsigned int Neighborlist<Real>::num_builds() {
+    unsigned int h[4];
+    HIP_CHECK(hipMemcpy(h, d_counters_.data, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return h[3];
+}
+
 template <typename Real>
 void Neighborlist<Real>::build_device(
     const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
@@ -866,5 +872,94 @@ void NonbondedPairListPrecomputed<Real>::du_dp_fixed_to_float(const int N, const
 
 template class NonbondedPairListPrecomputed<float>;
 template class NonbondedPairListPrecomputed<double>;
+
+// =============================================================================================================
+// Debug entry: the DEVICE fixed-point conversions on caller-supplied values (tests/test_gpu_fixed_point.py compares them
+// bit for bit with oracle/fixed_point.py).  Compiled in this translation unit so that they are the very functions, under
+// the very flags, that the kernels above inline.
+// =============================================================================================================
+template <typename Real, int KIND> __global__ void k_debug_float_to_fixed(const int n, const double *__restrict__ in, u64 *__restrict__ out) {
+    // no early return: the conversions contain wave-uniform branches (ballots) that every lane has to reach
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    u64 r = 0;
+    if constexpr (KIND == 3) { // the nonbonded force form FIX(prefactor * delta): in = (prefactor, delta) pairs
+        const Real p = live ? static_cast<Real>(in[2 * i]) : 0, d = live ? static_cast<Real>(in[2 * i + 1]) : 0;
+        u64 fy, fz;
+        pair_force_fixed(p, d, static_cast<Real>(0), static_cast<Real>(0), r, fy, fz);
+    } else {
+        const Real v = live ? static_cast<Real>(in[i]) : 0;
+        if constexpr (KIND == 0) {
+            r = float_to_fixed<Real>(v);
+        } else if constexpr (KIND == 1) {
+            r = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(v);
+        } else {
+            r = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(v);
+        }
+    }
+    if (live) {
+        out[i] = r;
+    }
+}
+
+template <typename Real> __global__ void k_debug_float_to_fixed_energy(const int n, const double *__restrict__ in, i128 *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const i128 r = float_to_fixed_energy<Real>(i < n ? static_cast<Real>(in[i]) : 0);
+    if (i < n) {
+        out[i] = r;
+    }
+}
+
+void debug_float_to_fixed(const int precision_bytes, const int kind, const int n, const double *h_in, u64 *h_out) {
+    if (kind < 0 || kind > 3) {
+        throw std::runtime_error("debug_float_to_fixed: kind must be 0 (2^36), 1 (2^37), 2 (2^38) or 3 (force product)");
+    }
+    const int n_in = kind == 3 ? 2 * n : n;
+    DeviceBuffer<double> d_in(std::max(n_in, 1));
+    DeviceBuffer<u64> d_out(std::max(n, 1));
+    if (n == 0) {
+        return;
+    }
+    d_in.copy_from(h_in, n_in);
+    const int tpb = 256, blocks = ceil_divide(n, tpb);
+#define TM_DBG(REAL, KIND) k_debug_float_to_fixed<REAL, KIND><<<blocks, tpb, 0, 0>>>(n, d_in.data, d_out.data)
+    if (precision_bytes == 8) {
+        switch (kind) {
+        case 0: TM_DBG(double, 0); break;
+        case 1: TM_DBG(double, 1); break;
+        case 2: TM_DBG(double, 2); break;
+        default: TM_DBG(double, 3); break;
+        }
+    } else {
+        switch (kind) {
+        case 0: TM_DBG(float, 0); break;
+        case 1: TM_DBG(float, 1); break;
+        case 2: TM_DBG(float, 2); break;
+        default: TM_DBG(float, 3); break;
+        }
+    }
+#undef TM_DBG
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(0));
+    d_out.copy_to(h_out, n);
+}
+
+void debug_float_to_fixed_energy(const int precision_bytes, const int n, const double *h_in, i128 *h_out) {
+    DeviceBuffer<double> d_in(std::max(n, 1));
+    DeviceBuffer<i128> d_out(std::max(n, 1));
+    if (n == 0) {
+        return;
+    }
+    d_in.copy_from(h_in, n);
+    const int tpb = 256, blocks = ceil_divide(n, tpb);
+    if (precision_bytes == 8) {
+        k_debug_float_to_fixed_energy<double><<<blocks, tpb, 0, 0>>>(n, d_in.data, d_out.data);
+    } else {
+        k_debug_float_to_fixed_energy<float><<<blocks, tpb, 0, 0>>>(n, d_in.data, d_out.data);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(0));
+    d_out.copy_to(h_out, n);
+}
 
 } // namespace tmamd

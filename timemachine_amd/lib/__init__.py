@@ -1,4 +1,10 @@
-"""Thin dataclasses whose ``.impl()`` constructs ``custom_ops`` objects (reference: timemachine/lib/__init__.py:12-62)."""
+"""Picklable descriptions of the integrators / movers of an MD run; ``.impl()`` builds the ``custom_ops`` object.
+
+The SCHEMA is the reference's (timemachine/lib/__init__.py:12-62) because callers construct these positionally and
+by keyword: class names, field names, field order, defaults, and ``impl()`` / ``impl(bound_potentials)``.  Which
+``custom_ops`` constructor argument each field feeds is stated once, in ``_CTOR_ARGS``, next to the wrap_kernels.cpp lines
+that define that constructor.
+"""
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -7,43 +13,50 @@ from numpy.typing import NDArray
 
 from . import custom_ops
 
+# custom_ops constructor argument order, by class (field names of the dataclass; "*" = the objects handed to impl())
+_CTOR_ARGS = {
+    "LangevinIntegrator": ("masses", "temperature", "dt", "friction", "seed"),  # wrap_kernels.cpp:699-715
+    "VelocityVerletIntegrator": ("dt", "cbs"),  # wrap_kernels.cpp:717-729
+    "MonteCarloBarostat": (  # wrap_kernels.cpp:196-294
+        "N", "pressure", "temperature", "group_idxs", "interval", "*", "seed", "adaptive_scaling_enabled", "initial_volume_scale_factor",
+    ),
+}
+
+
+class _Described:
+    """impl(): look the constructor up by the dataclass' own name and feed it the fields in _CTOR_ARGS order."""
+
+    def _ctor_value(self, name):
+        return getattr(self, name)
+
+    def impl(self, *handed_over):
+        cls_name = type(self).__name__
+        args = [handed_over[0] if name == "*" else self._ctor_value(name) for name in _CTOR_ARGS[cls_name]]
+        return getattr(custom_ops, cls_name)(*args)
+
 
 @dataclass
-class LangevinIntegrator:
-    """reference: timemachine/lib/__init__.py:12-21 (same field order, same impl() call)."""
-
+class LangevinIntegrator(_Described):
     temperature: float
     dt: float
     friction: float
     masses: NDArray[np.float64]
     seed: int
 
-    def impl(self):
-        return custom_ops.LangevinIntegrator(self.masses, self.temperature, self.dt, self.friction, self.seed)
-
 
 @dataclass
-class VelocityVerletIntegrator:
-    """reference: timemachine/lib/__init__.py:24-37 (cbs = -dt / masses, computed in __post_init__)."""
-
+class VelocityVerletIntegrator(_Described):
     dt: float
     masses: NDArray[np.float64]
 
-    cbs: NDArray[np.float64] = field(init=False)
+    cbs: NDArray[np.float64] = field(init=False)  # what the device kernel multiplies du/dx with: -dt / m
 
     def __post_init__(self):
-        cb = self.dt / np.asarray(self.masses, dtype=np.float64)
-        cb *= -1
-        self.cbs = cb
-
-    def impl(self):
-        return custom_ops.VelocityVerletIntegrator(self.dt, self.cbs)
+        self.cbs = np.negative(self.dt / np.asarray(self.masses, dtype=np.float64))
 
 
 @dataclass
-class MonteCarloBarostat:
-    """reference: timemachine/lib/__init__.py:40-62 (same fields; impl(bound_potentials) takes custom_ops.BoundPotential objects)."""
-
+class MonteCarloBarostat(_Described):
     N: int
     pressure: float
     temperature: float
@@ -53,15 +66,11 @@ class MonteCarloBarostat:
     adaptive_scaling_enabled: bool = True
     initial_volume_scale_factor: Optional[float] = None
 
+    def _ctor_value(self, name):
+        if name == "initial_volume_scale_factor":
+            # None (and 0) reach the device as 0.0, its "start at 1 % of the box volume" marker (barostat.cu:167-171)
+            return float(self.initial_volume_scale_factor) if self.initial_volume_scale_factor else 0.0
+        return getattr(self, name)
+
     def impl(self, bound_potentials):
-        return custom_ops.MonteCarloBarostat(
-            self.N,
-            self.pressure,
-            self.temperature,
-            self.group_idxs,
-            self.interval,
-            bound_potentials,
-            self.seed,
-            self.adaptive_scaling_enabled,
-            self.initial_volume_scale_factor or 0.0,  # 0.0 means "1 % of the initial box volume"
-        )
+        return super().impl(bound_potentials)

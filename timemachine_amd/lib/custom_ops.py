@@ -10,6 +10,7 @@ ctypes marshalling, fixed-point -> float conversion of the returned accumulators
 this module without the compiled library raises ImportError, and every method runs on the GPU.
 """
 import ctypes
+import inspect
 import os
 
 import numpy as np
@@ -282,11 +283,19 @@ def _new_potential(cls, create_fn, *args, keep=()):
 def _declare_precision_classes(base_name, ctor):
     """Creates <base_name>_f32 / _f64 (the reference declares each template twice, wrap_kernels.cpp:2186-2216)."""
     out = []
+    # the object is made in __new__ (a wrapped C handle); __init__ only carries the constructor's signature, so that
+    # inspect.signature(cls.__init__) reads like the reference's stubs (tests/test_api_conformance.py)
+    ctor_params = list(inspect.signature(ctor).parameters.values())[2:]  # drop (cls, prec)
+    init_signature = inspect.Signature([inspect.Parameter("self", inspect.Parameter.POSITIONAL_OR_KEYWORD)] + ctor_params)
     for suffix, prec in (("f32", _F32), ("f64", _F64)):
         def __new__(cls, *args, _prec=prec, **kwargs):
             return ctor(cls, _prec, *args, **kwargs)
 
-        klass = type(f"{base_name}_{suffix}", (Potential,), {"__new__": __new__, "__init__": lambda self, *a, **k: None})
+        def __init__(self, *a, **k):
+            pass
+
+        __init__.__signature__ = init_signature
+        klass = type(f"{base_name}_{suffix}", (Potential,), {"__new__": __new__, "__init__": __init__})
         out.append(klass)
     return out
 
@@ -454,7 +463,14 @@ def _all_pairs_get_tile_count(self):
     return n.value
 
 
+def _all_pairs_get_build_count(self):
+    n = ctypes.c_uint(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_build_count(self._h, ctypes.byref(n)))
+    return n.value
+
+
 for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
+    _k.get_build_count = _all_pairs_get_build_count  # diagnostic (not in the reference surface)
     _k.set_atom_idxs = _all_pairs_set_atom_idxs
     _k.get_atom_idxs = _all_pairs_get_atom_idxs
     _k.get_num_atom_idxs = _all_pairs_get_num_atom_idxs
@@ -480,7 +496,7 @@ class SummedPotential(Potential):
             _c_int(1 if parallel else 0), keep=potentials)
         return obj
 
-    def __init__(self, *a, **k):
+    def __init__(self, potentials, params_sizes, parallel=True):
         pass
 
     def get_potentials(self):
@@ -496,7 +512,7 @@ class FanoutSummedPotential(Potential):
             cls, _lib.tm_fanout_summed_potential_create, _handles(potentials), _c_int(len(potentials)), _c_int(1 if parallel else 0),
             keep=potentials)
 
-    def __init__(self, *a, **k):
+    def __init__(self, potentials, parallel=True):
         pass
 
     def get_potentials(self):
@@ -879,6 +895,24 @@ def hilbert_lut():
     return out
 
 
+def debug_float_to_fixed(values, precision, kind=0):
+    """The device's fixed-point conversion of `values` (see include/timemachine_amd.h: tm_debug_float_to_fixed).
+    kind 3 takes an [n, 2] array of (prefactor, delta) pairs.  -> uint64[n]"""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    n = v.shape[0] if kind == 3 else v.size
+    out = np.zeros(n, dtype=np.uint64)
+    _check(_lib.tm_debug_float_to_fixed(_c_int(_F64 if np.dtype(precision) == np.float64 else _F32), _c_int(int(kind)), _ptr(v), _c_int(n), _ptr(out)))
+    return out
+
+
+def debug_float_to_fixed_energy(values, precision):
+    """FLOAT_TO_FIXED_ENERGY on the device -> list of python ints (signed 128-bit values)."""
+    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+    out = np.zeros(v.size, dtype=[("lo", np.uint64), ("hi", np.int64)])
+    _check(_lib.tm_debug_float_to_fixed_energy(_c_int(_F64 if np.dtype(precision) == np.float64 else _F32), _ptr(v), _c_int(v.size), _ptr(out)))
+    return [(int(r["hi"]) << 64) | int(r["lo"]) for r in out]
+
+
 def profile_set_enabled(enabled):
     _check(_lib.tm_profile_set_enabled(_c_int(1 if enabled else 0)))
 
@@ -904,7 +938,25 @@ def _not_on_hot_path(name):
 
 
 for _name in (
-    "BDExchangeMove_f32",
-    "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
+    # exchange movers and their device helpers (cpp/src/bd_exchange_move.cu, tibd_exchange_move.cu, segmented_*.cu)
+    "BDExchangeMove_f32", "BDExchangeMove_f64", "TIBDExchangeMove_f32", "TIBDExchangeMove_f64",
+    "NonbondedMolEnergyPotential_f32", "NonbondedMolEnergyPotential_f64", "SegmentedSumExp_f32", "SegmentedSumExp_f64",
+    "SegmentedWeightedRandomSampler_f32", "SegmentedWeightedRandomSampler_f64",
+    # module-level helpers of the exchange movers / local MD (wrap_kernels.cpp:2228-2309)
+    "atom_by_atom_energies_f32", "atom_by_atom_energies_f64", "inner_and_outer_mols_f32", "inner_and_outer_mols_f64", "rmsd_align",
+    "rotate_and_translate_mol_f32", "rotate_and_translate_mol_f64", "rotate_coords_f32", "rotate_coords_f64",
+    "translations_inside_and_outside_sphere_host_f32", "translations_inside_and_outside_sphere_host_f64",
 ):
     globals()[_name] = _not_on_hot_path(_name)
+
+
+def _local_md_not_built(name):
+    def method(self, *a, **k):
+        raise NotImplementedError(f"Context.{name}: local MD is outside the MI355X hot path of timemachine_amd (see DESIGN.md, 'out of scope')")
+
+    method.__name__ = name
+    return method
+
+
+for _name in ("multiple_steps_local", "multiple_steps_local_selection", "setup_local_md"):
+    setattr(Context, _name, _local_md_not_built(_name))

@@ -27,25 +27,21 @@ class PeriodicTorsion(Potential):
 
 
 def filter_exclusions(atom_idxs, exclusion_idxs, scale_factors, update_idxs: bool = False):
-    """Exclusions (and scales) whose two atoms are both in ``atom_idxs``.
-    reference: timemachine/potentials/nonbonded.py:176-218."""
-    atom_idxs_set = set(int(a) for a in atom_idxs)
-    map_to_filtered = {int(j): i for i, j in enumerate(atom_idxs)}
-    kept_idxs, kept_scales = [], []
-    for (i, j), sf in zip(np.asarray(exclusion_idxs), np.asarray(scale_factors)):
-        i, j = int(i), int(j)
-        if i not in atom_idxs_set or j not in atom_idxs_set:
-            continue
-        if update_idxs:
-            i, j = map_to_filtered[i], map_to_filtered[j]
-        kept_idxs.append((i, j))
-        kept_scales.append(sf)
-    filtered_exclusion_idxs = np.array(kept_idxs, dtype=np.int32)
-    filtered_scale_factors = np.array(kept_scales)
-    if not filtered_scale_factors.shape[0]:
-        filtered_scale_factors = filtered_scale_factors.reshape((0, np.asarray(scale_factors).shape[1]))
-        filtered_exclusion_idxs = filtered_exclusion_idxs.reshape((0, 2))
-    return filtered_exclusion_idxs, filtered_scale_factors
+    """The exclusions whose two atoms both belong to ``atom_idxs`` (with their scale factors); ``update_idxs`` renumbers
+    the pairs to positions within ``atom_idxs``.  Same contract as timemachine/potentials/nonbonded.py:176-218."""
+    atom_idxs = np.asarray(atom_idxs, dtype=np.int64).reshape(-1)
+    pairs = np.asarray(exclusion_idxs, dtype=np.int64).reshape(-1, 2)
+    scales = np.asarray(scale_factors)
+    inside = np.isin(pairs, atom_idxs).all(axis=1) if len(atom_idxs) else np.zeros(len(pairs), dtype=bool)
+    kept = pairs[inside]
+    if update_idxs and len(kept):
+        # position of each kept atom within atom_idxs (atom_idxs is unique, not necessarily sorted)
+        order = np.argsort(atom_idxs, kind="stable")
+        kept = order[np.searchsorted(atom_idxs[order], kept)]
+    kept = kept.astype(np.int32)
+    if not len(kept):
+        kept = kept.reshape(-1)  # the reference returns a flat empty index array here (nonbonded.py:213); kept for drop-in equality
+    return kept, scales[inside].reshape(-1, scales.shape[1])
 
 
 @dataclass

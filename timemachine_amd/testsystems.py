@@ -192,6 +192,35 @@ def small_solvated_ligand(lamb: float = 0.0, seed: int = 2025) -> System:
     return add_chain_ligand(build_water_box(772, 2.85, seed=seed), 20, lamb=lamb)
 
 
+def config1_water_cluster(box_length: float, seed: int = 2025) -> System:
+    """BASELINE config 1: 85 flexible waters (255 atoms) at liquid density + 1 neutral LJ atom = 256 atoms, as a
+    1.37 nm cluster in the middle of a `box_length` box: 100.0 = the reference's "vacuum" box (tests/test_bonded.py:26),
+    3.0 = the smallest periodic box its tests use (tests/test_md.py:44).  SURVEY.md section 8(d)."""
+    side = (85 / WATER_NUMBER_DENSITY) ** (1 / 3)
+    w = build_water_box(85, side, seed=seed)
+    shift = 0.5 * (box_length - side)
+    lj = np.array([[side + 0.25, 0.5 * side, 0.5 * side]])  # just outside one face of the cluster
+    coords = np.concatenate([w.coords, lj]) + shift
+    nb = np.concatenate([w.nb_params, [[0.0, 0.34 / 2, np.sqrt(0.5), 0.0]]])
+    return System(
+        coords=coords, box=np.eye(3) * box_length, masses=np.concatenate([w.masses, [39.948]]), nb_params=nb,
+        exclusion_idxs=w.exclusion_idxs, scale_factors=w.scale_factors, bond_idxs=w.bond_idxs, bond_params=w.bond_params,
+        angle_idxs=w.angle_idxs, angle_params=w.angle_params, torsion_idxs=w.torsion_idxs, torsion_params=w.torsion_params,
+        beta=w.beta, cutoff=w.cutoff, num_water_atoms=w.num_atoms,
+    )
+
+
+def config4_solvated_ligand(lamb: float = 0.0, seed: int = 2025) -> System:
+    """BASELINE config 4 shape: a 30-atom ligand in a 4.0 nm water box (~6.4k atoms; tests/test_benchmark.py:541),
+    w_ligand = lamb * cutoff.  Windows differ only in the ligand's nonbonded parameters."""
+    return add_chain_ligand(build_water_box(2138, 4.0, seed=seed), 30, lamb=lamb)
+
+
+def config5_complex_sized(lamb: float = 0.0, seed: int = 2025) -> System:
+    """BASELINE config 5 size: a 40-atom ligand in a 6.8 nm water box (~31k atoms, "30-60k-atom synthetic complex")."""
+    return add_chain_ligand(build_water_box(10500, 6.8, seed=seed), 40, lamb=lamb)
+
+
 def bound_potentials(sys: System, precision=np.float32, nblist_padding: float = 0.1):
     """[HarmonicBond, HarmonicAngle, (PeriodicTorsion), Nonbonded] bound to their parameters -- the shape of a
     reference state (fe/free_energy.py:614-657 packs the same list into one SummedPotential)."""
