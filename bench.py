@@ -1,15 +1,31 @@
 #!/usr/bin/env python
 """Headline benchmark: ns/day of Langevin MD on a DHFR-sized (23 559-atom) explicit-water box at dt = 2.5 fs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f64|f32] [--cutoff 1.2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision f64|f32] [--cutoff 1.2] [--mode md|hrex]
 
 Protocol = the reference's own (tests/test_benchmark.py:243-282): build the system, equilibrate untimed, then time
 ctxt.multiple_steps(K) and report ns/day = K / t * 86400 * dt[ps] * 1e-3.  A "step" is one pass of the hot path: force
 evaluation (NonbondedAllPairs + NonbondedExclusions + HarmonicBond + HarmonicAngle) + the BAOAB Langevin update, all
-resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs an independent replica
-of the same workload (free-energy windows never interact during MD), `value` is the aggregate over ranks, scaling is
-weak, and the only collective is the end-of-run gather of reduced potentials (RCCL over xGMI), outside the timed region
--- exactly where BASELINE's north star puts it.
+resident in HBM.
+
+Timing.  The timed Context is settled with SETTLE_STEPS untimed steps (part of the equilibration: first list builds,
+allocator and clock ramp), then W warm-up steps, then EXACTLY K steps between barrier + device synchronisation on both
+sides.  `value` comes from HIP events recorded on the Context's stream right before the first and right after the last
+of those K steps (tm_context_last_multiple_steps_ms), maximum over ranks; the host wall clock around the same call is
+reported next to it (`host_ms_per_step`: it additionally contains the final frame's device-to-host copy and the Python
+call overhead, 0.3 ms in total -- visible at K = 20, invisible at K = 2000).
+
+N > 1.  `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one per GPU, RCCL); under an
+existing launcher (RANK / WORLD_SIZE set) it joins that job and insists that WORLD_SIZE == --gpus.
+  --mode md    every rank runs an independent replica of the same workload (free-energy windows never interact during
+               MD); `value` is the aggregate over ranks, scaling is weak, and the only collective is the end-of-run
+               gather of reduced potentials (RCCL over xGMI), outside the timed region -- where BASELINE's north star
+               puts it.  Its latency is reported.
+  --mode hrex  BASELINE config 5's shape: 24 lambda windows of a ~31k-atom state dealt round-robin to the ranks
+               (parallel.windows_for_rank), 400 MD steps per frame, then one exchange step: the (replica, state) energy
+               matrix rows of the resident replicas (execute_batch_sparse, max_delta_states = 4), ONE all_gather, the
+               identical seeded swap chain on every rank, parameters re-bound (fe/free_energy.py:1148-1200,1537-1551).
+               Reports aggregate ns/day, frames/s and the measured exchange latency.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline       algorithmic HBM bytes of the dominant kernel (k_nonbonded_tiles) per launch / its measured duration
@@ -17,11 +33,14 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  HBM-bound, so see roofline_valu for the roofline that actually binds it
   roofline_valu  algorithmic f64 flops per launch / duration against the 78.6 TFLOP/s FP64 vector peak
   cpu_baseline   the oracle's torch-f64 restatement of the reference's JAX path timed on the host cores on a bounded
-                 sample of the same workload (rank 0, N == 1 only)
+                 sample of the same workload, 3 repetitions (rank 0, N == 1 only); cpu_baseline_configs: BASELINE
+                 configs 1 (500 BAOAB steps in each box) and 2 (u + du_dx + du_dp, 10 repetitions) the same way
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,44 +52,114 @@ sys.path.insert(0, REPO)
 DT = 2.5e-3  # ps
 TEMPERATURE = 300.0
 FRICTION = 1.0
+SETTLE_STEPS = 500  # untimed, on the timed Context, whatever --warmup says
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # = 1/2 of the 157.3 TFLOP/s FP32 vector peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TFLOPS = 157.3
 C_PAIR_FLOPS = 280.0  # per interacting pair (rsqrt, erfc, exp, sincos, LJ, fixed-point conversions)
 C_SLOT_FLOPS = 20.0  # per evaluated slot (min-image distance + cutoff test)
+METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--mode", choices=["md", "hrex"], default="md")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cutoff", type=float, default=1.2)
+    ap.add_argument("--padding", type=float, default=0.1, help="nblist_padding of the nonbonded potential (results do not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=400)
-    ap.add_argument("--windows", type=int, default=8, help="lambda windows of the end-of-run u_kl gather")
+    ap.add_argument("--windows", type=int, default=None, help="lambda windows (md: rows of the end-of-run u_kl gather, default 8; hrex: states, default 24)")
+    ap.add_argument("--steps-per-frame", type=int, default=400, help="hrex: MD steps between exchanges (fe/free_energy.py default)")
+    ap.add_argument("--max-delta-states", type=int, default=4, help="hrex: fe/free_energy.py:99")
     ap.add_argument("--equil-scale", type=float, default=1.0, help="scale the untimed equilibration (profiling runs)")
     ap.add_argument("--equil-precision", choices=["f64", "f32"], default="f32")
-    ap.add_argument("--parallel-children", action="store_true", help="SummedPotential(parallel=True) (accepted for interface parity; children always run in sequence)")
-    ap.add_argument("--separate-potentials", action="store_true", help="pass the potentials to Context one by one (serial) instead of one SummedPotential")
-    return ap.parse_args()
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto")
+    ap.add_argument("--stub", action="store_true", help="no GPU work: a stand-in Context that sleeps (CPU tests of the launch / collective / report plumbing)")
+    return ap.parse_args(argv)
 
 
-def init_distributed(n_gpus):
+# ---------------------------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------------------------
+def maybe_self_launch(args):
+    """--gpus N with no launcher around us: become N ranks (the reference's "one process per device",
+    timemachine/parallel/client.py:188-218).  Returns only in the ranks."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_distributed(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    backend = None
     if world > 1:
+        import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    return rank, local_rank, world
+        backend = args.backend
+        if backend == "auto":
+            backend = "nccl" if (torch.cuda.is_available() and not args.stub) else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+        assert dist.get_world_size() == args.gpus
+    return rank, local_rank, world, backend
 
 
+def device_sync(co):
+    if co is not None:
+        co.device_synchronize()
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except ImportError:
+        pass
+
+
+class StubContext:
+    """Stand-in for custom_ops.Context (--stub): sleeps 20 us per step.  Exercises everything around the hot path."""
+
+    def __init__(self, n_atoms):
+        self.n_atoms = n_atoms
+        self._ms = 0.0
+
+    def multiple_steps(self, n, interval=0):
+        t0 = time.perf_counter()
+        time.sleep(20e-6 * n)
+        self._ms = 1e3 * (time.perf_counter() - t0)
+        return np.zeros((1, self.n_atoms, 3)), np.zeros((1, 3, 3))
+
+    def last_multiple_steps_ms(self):
+        return self._ms
+
+    def get_x_t(self):
+        return np.zeros((self.n_atoms, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workload pieces
+# ---------------------------------------------------------------------------------------------------------------------
 def equilibrate(co, LangevinIntegrator, system, make_bps, seed, scale=1.0, prec=np.float32):
     """Lattice start -> liquid: short, strongly thermostatted stages with growing time step (untimed)."""
     x, v, box = system.coords.copy(), np.zeros_like(system.coords), system.box
@@ -93,48 +182,6 @@ def count_pairs_within(x, box, cutoff):
     xi = np.clip(xi, 0.0, np.nextafter(L, 0.0))
     tree = cKDTree(xi, boxsize=L)
     return int(tree.count_neighbors(tree, cutoff) - len(x)) // 2
-
-
-def cpu_baseline(system, x, cutoff):
-    """oracle (torch f64, row-blocked dense evaluation == the reference's JAX formulation) on the host cores,
-    bounded sample: the first `rows` rows of the i<j pair matrix, scaled by the pair count."""
-    import torch
-
-    from oracle import ref_potentials as rp
-
-    cores = min(os.cpu_count() or 1, 64)  # torch's elementwise kernels stop scaling long before 256 threads
-    torch.set_num_threads(cores)
-    N = system.num_atoms
-    rows = 3072  # ~13 s of CPU work on 64 threads (the contract asks for a 10-30 s sample)
-    xt = torch.tensor(x, requires_grad=True)
-    pt = torch.tensor(system.nb_params)
-    bt = torch.tensor(system.box)
-    t0 = time.time()
-    # evaluate only row blocks [0, rows): pairs (i, j > i) for i < rows
-    total = 0.0
-    for r0 in range(0, rows, 512):
-        r1 = min(r0 + 512, rows)
-        d3 = rp.delta_r(xt[r0:r1][:, None, :], xt[r0:][None, :, :], torch.diagonal(bt))
-        d2 = (d3 * d3).sum(-1)
-        upper = torch.arange(r0, r1)[:, None] < torch.arange(r0, N)[None, :]
-        d2 = torch.where(upper, d2, torch.full_like(d2, 1e6))
-        lj, es = rp._pair_energies(torch.sqrt(d2), pt[r0:r1, 0][:, None] * pt[None, r0:, 0], pt[r0:r1, 1][:, None] + pt[None, r0:, 1], pt[r0:r1, 2][:, None] * pt[None, r0:, 2], system.beta, cutoff)
-        e = lj.sum() + es.sum()
-        e.backward()
-        total += float(e.detach())
-    elapsed = time.time() - t0
-    pairs_sample = sum(N - 1 - i for i in range(rows))
-    pairs_full = N * (N - 1) // 2
-    t_step = elapsed * pairs_full / pairs_sample
-    return {
-        "value": 86400.0 * DT * 1e-3 / t_step,
-        "unit": "ns/day",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"du/dx of NonbondedAllPairs for rows 0..{rows - 1} of the i<j pair matrix ({pairs_sample / pairs_full:.1%} of all pairs, {elapsed:.1f} s), "
-        f"scaled to the full matrix; torch f64 on {cores} threads; oracle restatement of the reference's dense JAX path, not JAX itself",
-        "seconds_per_force_eval_extrapolated": t_step,
-    }
 
 
 def _walk(pot):
@@ -161,112 +208,252 @@ def find_nonbonded(bps):
     raise RuntimeError("no Nonbonded in the state")
 
 
-# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/r01_v9_pmc_f64.txt
-PMC_TRAFFIC_BYTES = {"f64": (11652 + 44802) * 1024, "f32": (7215 + 33845) * 1024}
-
-
-def main():
-    args = parse_args()
-    rank, local_rank, world = init_distributed(args.gpus)
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle timed on the host cores; kind "port": a restatement of the reference's JAX path, not JAX)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_threads(limit=64):
     import torch
 
-    from timemachine_amd import parallel
-    from timemachine_amd import potentials as P
-    from timemachine_amd import testsystems as ts
-    from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+    cores = min(os.cpu_count() or 1, limit)  # torch's elementwise kernels stop scaling long before 256 threads
+    torch.set_num_threads(cores)
+    return cores
 
-    if co.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
-    co.set_device(local_rank)
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
 
-    precision = np.float64 if args.precision == "f64" else np.float32
-    system = ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=args.cutoff)
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(system, x, cutoff, reps=3, rows_per_rep=1024):
+    """config 3: du/dx of NonbondedAllPairs on `reps` disjoint row slabs of the i<j pair matrix (row-blocked dense
+    evaluation == the reference's JAX formulation), each scaled to the full matrix by its pair count."""
+    import torch
+
+    from oracle import ref_potentials as rp
+
+    cores = _cpu_threads()
     N = system.num_atoms
+    pt = torch.tensor(system.nb_params)
+    bt = torch.tensor(system.box)
+    pairs_full = N * (N - 1) // 2
+    estimates, seconds, slabs = [], [], []
+    for rep in range(reps):
+        start = (rep * (N // max(reps, 1))) // 512 * 512
+        rows = range(start, min(start + rows_per_rep, N - 1))
+        xt = torch.tensor(x, requires_grad=True)
+        t0 = time.time()
+        for r0 in range(rows.start, rows.stop, 512):
+            r1 = min(r0 + 512, rows.stop)
+            d3 = rp.delta_r(xt[r0:r1][:, None, :], xt[r0:][None, :, :], torch.diagonal(bt))
+            d2 = (d3 * d3).sum(-1)
+            upper = torch.arange(r0, r1)[:, None] < torch.arange(r0, N)[None, :]
+            d2 = torch.where(upper, d2, torch.full_like(d2, 1e6))
+            lj, es = rp._pair_energies(torch.sqrt(d2), pt[r0:r1, 0][:, None] * pt[None, r0:, 0], pt[r0:r1, 1][:, None] + pt[None, r0:, 1], pt[r0:r1, 2][:, None] * pt[None, r0:, 2], system.beta, cutoff)
+            (lj.sum() + es.sum()).backward()
+        el = time.time() - t0
+        pairs_sample = sum(N - 1 - i for i in rows)
+        estimates.append(el * pairs_full / pairs_sample)
+        seconds.append(el)
+        slabs.append(f"{rows.start}..{rows.stop - 1}")
+    t_step = float(np.mean(estimates))
+    return {
+        "value": 86400.0 * DT * 1e-3 / t_step,
+        "unit": "ns/day",
+        "cores": cores,
+        "cpu": _cpu_model(),
+        "kind": "port",
+        "sample": f"config 3: du/dx of NonbondedAllPairs on {reps} row slabs of the i<j pair matrix (rows {', '.join(slabs)}; {sum(seconds):.1f} s of CPU work), "
+        f"each scaled to the full matrix by pair count; torch f64 on {cores} threads; oracle restatement of the reference's dense JAX path, not JAX itself",
+        "seconds_per_force_eval_extrapolated": t_step,
+        "repetitions": reps,
+        "spread_rel": float((max(estimates) - min(estimates)) / t_step),
+    }
 
-    def make_bps(prec):
-        # one SummedPotential for the whole state -- how the reference packs a state
-        # (fe/free_energy.py:614-657: make_summed_potential(...).to_gpu(np.float32) -> one BoundPotential)
-        bps = ts.bound_potentials(system, prec)
-        if args.separate_potentials:
-            return [bp.to_gpu(prec).bound_impl for bp in bps]
-        summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps], parallel=args.parallel_children)
-        return [summed.bind_params_list([bp.params for bp in bps]).to_gpu(prec).bound_impl]
 
-    seed = 1234 + rank
-    x, v = equilibrate(co, LangevinIntegrator, system, make_bps, seed, args.equil_scale, np.float64 if args.equil_precision == "f64" else np.float32)
+def cpu_baseline_configs():
+    """BASELINE configs 1 and 2 on the host cores."""
+    from oracle import integrator as oi
+    from oracle import ref_potentials as rp
+    from timemachine_amd import testsystems as ts
+
+    out = {"cpu": _cpu_model(), "kind": "port"}
+    # config 1: 256-atom water cluster, full MD loop (dense forces + python BAOAB), both boxes.  256 x 256 tensors: one
+    # thread is the fastest setting by an order of magnitude (64 threads spend their time waking each other up)
+    cores1 = _cpu_threads(1)
+    for tag, L, n_steps in (("vacuum_100nm", 100.0, 500), ("pbc_3nm", 3.0, 500)):
+        s = ts.config1_water_cluster(L)
+        N = s.num_atoms
+        rng = np.random.default_rng(1)
+        ca, cb, cc = oi.langevin_coefficients(TEMPERATURE, 1.0e-3, FRICTION, s.masses)
+        x, v = s.coords.copy(), np.zeros((N, 3))
+        t0 = time.time()
+        for _ in range(n_steps):
+            f = -rp.nonbonded(x, s.nb_params, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff)[1]
+            f -= rp.harmonic_bond(x, s.bond_params, s.box, s.bond_idxs)[1]
+            f -= rp.harmonic_angle(x, s.angle_params, s.box, s.angle_idxs)[1]
+            x, v = oi.baoab_step(x, v, f, rng.normal(size=(N, 3)), ca, cb, cc, 1.0e-3)
+        el = time.time() - t0
+        assert np.all(np.isfinite(x))
+        out[f"config1_{tag}"] = {"cores": cores1, "steps": n_steps, "seconds": el, "ms_per_step": 1e3 * el / n_steps, "ns_day_at_1fs": n_steps / el * 86400 * 1.0e-3 * 1e-3,
+                                 "what": "256 atoms, oracle forces (nonbonded + bond + angle, u and du_dx by autograd) + f64 BAOAB, dt 1 fs"}
+    # config 2: ~2.2k-atom solvated ligand, u + du_dx + du_dp of every term
+    cores2 = _cpu_threads()
+    s = ts.small_solvated_ligand(lamb=0.3)
+    x = s.coords
+    times = []
+    for _ in range(10):
+        t0 = time.time()
+        rp.nonbonded(x, s.nb_params, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff)
+        rp.harmonic_bond(x, s.bond_params, s.box, s.bond_idxs)
+        rp.harmonic_angle(x, s.angle_params, s.box, s.angle_idxs)
+        rp.periodic_torsion(x, s.torsion_params, s.box, s.torsion_idxs)
+        times.append(time.time() - t0)
+    out["config2"] = {"cores": cores2, "repetitions": 10, "seconds_mean": float(np.mean(times)), "seconds_min": float(np.min(times)), "seconds_max": float(np.max(times)),
+                      "atoms": s.num_atoms, "what": "u + du_dx + du_dp of Nonbonded, HarmonicBond, HarmonicAngle, PeriodicTorsion (oracle, torch f64 autograd)"}
+    return out
+
+
+# k_nonbonded_tiles<Real, false, true, false>, per dispatch: (FETCH_SIZE + WRITE_SIZE) KB * 1024 -- profiles/*_pmc_*.txt
+PMC_TRAFFIC = {
+    "f64": {"bytes": (11652 + 44802) * 1024, "source": "profiles/r01_v9_pmc_f64.txt"},
+    "f32": {"bytes": (7215 + 33845) * 1024, "source": "profiles/r01_v9_pmc_f64.txt"},
+}
+
+
+def load_pmc_traffic():
+    """newest committed PMC summary wins (profiles/pmc_traffic.json is written by scripts/gpu_pmc.sh's post-processing)"""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            return json.load(fh)
+    return PMC_TRAFFIC
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --mode md
+# ---------------------------------------------------------------------------------------------------------------------
+def run_md(args, rank, local_rank, world, backend):
+    from timemachine_amd import parallel
+
+    co = None
+    if not args.stub:
+        from timemachine_amd import potentials as P
+        from timemachine_amd import testsystems as ts
+        from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+        if co.device_count() < 1:
+            raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
+        co.set_device(local_rank)
+        precision = np.float64 if args.precision == "f64" else np.float32
+        system = ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=args.cutoff)
+        N = system.num_atoms
+
+        def make_bps(prec):
+            # one SummedPotential for the whole state -- how the reference packs a state
+            # (fe/free_energy.py:614-657: make_summed_potential(...).to_gpu(np.float32) -> one BoundPotential)
+            bps = ts.bound_potentials(system, prec, nblist_padding=args.padding)
+            summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps])
+            return [summed.bind_params_list([bp.params for bp in bps]).to_gpu(prec).bound_impl]
+
+        seed = 1234 + rank
+        x, v = equilibrate(co, LangevinIntegrator, system, make_bps, seed, args.equil_scale, np.float64 if args.equil_precision == "f64" else np.float32)
+    else:
+        N, system = 23559, None
 
     def run(prec, steps, warmup, profile_steps):
-        bps = make_bps(prec)
-        ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps)
-        ctxt.multiple_steps(max(warmup, 1), 0)
+        if args.stub:
+            bps, ctxt = None, StubContext(N)
+        else:
+            bps = make_bps(prec)
+            ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps)
+        device_sync(co)  # the first call initialises torch's HIP context (seconds): do it here, not in front of the clock
+        ctxt.multiple_steps(SETTLE_STEPS, 0)  # untimed, whatever --warmup says (see the module docstring)
+        if warmup > 0:
+            ctxt.multiple_steps(warmup, 0)
         parallel.barrier()
-        co.device_synchronize()
-        torch.cuda.synchronize()
+        device_sync(co)
         t0 = time.perf_counter()
         ctxt.multiple_steps(steps, 0)
-        co.device_synchronize()
-        torch.cuda.synchronize()
+        dev_s = 1e-3 * ctxt.last_multiple_steps_ms()
+        device_sync(co)
         parallel.barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed = parallel.max_over_ranks(elapsed)
+        host_s = time.perf_counter() - t0
+        dev_s, host_s = parallel.max_over_ranks(dev_s), parallel.max_over_ranks(host_s)
         xf = ctxt.get_x_t()
         assert np.all(np.isfinite(xf)), "trajectory diverged"
         prof = None
-        if profile_steps > 0:
+        if profile_steps > 0 and not args.stub:
+            nb = find_all_pairs(bps)
+            builds0 = nb.get_build_count()
             co.profile_reset()
             co.profile_set_enabled(True)
             ctxt.multiple_steps(profile_steps, 0)
             total_ms, launches = co.profile_read("nonbonded_tiles")
             co.profile_set_enabled(False)
             co.profile_reset()
-            nb = find_all_pairs(bps)
-            prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": nb.get_tile_ixn_count()}
-        return elapsed, xf, ctxt, bps, prof
+            prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": nb.get_tile_ixn_count(),
+                    "run_ms": ctxt.last_multiple_steps_ms(), "steps": profile_steps, "builds": nb.get_build_count() - builds0}
+        return dev_s, host_s, xf, bps, prof
 
-    elapsed, xf, ctxt, bps, prof = run(precision, args.steps, args.warmup, args.profile_steps if rank == 0 else 0)
-    steps_per_s = args.steps / elapsed
-    ns_day = steps_per_s * 86400.0 * DT * 1e-3 * world
+    dev_s, host_s, xf, bps, prof = run(None if args.stub else precision, args.steps, args.warmup, args.profile_steps if rank == 0 else 0)
+    ns_day = args.steps / dev_s * 86400.0 * DT * 1e-3 * world
 
     # ---- end-of-run reduced-potential gather (outside the timed region): each rank evaluates its final frame under
     # every window's parameters (charges scaled by lambda_l) and the rows are all-gathered over RCCL
-    n_windows = max(args.windows, world)
+    n_windows = max(args.windows or 8, world)
     my_windows = parallel.windows_for_rank(world, world, rank)  # one replica per rank
-    lambdas = np.linspace(0.0, 1.0, n_windows)
-    params_l = np.stack([system.nb_params * np.array([1.0 - 0.1 * lam, 1.0, 1.0, 1.0]) for lam in lambdas])
-    nb_pot = find_nonbonded(bps)
-    _, _, u_row = nb_pot.execute_batch(xf[None], params_l, system.box[None], False, False, True)
-    kT = 0.008314462618 * TEMPERATURE
-    u_kl = parallel.gather_rows(my_windows, u_row.reshape(1, -1) / kT, world)
-    gather_ok = bool(np.all(np.isfinite(u_kl)))
+    if args.stub:
+        u_row = np.full((1, n_windows), float(rank))
+    else:
+        lambdas = np.linspace(0.0, 1.0, n_windows)
+        params_l = np.stack([system.nb_params * np.array([1.0 - 0.1 * lam, 1.0, 1.0, 1.0]) for lam in lambdas])
+        _, _, u_row = find_nonbonded(bps).execute_batch(xf[None], params_l, system.box[None], False, False, True)
+        u_row = u_row.reshape(1, -1) / (0.008314462618 * TEMPERATURE)
+    parallel.barrier()
+    t0 = time.perf_counter()
+    u_kl = parallel.gather_rows(my_windows, u_row, world, row_length=n_windows)
+    gather_ms = 1e3 * parallel.max_over_ranks(time.perf_counter() - t0)
+    gather_ok = bool(np.all(np.isfinite(u_kl))) and u_kl.shape == (world, n_windows)
 
     if rank != 0:
         return
 
     out = {
-        "metric": "ns/day (23k-atom solvated box, 2.5 fs) per GPU",
+        "metric": METRIC,
         "value": ns_day,
         "unit": "ns/day",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": 1e3 * dev_s / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
         "config": {
-            "workload": "configs[2]: DHFR-sized explicit-water box, 7853 flexible TIP3P-like waters = 23559 atoms, box 6.223 nm, "
+            "workload": "configs[2] (zero-based; BASELINE's third): DHFR-sized explicit-water box, 7853 flexible TIP3P-like waters = 23559 atoms, box 6.223 nm, "
             f"direct-space erfc*switch electrostatics + LJ, cutoff {args.cutoff} nm, beta 2.0, HMR, dt 2.5 fs, Langevin 300 K friction 1/ps; "
             "one independent replica per GPU",
             "atoms": N,
             "potentials": f"HarmonicBond/HarmonicAngle/Nonbonded(AllPairs+Exclusions) *_{args.precision}, LangevinIntegrator<float>",
             "replicas": world,
+            "nblist_padding": args.padding,
         },
-        "device": co.device_name(),
+        "timing": f"HIP events on the Context stream around the {args.steps} timed steps (max over ranks), after {SETTLE_STEPS} settle + {args.warmup} warm-up steps",
+        "host_ms_per_step": 1e3 * host_s / args.steps,
+        "host_ns_day": args.steps / host_s * 86400.0 * DT * 1e-3 * world,
+        "world_size": world,
+        "backend": backend,
+        "device": "stub" if args.stub else co.device_name(),
         "mbar_gather_ok": gather_ok,
+        "mbar_gather_ms": gather_ms,
     }
 
     if prof is not None:
@@ -279,6 +466,9 @@ def main():
         bytes_alg = (rec + 48) * N + 132 * tiles
         flops_alg = C_PAIR_FLOPS * p_int + C_SLOT_FLOPS * 1024 * tiles
         peak_fl = FP64_VALU_PEAK_TFLOPS if args.precision == "f64" else FP32_VALU_PEAK_TFLOPS
+        pmc = load_pmc_traffic().get(args.precision, {})
+        out["profiled"] = {"steps": prof["steps"], "ns_day": prof["steps"] / (1e-3 * prof["run_ms"]) * 86400.0 * DT * 1e-3,
+                           "steps_per_list_build": prof["steps"] / max(prof["builds"], 1), "note": "the same Context, per-launch HIP events on"}
         out["roofline"] = {
             "bound": "hbm",
             "kernel": "k_nonbonded_tiles",
@@ -287,10 +477,10 @@ def main():
             "unit": "GB/s",
             "frac": bytes_alg / t_s / 1e9 / HBM_PEAK_GBS,
             # FETCH_SIZE + WRITE_SIZE per dispatch of this kernel from the committed PMC passes (separate rocprofv3 --pmc runs
-            # of this very command, scripts/gpu_pmc.sh -> profiles/r01_v9_pmc_f64.txt); counters uncalibrated for this
-            # access pattern (MI355X_MICROARCH.md, HBM section).  ~20x the algorithmic bytes: the flush's u64 atomics.
-            "traffic": PMC_TRAFFIC_BYTES.get(args.precision),
-            "traffic_source": "profiles/r01_v9_pmc_f64.txt (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
+            # of this very command, scripts/gpu_pmc.sh); counters uncalibrated for this access pattern
+            # (MI355X_MICROARCH.md, HBM section)
+            "traffic": pmc.get("bytes"),
+            "traffic_source": f"{pmc.get('source')} (FETCH_SIZE + WRITE_SIZE, KB per dispatch; measured in separate --pmc passes, not in this run)",
             "bytes_per_launch": bytes_alg,
             "kernel_ms": prof["kernel_ms"],
             "launches_timed": prof["launches"],
@@ -307,21 +497,163 @@ def main():
             "pairs_within_cutoff": p_int,
             "tiles_32x32": tiles,
             "tile_occupancy": p_int / (1024.0 * tiles) if tiles else None,
-            "kernel_share_of_step": prof["kernel_ms"] / (1e3 * elapsed / args.steps),
+            "kernel_share_of_step": prof["kernel_ms"] / (1e3 * dev_s / args.steps),
         }
 
-    if world == 1:
+    if world == 1 and not args.stub:
         # the other precision, for the record (the reference ships f32 kernels; BASELINE asks for f64 forces)
         other = np.float32 if precision == np.float64 else np.float64
         try:
-            e2, _, _, _, _ = run(other, max(args.steps // 2, 1), max(args.warmup // 2, 1), 0)
-            out["ns_day_" + ("f32" if other == np.float32 else "f64")] = (max(args.steps // 2, 1) / e2) * 86400.0 * DT * 1e-3
+            d2, _, _, _, _ = run(other, max(args.steps // 2, 1), max(args.warmup // 2, 1), 0)
+            out["ns_day_" + ("f32" if other == np.float32 else "f64")] = (max(args.steps // 2, 1) / d2) * 86400.0 * DT * 1e-3
         except Exception as exc:  # pragma: no cover
             out["other_precision_error"] = str(exc)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, xf, args.cutoff)
+            out["cpu_baseline_configs"] = cpu_baseline_configs()
 
     print(json.dumps(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --mode hrex
+# ---------------------------------------------------------------------------------------------------------------------
+def run_hrex(args, rank, local_rank, world, backend):
+    from timemachine_amd import hrex, parallel
+
+    n_states = args.windows or 24
+    steps_per_frame = args.steps_per_frame
+    n_frames = max(args.steps // steps_per_frame, 1)
+    warm_frames = max(args.warmup // steps_per_frame, 1)
+    dh = hrex.DistributedHREX(n_states, TEMPERATURE, max_delta_states=args.max_delta_states, world_size=world, rank=rank)
+    mine = dh.local_replicas
+    co = None
+    if not args.stub:
+        from timemachine_amd import potentials as P
+        from timemachine_amd import testsystems as ts
+        from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+        if co.device_count() < 1:
+            raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
+        co.set_device(local_rank)
+        prec = np.float64 if args.precision == "f64" else np.float32
+        system = ts.config5_complex_sized(0.0)
+        N = system.num_atoms
+        lig = np.arange(system.num_water_atoms, N)
+        lambdas = np.linspace(0.0, 0.5, n_states)
+        params_by_state = np.stack([system.nb_params] * n_states)
+        for k, lam in enumerate(lambdas):  # windows differ only in the ligand's nonbonded parameters (4D decoupling + charge scaling)
+            params_by_state[k][lig, 3] = lam * system.cutoff
+            params_by_state[k][lig, 0] *= 1.0 - 0.5 * lam
+
+        def make_bps(p):
+            return [bp.to_gpu(p).bound_impl for bp in ts.bound_potentials(system, p, nblist_padding=args.padding)]
+
+        x0, v0 = equilibrate(co, LangevinIntegrator, system, make_bps, 99, args.equil_scale, np.float32)
+        unbound = P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff).to_gpu(prec).unbound_impl
+        ctxts, bound_nb = [], []
+        for r in mine:
+            bps = make_bps(prec)
+            bps[-1].set_params(params_by_state[r].reshape(-1))
+            ctxts.append(co.Context(x0, v0, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, 500 + r).impl(), bps))
+            bound_nb.append(bps[-1])
+        boxes = np.stack([system.box] * len(mine))
+    else:
+        N = 31000
+        ctxts = [StubContext(N) for _ in mine]
+
+    timers = {"md": 0.0, "matrix": 0.0, "exchange": 0.0, "rebind": 0.0}
+
+    def frame(it, timed):
+        t0 = time.perf_counter()
+        for c in ctxts:
+            c.multiple_steps(steps_per_frame, 0)
+        device_sync(co)
+        t1 = time.perf_counter()
+        if args.stub:
+            state = dh.state_of_replica()
+            rows = np.full((len(mine), n_states), np.inf)
+            for i, r in enumerate(mine):
+                lo, hi = max(0, state[r] - args.max_delta_states), min(n_states - 1, state[r] + args.max_delta_states)
+                rows[i, lo : hi + 1] = 0.1 * np.abs(np.arange(lo, hi + 1) - r)
+        else:
+            coords = np.stack([c.get_x_t() for c in ctxts])
+            rows = hrex.compute_potential_matrix(unbound, coords, boxes, params_by_state, dh.replica_idx_by_state, args.max_delta_states, replicas=mine)
+        t2 = time.perf_counter()
+        new_states = dh.exchange(rows, seed=1000 + it)  # collective: one all_gather + the identical swap chain everywhere
+        t3 = time.perf_counter()
+        if not args.stub:
+            for i in range(len(mine)):
+                bound_nb[i].set_params(params_by_state[new_states[i]].reshape(-1))
+        t4 = time.perf_counter()
+        if timed:
+            timers["md"] += t1 - t0
+            timers["matrix"] += t2 - t1
+            timers["exchange"] += t3 - t2
+            timers["rebind"] += t4 - t3
+
+    for it in range(warm_frames):
+        frame(it, False)
+    parallel.barrier()
+    device_sync(co)
+    t0 = time.perf_counter()
+    for it in range(n_frames):
+        frame(warm_frames + it, True)
+    device_sync(co)
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    for c in ctxts:
+        assert np.all(np.isfinite(c.get_x_t())), "trajectory diverged"
+    t_max = {k: parallel.max_over_ranks(v) for k, v in timers.items()}
+    if rank != 0:
+        return
+    md_steps = n_frames * steps_per_frame
+    accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
+    proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
+    print(json.dumps({
+        "metric": "ns/day aggregate over all lambda windows, HREX (BASELINE config 5 shape)",
+        "value": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3,
+        "unit": "ns/day",
+        "n_gpus": world,
+        "steps": md_steps,
+        "warmup": warm_frames * steps_per_frame,
+        "ms_per_step": 1e3 * elapsed / md_steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic",
+        "config": {
+            "workload": f"configs[4] (zero-based; BASELINE's fifth) shape: {n_states} lambda windows of a {N}-atom solvated-ligand state, round-robin over {world} GPU(s) "
+            f"({len(mine)} resident replicas on rank 0), {steps_per_frame} steps per frame, neighbour exchange with max_delta_states {args.max_delta_states}, "
+            f"{n_states}^3 swap attempts per frame; ms_per_step is wall time per MD step of ONE window slot (all windows of a rank run back to back)",
+            "atoms": N, "windows": n_states, "frames": n_frames, "nblist_padding": args.padding,
+        },
+        "frames_per_s": n_frames / elapsed,
+        "per_frame_ms": {k: 1e3 * v / n_frames for k, v in t_max.items()},
+        "exchange_latency_ms": 1e3 * (t_max["matrix"] + t_max["exchange"] + t_max["rebind"]) / n_frames,
+        "swap_acceptance": accepted / max(proposed, 1),
+        "world_size": world,
+        "backend": backend,
+        "device": "stub" if args.stub else co.device_name(),
+    }))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    maybe_self_launch(args)
+    rank, local_rank, world, backend = init_distributed(args)
+    try:
+        if args.mode == "hrex":
+            run_hrex(args, rank, local_rank, world, backend)
+        else:
+            run_md(args, rank, local_rank, world, backend)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

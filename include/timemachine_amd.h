@@ -205,6 +205,9 @@ int tm_context_finalize(tm_context_t ctxt);
 /* multiple_steps(n_steps, store_x_interval): the caller computes n_samples = n_steps / (store_x_interval or n_steps)
  * exactly as the binding does (wrap_kernels.cpp:347-369) and passes xs[n_samples,N,3], boxes[n_samples,3,3]. */
 int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, double *xs, double *boxes);
+/* measurement aid (bench.py): device time, in ms, of the steps of the last tm_context_multiple_steps call -- HIP events
+ * on the context's stream around the first .. last step (the final frame's device-to-host copy is outside) */
+int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms);
 int tm_context_get_x_t(tm_context_t ctxt, double *out);
 int tm_context_get_v_t(tm_context_t ctxt, double *out);
 int tm_context_get_box(tm_context_t ctxt, double *out);
@@ -241,6 +244,19 @@ int tm_hilbert_lut(uint32_t *out);
 int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
+/* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.cuh):
+ * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
+ * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */
+int tm_es_force_table(double beta, double *out);
+
+/* ---- HREX: a batch of neighbour-swap Metropolis moves on the state -> replica permutation (host only; no device work)
+ * replaces the jitted loop timemachine/md/hrex.py:50-130 (_run_neighbor_swaps): for attempt t, pair k = pair_idxs[t] =
+ * (s_a, s_b); accept iff uniform_samples[t] < exp(min(0, log_q[r_a, s_b] + log_q[r_b, s_a] - log_q[r_a, s_a] - log_q[r_b, s_b]))
+ * (false for NaN).  log_q_kl is [n_replicas, n_states] row-major; proposed / accepted are per pair. */
+int tm_hrex_run_neighbor_swaps(int n_replicas, int n_states, const int64_t *replica_idx_by_state, int n_pairs, const int64_t *neighbor_pairs,
+                               const double *log_q_kl, int n_attempts, const int64_t *pair_idxs, const double *uniform_samples,
+                               int64_t *out_replica_idx_by_state, uint32_t *proposed, uint32_t *accepted);
+
 /* debug: run the DEVICE fixed-point conversions (the functions the kernels inline) on caller-supplied values.
  *   kind 0: FLOAT_TO_FIXED (2^36; forces of bonded terms, du/dq, du/dw)      k_fixed_point.cuh:56-71
  *   kind 1 / 2: FLOAT_TO_FIXED_DU_DP with 2^37 (du/dsig) / 2^38 (du/deps)    fixed_point.hpp:8-11

@@ -1,0 +1,61 @@
+"""CPU tests of bench.py's launch / collective / report plumbing with a stubbed step (--stub: a stand-in Context that
+sleeps; everything else -- self-launch of N ranks through torch.distributed.run, gloo process group, barriers, max over
+ranks, the gather, HREX exchange, the JSON line -- is the code the GPU run uses over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _run(*flags, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--stub", *flags], capture_output=True, text=True, timeout=300, env=e, cwd=REPO)
+    return r
+
+
+def _line(r):
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in out, k
+    assert "workload" in out["config"] and "model" not in out["config"]
+    return out
+
+
+def test_bench_single_rank_stub():
+    out = _line(_run("--steps", "20", "--warmup", "5"))
+    assert out["n_gpus"] == 1 and out["world_size"] == 1 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["value"] > 0 and out["host_ms_per_step"] >= out["ms_per_step"] * 0.5
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it becomes a 2-rank job (gloo here, RCCL on the GPU box)."""
+    out = _line(_run("--gpus", "2", "--steps", "40", "--warmup", "10"))
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["backend"] == "gloo"
+    assert out["config"]["replicas"] == 2 and out["scaling"] == "weak"
+    assert out["mbar_gather_ok"] is True and out["mbar_gather_ms"] > 0
+    single = _line(_run("--steps", "40", "--warmup", "10"))
+    assert out["value"] > 1.2 * single["value"]  # aggregate over both ranks, not per rank
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    r = _run("--gpus", "4", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in (r.stdout + r.stderr)
+
+
+def test_bench_hrex_mode_two_ranks():
+    out = _line(_run("--gpus", "2", "--mode", "hrex", "--windows", "6", "--steps", "800", "--warmup", "400"))
+    assert out["n_gpus"] == 2 and out["config"]["windows"] == 6 and out["config"]["frames"] == 2
+    assert out["scaling"] == "strong" and out["frames_per_s"] > 0 and out["exchange_latency_ms"] > 0
+    assert 0.0 < out["swap_acceptance"] <= 1.0
+    assert set(out["per_frame_ms"]) == {"md", "matrix", "exchange", "rebind"}

@@ -151,3 +151,38 @@ def test_committed_bench_lines_follow_the_contract():
     assert c["kind"] in ("reference", "port")
     # value == steps / time: ns/day from ms per step at 2.5 fs
     assert abs(d["value"] - d["n_gpus"] * 86400.0 * 2.5e-6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_es_force_table_matches_the_analytic_function():
+    """The f64 kernels' tabulated electrostatic force factor F(d^2) = (D'(d)/d - D(d)/d^2)/d, D = erfc(beta d) S(d)
+    (csrc/nb_es_table.cuh) against the analytic form in numpy/scipy: <= 1e-11 relative over d in [0.0884, 1.2) nm, exactly
+    the interval layout the device indexes with the bits of d^2."""
+    from scipy.special import erfc
+
+    from timemachine_amd.lib import custom_ops
+
+    for beta in (2.0, 2.6):
+        tab = custom_ops.es_force_table(beta)
+        assert tab.shape == (256, 6) and np.all(np.isfinite(tab))
+        rng = np.random.default_rng(0)
+        s = np.exp(rng.uniform(np.log(2.0**-7), np.log(1.44), 200000))
+        s = np.concatenate([s, [2.0**-7, 0.01, 0.25, 1.0, np.nextafter(1.44, 0)]])
+        bits = s.view(np.uint64)
+        idx = (bits >> np.uint64(47)).astype(np.int64) - ((1023 - 7) << 5)
+        frac = ((bits & np.uint64((1 << 47) - 1)) << np.uint64(5)) | np.uint64(0x3FF0000000000000)
+        t = frac.view(np.float64) - 1.0
+        assert idx.min() >= 0 and idx.max() < 256 and t.min() >= 0 and t.max() < 1
+        c = tab[idx]
+        p = c[:, 5]
+        for k in (4, 3, 2, 1, 0):
+            p = p * t + c[:, k]
+        d = np.sqrt(s)
+        q = (d / 1.2) ** 8
+        S = np.cos(0.5 * np.pi * q) ** 3
+        dS = -12 * np.pi / 1.2**8 * d**7 * np.sin(0.5 * np.pi * q) * np.cos(0.5 * np.pi * q) ** 2
+        e = erfc(beta * d)
+        de = -2 * beta / np.sqrt(np.pi) * np.exp(-((beta * d) ** 2))
+        F = ((e * dS + de * S) / d - e * S / d**2) / d
+        # F -> 0 at the end of the switch: an absolute floor there (1e-10 in F = 6e-9 kJ/mol/nm on a water O-H pair)
+        assert np.all(np.abs(p - F) < 3e-11 * np.abs(F) + 1e-10)
+        assert np.max(np.abs(p - F)[s < 1.0] / np.abs(F)[s < 1.0]) < (6e-12 if beta == 2.0 else 3e-11)

@@ -269,6 +269,8 @@ def test_hrex_swap_chain_matches_reference_fixture():
     for tag in ("a", "b"):
         args = (g[f"{tag}_perm0"], g[f"{tag}_pairs"], g[f"{tag}_log_q"], g[f"{tag}_pair_idxs"], g[f"{tag}_uniforms"])
         perm, proposed, accepted = th.run_neighbor_swaps(*args)
+        for got, want in zip(th.run_neighbor_swaps_python(*args), (perm, proposed, accepted)):
+            np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(perm, g[f"{tag}_perm"])
         np.testing.assert_array_equal(proposed, g[f"{tag}_proposed"])
         np.testing.assert_array_equal(accepted, g[f"{tag}_accepted"])

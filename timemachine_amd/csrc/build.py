@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtimemachine_amd.so")
 SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "potential.hip", "c_api.cpp"]
 HEADERS = [
-    "common.hpp", "engine.hpp", "fixed_point.cuh", "nb_pair.cuh", "kernels_nonbonded.cuh", "kernels_nblist.cuh", "kernels_bonded.cuh", "philox.cuh", "nb_math.cuh", "nb_math_coeffs.h",
+    "common.hpp", "engine.hpp", "fixed_point.cuh", "nb_pair.cuh", "kernels_nonbonded.cuh", "kernels_nblist.cuh", "kernels_bonded.cuh", "philox.cuh", "nb_math.cuh", "nb_math_coeffs.h", "nb_es_table.cuh",
     "profiler.hpp", "../../include/timemachine_amd.h",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -43,11 +43,16 @@ def _compile(src):
     return src, obj, r.returncode, r.stdout + r.stderr
 
 
-def build_variant(tag, defines):
-    """debug/ablation variant: lib<...>_<tag>.so with extra -D flags (selected at run time with TM_AMD_LIB)"""
+def build_variant(tag, defines, only=None):
+    """debug/ablation variant: lib<...>_<tag>.so with extra -D flags (selected at run time with TM_AMD_LIB).
+    `only`: recompile just these sources with the flags and link the product build's objects for the rest (tile-kernel
+    experiments: the macros only reach nonbonded.hip)."""
     out = os.path.join(HERE, f"libtimemachine_amd_{tag}.so")
-    objs = []
+    objs, temps = [], []
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(HERE, os.path.splitext(src)[0] + ".o"))
+            continue
         obj = os.path.join(HERE, os.path.splitext(src)[0] + f".{tag}.o")
         cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -55,10 +60,11 @@ def build_variant(tag, defines):
             print(r.stdout + r.stderr, file=sys.stderr)
             raise RuntimeError(f"hipcc failed on {src}")
         objs.append(obj)
+        temps.append(obj)
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed")
-    for o in objs:
+    for o in temps:
         os.remove(o)
     return out
 
@@ -87,8 +93,10 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:
-        i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], sys.argv[i + 2 :]))
+    if "--variant" in sys.argv or "--nb-variant" in sys.argv:
+        # --variant TAG DEFINES...: every source recompiled; --nb-variant TAG DEFINES...: nonbonded.hip only
+        nb_only = "--nb-variant" in sys.argv
+        i = sys.argv.index("--nb-variant" if nb_only else "--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2 :], only=("nonbonded.hip",) if nb_only else None))
     else:
         print(build(force="--force" in sys.argv))

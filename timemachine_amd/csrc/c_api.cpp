@@ -622,6 +622,11 @@ int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, dou
     ctxt->p->multiple_steps(n_steps, n_samples, xs, boxes);
     TM_CATCH
 }
+int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms) {
+    TM_TRY
+    *ms = ctxt->p->last_multiple_steps_ms();
+    TM_CATCH
+}
 int tm_context_get_x_t(tm_context_t ctxt, double *out) {
     TM_TRY
     ctxt->p->get_x_t(out);
@@ -789,6 +794,48 @@ int tm_profile_read(const char *kernel_name, double *total_ms, long long *launch
 int tm_profile_reset(void) {
     TM_TRY
     Profiler::get().reset();
+    TM_CATCH
+}
+int tm_es_force_table(double beta, double *out) {
+    TM_TRY
+    es_force_table_host(beta, out);
+    TM_CATCH
+}
+int tm_hrex_run_neighbor_swaps(
+    int n_replicas, int n_states, const int64_t *replica_idx_by_state, int n_pairs, const int64_t *neighbor_pairs, const double *log_q_kl,
+    int n_attempts, const int64_t *pair_idxs, const double *uniform_samples, int64_t *out_replica_idx_by_state, uint32_t *proposed,
+    uint32_t *accepted) {
+    TM_TRY
+    require(n_replicas > 0 && n_states > 0 && n_pairs >= 0 && n_attempts >= 0, "run_neighbor_swaps: negative size");
+    std::vector<int64_t> perm(replica_idx_by_state, replica_idx_by_state + n_states);
+    for (int64_t r : perm) {
+        require(r >= 0 && r < n_replicas, "run_neighbor_swaps: replica index out of range");
+    }
+    for (int k = 0; k < n_pairs; k++) {
+        proposed[k] = 0;
+        accepted[k] = 0;
+        require(neighbor_pairs[2 * k] >= 0 && neighbor_pairs[2 * k] < n_states && neighbor_pairs[2 * k + 1] >= 0 && neighbor_pairs[2 * k + 1] < n_states,
+                "run_neighbor_swaps: state index out of range");
+    }
+    for (int t = 0; t < n_attempts; t++) {
+        const int64_t k = pair_idxs[t];
+        require(k >= 0 && k < n_pairs, "run_neighbor_swaps: pair index out of range");
+        const int64_t s_a = neighbor_pairs[2 * k], s_b = neighbor_pairs[2 * k + 1];
+        proposed[k] += 1;
+        const int64_t r_a = perm[s_a], r_b = perm[s_b];
+        const double before = log_q_kl[r_a * n_states + s_a] + log_q_kl[r_b * n_states + s_b];
+        const double after = log_q_kl[r_a * n_states + s_b] + log_q_kl[r_b * n_states + s_a];
+        const double diff = after - before; // NaN for (-inf) - (-inf): the comparison below is then false, as in jnp
+        const double acceptance_probability = std::exp(diff < 0.0 ? diff : (diff >= 0.0 ? 0.0 : diff));
+        if (uniform_samples[t] < acceptance_probability) {
+            perm[s_a] = r_b;
+            perm[s_b] = r_a;
+            accepted[k] += 1;
+        }
+    }
+    for (int s = 0; s < n_states; s++) {
+        out_replica_idx_by_state[s] = perm[s];
+    }
     TM_CATCH
 }
 int tm_debug_float_to_fixed(int precision, int kind, const double *in, int n, uint64_t *out) {

@@ -4,6 +4,7 @@
 // C ABI in include/timemachine_amd.h is a 1:1 door onto it.  Everything device-side is HIP for gfx950.
 #pragma once
 #include "common.hpp"
+#include "nb_es_table.cuh"
 
 #include <memory>
 #include <optional>
@@ -43,6 +44,7 @@ struct FusedSegment {
     const double *scales; // pair lists: [count][2]
     double beta, cutoff;  // pair lists
     const int *aux;       // chiral bond restraints: signs [count]
+    const double *es_table = nullptr; // pair lists, f64 kernels: the electrostatic force-factor table of `beta` (nb_es_table.cuh)
 };
 struct FusedTable {
     int n;
@@ -434,6 +436,7 @@ protected:
     const int N_;
     int K_;
     const double beta_, cutoff_, nblist_padding_;
+    const double *d_es_table_ = nullptr; // f64 kernels: electrostatic force-factor table of beta_ (shared per device and beta)
     const bool disable_hilbert_;
     int calls_since_sort_;
     int parity_;
@@ -490,6 +493,7 @@ public:
 private:
     int M_;
     double beta_, cutoff_;
+    const double *d_es_table_ = nullptr; // f64 kernels: electrostatic force-factor table of beta_
     DeviceBuffer<int> d_pair_idxs_;
     DeviceBuffer<double> d_scales_;
     DeviceBuffer<i128> d_u_partials_;
@@ -647,8 +651,13 @@ public:
     std::vector<std::shared_ptr<BoundPotential>> get_potentials() const { return bps_; }
     std::vector<std::shared_ptr<Mover>> get_movers() const { return movers_; }
     hipStream_t stream() const { return stream_; }
+    // device time of the steps of the last multiple_steps call: HIP events recorded on the context's stream right
+    // before the first step and right after the last one (the final frame's device-to-host copy comes after)
+    double last_multiple_steps_ms();
 
 private:
+    hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr;
+    bool ev_valid_ = false;
     int N_;
     std::vector<std::shared_ptr<Mover>> movers_;
     int step_;

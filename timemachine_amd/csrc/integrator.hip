@@ -353,7 +353,22 @@ Context::Context(
     }
 }
 
-Context::~Context() {}
+Context::~Context() {
+    if (ev_start_) {
+        (void)hipEventDestroy(ev_start_);
+        (void)hipEventDestroy(ev_stop_);
+    }
+}
+
+double Context::last_multiple_steps_ms() {
+    if (!ev_valid_) {
+        throw std::runtime_error("no multiple_steps call has been timed yet");
+    }
+    float ms = 0;
+    HIP_CHECK(hipEventSynchronize(ev_stop_));
+    HIP_CHECK(hipEventElapsedTime(&ms, ev_start_, ev_stop_));
+    return static_cast<double>(ms);
+}
 
 void Context::_verify_coords_and_box(const double *coords, const double *box, hipStream_t stream) {
     // reference: context.cu:52-78 (messages are matched by tests/test_md.py:929,1007)
@@ -403,8 +418,20 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     }
     hipStream_t stream = stream_;
     intg_->initialize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
+    if (ev_start_ == nullptr) {
+        HIP_CHECK(hipEventCreate(&ev_start_));
+        HIP_CHECK(hipEventCreate(&ev_stop_));
+    }
+    ev_valid_ = false;
+    if (n_steps > 0) {
+        HIP_CHECK(hipEventRecord(ev_start_, stream));
+    }
     for (int i = 1; i <= n_steps; i++) {
         this->_step(stream);
+        if (i == n_steps) {
+            HIP_CHECK(hipEventRecord(ev_stop_, stream));
+            ev_valid_ = true;
+        }
         if (i % store_x_interval == 0) {
             double *box_ptr = h_box + static_cast<size_t>(i / store_x_interval - 1) * 9;
             double *coord_ptr = h_x + static_cast<size_t>(i / store_x_interval - 1) * N_ * 3;

@@ -61,9 +61,11 @@ template <typename Real, bool DU_DP> struct TileShape {
 #define TM_TILE_F32_WG_WAVES 8
 #define TM_TILE_F32_WGS 2
 #endif
-    static const int waves = sizeof(Real) == 8 ? 4 * TM_TILE_WAVES_F64 : (DU_DP ? 16 : TM_TILE_F32_WG_WAVES);
+    // f64 du_dp variants: 3 waves per SIMD whatever the forces-only shape is (their per-wave LDS is 1.5x, their register need larger)
+    static const int f64_waves_per_simd = DU_DP ? (TM_TILE_WAVES_F64 < 3 ? TM_TILE_WAVES_F64 : 3) : TM_TILE_WAVES_F64;
+    static const int waves = sizeof(Real) == 8 ? 4 * f64_waves_per_simd : (DU_DP ? 16 : TM_TILE_F32_WG_WAVES);
     static const int wgs_per_cu = sizeof(Real) == 8 ? 1 : (DU_DP ? 1 : TM_TILE_F32_WGS);
-    static const int min_waves = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : (DU_DP ? 4 : (TM_TILE_F32_WG_WAVES * TM_TILE_F32_WGS) / 4);
+    static const int min_waves = sizeof(Real) == 8 ? f64_waves_per_simd : (DU_DP ? 4 : (TM_TILE_F32_WG_WAVES * TM_TILE_F32_WGS) / 4);
 #endif
     static const int waves_per_cu = waves * wgs_per_cu;
 };
@@ -185,7 +187,8 @@ template <typename Real, bool NEGATED>
 __device__ __forceinline__ i128 nonbonded_pair_list_term(
     const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl = ForceLayout{3, 1});
+    const double *__restrict__ es_table, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u,
+    const ForceLayout fl = ForceLayout{3, 1});
 
 // One 256-term block of a ForcePlan table (engine.hpp): bonded terms and pair lists, forces only.  Defined at the end of
 // this header; called by k_fused_forces and by the tail of the tile kernel.
@@ -215,6 +218,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const unsigned int items_cap,                  // bucket capacity: bucket b lives at items[b * items_cap ...]
     const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
+    const double *__restrict__ es_table, // f64: the electrostatic force-factor table of beta (nb_es_table.cuh); f32: unused
     u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, const int acc_stride, i128 *__restrict__ u_partials,
     // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
@@ -227,15 +231,17 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         float4 rowf[TILE]; // phase-1 copy of the row atoms: (x, y, z, w) relative to the tile origin, f32
         Real row[7][TILE];
         Real col[7][NB_CHUNK];
-        u64 fi[COMPUTE_DU_DX ? 3 : 1][TILE];
-        u64 fj[COMPUTE_DU_DX ? 3 : 1][NB_CHUNK];
-        u64 pi[COMPUTE_DU_DP ? 4 : 1][TILE];
-        u64 pj[COMPUTE_DU_DP ? 4 : 1][NB_CHUNK];
+        u64 fi[COMPUTE_DU_DX ? 3 : 1][COMPUTE_DU_DX ? TILE : 1]; // outputs that are not asked for take 8 bytes, not a row
+        u64 fj[COMPUTE_DU_DX ? 3 : 1][COMPUTE_DU_DX ? NB_CHUNK : 1];
+        u64 pi[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? TILE : 1];
+        u64 pj[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? NB_CHUNK : 1];
         unsigned int rowatom[TILE];
         unsigned short queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // up to 4 rounds are appended between drains
     };
     __shared__ WaveLds s_wave[WAVES];
     __shared__ unsigned int s_ticket; // next position of this workgroup's pool
+    // f64: the workgroup's copy of the electrostatic force-factor table (12 KB, read-only after the barrier below)
+    __shared__ __attribute__((aligned(16))) double s_es_tab[sizeof(Real) == 8 ? ES_TAB_DOUBLES : 2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -253,7 +259,34 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     if (threadIdx.x == 0) {
         s_ticket = 0;
     }
+    if constexpr (sizeof(Real) == 8) {
+        for (int i = threadIdx.x; i < ES_TAB_DOUBLES; i += WAVES * 64) {
+            s_es_tab[i] = es_table[i];
+        }
+    }
     __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
+    // how phase 2 reaches the table: f64 reads the LDS copy with three ds_read_b128 per pair
+    struct EsTableLds {
+        const double *tab;
+        __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
+            const double2 *p = reinterpret_cast<const double2 *>(tab + idx * ES_TAB_COEFFS);
+            const double2 a = p[0], b = p[1], e = p[2];
+            c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
+        }
+    };
+#ifdef TM_ES_TAB_GLOBAL // experiment: the table through the vector L1 instead of LDS
+    using TileTab = std::conditional_t<sizeof(Real) == 8, EsTableGlobal, EsTableNone>;
+    TileTab es_tab{};
+    if constexpr (sizeof(Real) == 8) {
+        es_tab.tab = es_table;
+    }
+#else
+    using TileTab = std::conditional_t<sizeof(Real) == 8, EsTableLds, EsTableNone>;
+    TileTab es_tab{};
+    if constexpr (sizeof(Real) == 8) {
+        es_tab.tab = s_es_tab;
+    }
+#endif
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
@@ -434,8 +467,18 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         // Filter specialisations.  compact: every |row - origin| + |col - origin| stays below half a box length, so
         // row - col IS the minimum image and the three rint/fma pairs per slot are skipped.  needs_order: only tiles
         // whose columns reach back into (or before) the row block's own index range need the row < col test.
-        bool compact, needs_order;
+        // raw_compact: the same for the UNWRAPPED coordinates that phase 2 subtracts (atoms that have left the home
+        // cell by different numbers of box lengths make a tile non-compact there although its images are close): then
+        // |row - col| / box < 0.49 in every dimension, rint(.) == 0, fma(-box, 0, delta) == delta, and phase 2 skips
+        // min_image without changing a bit.
+        bool compact, needs_order, raw_compact;
         {
+            const Real rbx = static_cast<Real>(0.245) * bx.x, rby = static_cast<Real>(0.245) * bx.y, rbz = static_cast<Real>(0.245) * bx.z;
+            bool raw_far = ja < uK && !(fabs(cur.cj[0] - cur.ox) < rbx && fabs(cur.cj[1] - cur.oy) < rby && fabs(cur.cj[2] - cur.oz) < rbz);
+            if (lane < TILE && cur.ra < uK) {
+                raw_far = raw_far || !(fabs(cur.rr[0] - cur.ox) < rbx && fabs(cur.rr[1] - cur.oy) < rby && fabs(cur.rr[2] - cur.oz) < rbz);
+            }
+            raw_compact = __ballot(raw_far) == 0ull;
             const bool col_live = ja < uK;
             float cfrac = fmaxf(fabsf(cfx) * fibx, fmaxf(fabsf(cfy) * fiby, fabsf(cfz) * fibz));
             cfrac = col_live ? cfrac : 0.0f;
@@ -548,9 +591,12 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 if (lane < n) {
                     const unsigned int e = s_queue[base + lane];
                     const int pi = e >> 8, pj = e & 0xff;
-                    const Real ddx = min_image(s_row[0][pi] - s_col[0][pj], bx.x, bx.inv_x);
-                    const Real ddy = min_image(s_row[1][pi] - s_col[1][pj], bx.y, bx.inv_y);
-                    const Real ddz = min_image(s_row[2][pi] - s_col[2][pj], bx.z, bx.inv_z);
+                    Real ddx = s_row[0][pi] - s_col[0][pj], ddy = s_row[1][pi] - s_col[1][pj], ddz = s_row[2][pi] - s_col[2][pj];
+                    if (!raw_compact) { // wave-uniform; for a compact tile the three rint / fma pairs are exact no-ops
+                        ddx = min_image(ddx, bx.x, bx.inv_x);
+                        ddy = min_image(ddy, bx.y, bx.inv_y);
+                        ddz = min_image(ddz, bx.z, bx.inv_z);
+                    }
                     const Real ddw = s_row[3][pi] - s_col[3][pj];
                     const Real dd2 = pair_d2(ddx, ddy, ddz, ddw);
                     if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
@@ -559,8 +605,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     PairOut<Real> o;
 #if defined(TM_ABLATE) && TM_ABLATE == 4
                     o.prefactor = dd2 * qi; o.u = qj; o.inv_dij = qi; o.ebd = qj; o.sig_grad = 0; o.eps_grad = 0; o.has_lj = false; // ablation: no math
+#elif defined(TM_ABLATE) && TM_ABLATE == 5
+                    nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o, EsTableConst{}); // ablation: no table reads
 #else
-                    nb_pair<Real>(1, 1, qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o);
+                    nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o, es_tab);
 #endif
 #if defined(TM_ABLATE) && TM_ABLATE == 2
                     if (o.prefactor == static_cast<Real>(1.2345e-30)) { energy += 1; } // ablation: math, no accumulation
@@ -568,12 +616,19 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     if constexpr (COMPUTE_DU_DX) {
                         u64 fx, fy, fz;
                         pair_force_fixed(o.prefactor, ddx, ddy, ddz, fx, fy, fz);
-                        lds_add(&s_fi[0][pi], fx);
-                        lds_add(&s_fi[1][pi], fy);
-                        lds_add(&s_fi[2][pi], fz);
-                        lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
-                        lds_sub(&s_fj[1][pj], fy);
-                        lds_sub(&s_fj[2][pj], fz);
+#if defined(TM_ABLATE) && TM_ABLATE == 6
+                        const int ai = lane & 31, aj = lane; // ablation: the six LDS atomics without any address conflict
+#elif defined(TM_ABLATE) && TM_ABLATE == 7
+                        const int ai = pi, aj = lane; // ablation: conflict-free column atomics only
+#else
+                        const int ai = pi, aj = pj;
+#endif
+                        lds_add(&s_fi[0][ai], fx);
+                        lds_add(&s_fi[1][ai], fy);
+                        lds_add(&s_fi[2][ai], fz);
+                        lds_sub(&s_fj[0][aj], fx); // FIX(-p d) == -FIX(p d)
+                        lds_sub(&s_fj[1][aj], fy);
+                        lds_sub(&s_fj[2][aj], fz);
                     }
 #endif
                     if constexpr (COMPUTE_DU_DP) {
@@ -711,7 +766,7 @@ template <typename Real, bool NEGATED>
 __device__ __forceinline__ i128 nonbonded_pair_list_term(
     const int pair, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl) {
+    const double *__restrict__ es_table, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, const bool want_u, const ForceLayout fl) {
     i128 energy = 0;
     const NbBox<Real> bx = load_box<Real>(box);
     const int ia = pair_idxs[pair * 2 + 0], ja = pair_idxs[pair * 2 + 1];
@@ -729,7 +784,17 @@ __device__ __forceinline__ i128 nonbonded_pair_list_term(
         const Real charge_scale = static_cast<Real>(scales[pair * 2 + 0]);
         const Real lj_scale = static_cast<Real>(scales[pair * 2 + 1]);
         PairOut<Real> o;
-        nb_pair<Real>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o);
+        // the pair function of the tile kernel, fed from the table in global memory (12 KB: L1 / L2 resident)
+        using Tab = std::conditional_t<sizeof(Real) == 8, EsTableGlobal, EsTableNone>;
+        Tab tab{};
+        if constexpr (sizeof(Real) == 8) {
+            tab.tab = es_table;
+        }
+        if (du_dp != nullptr || want_u) { // uniform across the launch
+            nb_pair<true>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o, tab);
+        } else {
+            nb_pair<false>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o, tab);
+        }
 #define TM_ACC(ptr, val)                                                                                               \
 do {                                                                                                               \
     const u64 v_ = (val);                                                                                          \
@@ -774,12 +839,12 @@ template <typename Real, bool NEGATED>
 __global__ __launch_bounds__(256) void k_nonbonded_pair_list(
     const int M, const double *__restrict__ coords, const double *__restrict__ params, const double *__restrict__ box,
     const int *__restrict__ pair_idxs, const double *__restrict__ scales, const double beta_d, const double cutoff_d,
-    u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
+    const double *__restrict__ es_table, u64 *__restrict__ du_dx, u64 *__restrict__ du_dp, i128 *__restrict__ u_partials) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     i128 energy = 0;
     if (pair < M) {
         energy = nonbonded_pair_list_term<Real, NEGATED>(
-            pair, coords, params, box, pair_idxs, scales, beta_d, cutoff_d, du_dx, du_dp, u_partials != nullptr);
+            pair, coords, params, box, pair_idxs, scales, beta_d, cutoff_d, es_table, du_dx, du_dp, u_partials != nullptr);
     }
     if (u_partials) {
         // per-wave partial sums instead of one 16-byte store per pair
@@ -898,10 +963,10 @@ __device__ __forceinline__ void fused_dispatch(
     case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
     case FUSED_TORSION: periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
     case FUSED_PAIR_LIST:
-        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);
+        nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, du_dx, nullptr, false, fl);
         break;
     case FUSED_PAIR_LIST_NEGATED:
-        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);
+        nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, du_dx, nullptr, false, fl);
         break;
     case FUSED_PAIR_LIST_PRECOMPUTED:
         nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, du_dx, nullptr, false, fl);

@@ -15,6 +15,7 @@
 //   prefactor = es_prefactor - lj_prefactor
 #pragma once
 #include "fixed_point.cuh"
+#include "nb_es_table.cuh"
 #include "nb_math.cuh"
 
 namespace tmamd {
@@ -146,6 +147,105 @@ __device__ __forceinline__ void nb_pair(
     o.u = u;
     o.inv_dij = inv_dij;
     o.ebd = damping;
+}
+
+// ---------------- f64: electrostatic force factor from the table (nb_es_table.cuh) ----------------
+// Where a kernel keeps the table: LDS (tile kernel: a copy made at kernel start) or global memory (pair lists).  Both
+// hold the same doubles and feed the same arithmetic, so the two give identical bits.
+struct EsTableGlobal {
+    const double *__restrict__ tab;
+    __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
+        const double2 *p = reinterpret_cast<const double2 *>(tab + static_cast<size_t>(idx) * ES_TAB_COEFFS);
+        const double2 a = p[0], b = p[1], e = p[2];
+        c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
+    }
+};
+struct EsTableConst { // ablation builds only: no memory access at all
+    __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
+        for (int k = 0; k < ES_TAB_COEFFS; k++) {
+            c[k] = 0.5 + idx;
+        }
+    }
+};
+struct EsTableNone {}; // f32 kernels: analytic A&S erfc + hardware exp / sincos, no table
+
+// F(d2) such that the electrostatic force prefactor of a pair is charge_scale * q_i q_j * F(d2)
+template <typename Tab> __device__ __forceinline__ double es_force_factor(const double beta, const double d2, const Tab &tab) {
+    double t;
+    unsigned int idx = es_tab_index(d2, t);
+    const bool outside = idx >= static_cast<unsigned int>(ES_TAB_INTERVALS); // d2 < 2^-7 or d2 >= 2 (or NaN)
+    idx = outside ? 0u : idx;
+    double c[ES_TAB_COEFFS];
+    tab.load(idx, c);
+    double p = __builtin_fma(c[5], t, c[4]);
+    p = __builtin_fma(p, t, c[3]);
+    p = __builtin_fma(p, t, c[2]);
+    p = __builtin_fma(p, t, c[1]);
+    p = __builtin_fma(p, t, c[0]);
+    const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
+    double f = (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+    // below the table: clashing atoms (d < 0.088 nm) only -- the analytic form, behind a wave-uniform branch
+    const bool below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
+    if (__ballot(below) != 0ull) {
+        if (below) {
+            const double inv = tm_rsqrt_f64(d2);
+            double damping;
+            f = inv * real_es_factor(beta, d2 * inv, inv, inv * inv, damping);
+        }
+    }
+    return f;
+}
+
+// The f64 pair function.  WANT_U_DP = false (MD: forces only) never forms 1/d, erfc, exp or the switch function:
+//   prefactor = s_q q_i q_j F(d2) - s_lj eps_ij sig6 (48 sig6 - 24) / d2,   sig6 = (sig_ij^2 / d2)^3
+// WANT_U_DP = true adds, on top of the SAME prefactor arithmetic (so du/dx has the same bits whichever outputs are asked
+// for), the analytic damping function for the energy and du/dq, and the LJ parameter derivatives.
+template <bool WANT_U_DP, typename Tab>
+__device__ __forceinline__ void nb_pair(
+    double charge_scale, double lj_scale, double qi, double qj, double sig_i, double sig_j, double eps_i, double eps_j, double d2ij,
+    double beta, PairOut<double> &o, const Tab &tab) {
+    const double qij = qi * qj;
+    const double es_prefactor = charge_scale * qij * es_force_factor(beta, d2ij, tab);
+    const double inv_d2ij = tm_rcp_f64(d2ij);
+    double prefactor = es_prefactor;
+    double u = 0;
+    o.has_lj = (eps_i != 0 && eps_j != 0);
+    o.sig_grad = 0;
+    o.eps_grad = 0;
+    o.inv_dij = 0;
+    o.ebd = 0;
+    if (o.has_lj) {
+        const double eps_ij = eps_i * eps_j;
+        const double sig_ij = sig_i + sig_j;
+        const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
+        const double sig4 = sig2 * sig2;
+        const double sig6 = sig4 * sig2;
+        const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24);
+        prefactor -= lj_prefactor;
+        if constexpr (WANT_U_DP) {
+            u = lj_scale * 4 * eps_ij * (sig6 - 1) * sig6;
+            o.sig_grad = lj_scale * 24 * eps_ij * (sig_ij * sig4 * inv_d2ij) * (2 * sig6 - 1);
+            o.eps_grad = lj_scale * 4 * (sig6 - 1) * sig6;
+        }
+    }
+    if constexpr (WANT_U_DP) {
+        const double inv_dij = tm_rsqrt_f64(d2ij);
+        const double dij = d2ij * inv_dij;
+        double damping;
+        (void)real_es_factor(beta, dij, inv_dij, inv_dij * inv_dij, damping);
+        u += charge_scale * qij * inv_dij * damping;
+        o.inv_dij = inv_dij;
+        o.ebd = damping;
+    }
+    o.prefactor = prefactor;
+    o.u = u;
+}
+// f32: the analytic pair function above, whatever is asked for (the table argument is an empty tag)
+template <bool WANT_U_DP, typename AnyTab>
+__device__ __forceinline__ void nb_pair(
+    float charge_scale, float lj_scale, float qi, float qj, float sig_i, float sig_j, float eps_i, float eps_j, float d2ij, float beta,
+    PairOut<float> &o, const AnyTab &) {
+    nb_pair<float>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2ij, beta, o);
 }
 
 // minimum-image displacement component: delta -= L * nearbyint(delta / L)   (round-half-even, Appendix B.2).

@@ -10,6 +10,8 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <map>
 #include <numeric>
 #include <set>
 
@@ -30,6 +32,88 @@
 #endif
 
 namespace tmamd {
+
+// =============================================================================================================
+// Electrostatic force-factor table (nb_es_table.cuh)
+// =============================================================================================================
+// F(s) continued smoothly through d = 1.2 (no clamp: the kernels select 0 there), in long double
+static long double es_force_factor_reference(const long double beta, const long double s) {
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const long double d = sqrtl(s), inv = 1.0L / d;
+    const long double x = d / 1.2L;
+    const long double x2 = x * x, x4 = x2 * x2, q = x4 * x4;
+    const long double c = cosl(0.5L * pi * q), sn = sinl(0.5L * pi * q);
+    const long double S = c * c * c;
+    const long double d2 = d * d, d4 = d2 * d2, d7 = d4 * d2 * d;
+    const long double k8 = powl(1.0L / 1.2L, 8);
+    const long double dS = -12.0L * pi * k8 * d7 * sn * c * c;
+    const long double e = erfcl(beta * d);
+    const long double de = -2.0L * beta / sqrtl(pi) * expl(-(beta * d) * (beta * d));
+    const long double damp = e * S, dprime = e * dS + de * S;
+    return inv * (dprime * inv - damp * inv * inv);
+}
+
+void es_force_table_host(const double beta, double *out) {
+    const int n = ES_TAB_COEFFS;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int iv = 0; iv < ES_TAB_INTERVALS; iv++) {
+        const int e = ES_TAB_EXP_LO + iv / ES_TAB_PER_OCTAVE, j = iv % ES_TAB_PER_OCTAVE;
+        const long double lo = ldexpl(1.0L + static_cast<long double>(j) / ES_TAB_PER_OCTAVE, e);
+        const long double hi = ldexpl(1.0L + static_cast<long double>(j + 1) / ES_TAB_PER_OCTAVE, e);
+        // interpolation at the Chebyshev nodes of [0, 1] (near-minimax), solved for monomial coefficients in t
+        long double A[ES_TAB_COEFFS][ES_TAB_COEFFS + 1];
+        for (int k = 0; k < n; k++) {
+            const long double t = 0.5L + 0.5L * cosl((2 * k + 1) * pi / (2 * n));
+            long double pw = 1.0L;
+            for (int c = 0; c < n; c++) {
+                A[k][c] = pw;
+                pw *= t;
+            }
+            A[k][n] = es_force_factor_reference(beta, lo + (hi - lo) * t);
+        }
+        for (int c = 0; c < n; c++) { // Gauss-Jordan with partial pivoting (6 x 6, long double)
+            int piv = c;
+            for (int r = c + 1; r < n; r++) {
+                if (fabsl(A[r][c]) > fabsl(A[piv][c])) {
+                    piv = r;
+                }
+            }
+            for (int k = 0; k <= n; k++) {
+                std::swap(A[c][k], A[piv][k]);
+            }
+            for (int r = 0; r < n; r++) {
+                if (r != c) {
+                    const long double f = A[r][c] / A[c][c];
+                    for (int k = c; k <= n; k++) {
+                        A[r][k] -= f * A[c][k];
+                    }
+                }
+            }
+        }
+        for (int c = 0; c < n; c++) {
+            out[iv * n + c] = static_cast<double>(A[c][n] / A[c][c]);
+        }
+    }
+}
+
+const double *es_force_table_device(const double beta) {
+    // one table per (device, beta), kept for the life of the process: potentials of one state share it
+    static std::map<std::pair<int, double>, double *> cache;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const auto key = std::make_pair(dev, beta);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        return it->second;
+    }
+    std::vector<double> host(ES_TAB_DOUBLES);
+    es_force_table_host(beta, host.data());
+    double *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, ES_TAB_DOUBLES * sizeof(double)));
+    HIP_CHECK(hipMemcpy(d, host.data(), ES_TAB_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
+    cache[key] = d;
+    return d;
+}
 
 static const int STEPS_PER_SORT = 100;       // reference: cpp/src/nonbonded_all_pairs.cu:16
 static const int STEPS_PER_SORT_GROUP = 200; // reference: cpp/src/nonbonded_interaction_group.cu:17
@@ -438,6 +522,9 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::allocate() {
+    if (sizeof(Real) == 8) {
+        d_es_table_ = es_force_table_device(beta_);
+    }
     d_atom_idxs_.realloc(N_);
     d_perm_.realloc(N_);
     d_gathered_.realloc(static_cast<size_t>(N_ + 1) * 8); // + one all-zero sentinel record
@@ -611,7 +698,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     k_nonbonded_tiles<Real, U, X, PP><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
-        d_box, beta_, cutoff_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, piggyback_acc_, piggyback_atom_stride_, piggyback_comp_stride_, \
+        d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, piggyback_acc_, piggyback_atom_stride_, piggyback_comp_stride_, \
         d_timing_.data)
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
     int launched_waves = 0; // waves of this launch = energy partials it writes
@@ -765,6 +852,9 @@ NonbondedPairList<Real, Negated>::NonbondedPairList(
         throw std::runtime_error(
             "expected same number of pairs and scale tuples, but got " + std::to_string(M_) + " != " + std::to_string(scales.size() / 2));
     }
+    if (sizeof(Real) == 8) {
+        d_es_table_ = es_force_table_device(beta_);
+    }
     d_pair_idxs_.realloc(M_ * 2);
     d_scales_.realloc(M_ * 2);
     if (M_ > 0) {
@@ -779,7 +869,7 @@ void NonbondedPairList<Real, Negated>::plan_forces(const int N, const int P, con
     if (M_ > 0) {
         plan.add_segment(
             sizeof(Real),
-            FusedSegment{Negated ? FUSED_PAIR_LIST_NEGATED : FUSED_PAIR_LIST, M_, d_pair_idxs_.data, d_p, d_scales_.data, beta_, cutoff_},
+            FusedSegment{Negated ? FUSED_PAIR_LIST_NEGATED : FUSED_PAIR_LIST, M_, d_pair_idxs_.data, d_p, d_scales_.data, beta_, cutoff_, nullptr, d_es_table_},
             this, P, d_p);
     }
 }
@@ -792,7 +882,7 @@ void NonbondedPairList<Real, Negated>::execute_device(
         const int tpb = 256;
         const int blocks = ceil_divide(M_, tpb);
         k_nonbonded_pair_list<Real, Negated><<<blocks, tpb, 0, stream>>>(
-            M_, d_x, d_p, d_box, d_pair_idxs_.data, d_scales_.data, beta_, cutoff_, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
+            M_, d_x, d_p, d_box, d_pair_idxs_.data, d_scales_.data, beta_, cutoff_, d_es_table_, d_du_dx, d_du_dp, d_u ? d_u_partials_.data : nullptr);
         HIP_CHECK(hipGetLastError());
         if (d_u) {
             reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);

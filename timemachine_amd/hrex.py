@@ -37,7 +37,15 @@ def run_neighbor_swaps(replica_idx_by_state, pairs, log_q_kl, pair_idxs, uniform
     """A batch of neighbour-swap Metropolis moves on the state -> replica permutation (md/hrex.py:51-130).
 
     log_q_kl[r, s] = log unnormalised probability of replica r in state s (-inf = not evaluated: never accepted).
-    Returns (replica_idx_by_state, proposed[n_pairs], accepted[n_pairs])."""
+    Returns (replica_idx_by_state, proposed[n_pairs], accepted[n_pairs]).  Runs in the native library
+    (tm_hrex_run_neighbor_swaps); `run_neighbor_swaps_python` below is the same chain spelled out in numpy."""
+    from .lib import custom_ops
+
+    return custom_ops.hrex_run_neighbor_swaps(replica_idx_by_state, pairs, log_q_kl, pair_idxs, uniform_samples)
+
+
+def run_neighbor_swaps_python(replica_idx_by_state, pairs, log_q_kl, pair_idxs, uniform_samples):
+    """The chain of `run_neighbor_swaps`, statement by statement as md/hrex.py:91-121 has it (tests compare the two)."""
     perm = np.array(replica_idx_by_state, dtype=np.int64)
     pairs = np.asarray(pairs, dtype=np.int64)
     log_q_kl = np.asarray(log_q_kl, dtype=np.float64)
@@ -129,7 +137,7 @@ class DistributedHREX:
     def exchange(self, local_rows: np.ndarray, seed: int):
         """local_rows [len(local_replicas), n_states]: energies (kJ/mol) of this rank's replicas, np.inf where not
         evaluated.  Returns the new state index of each local replica."""
-        U_kl = parallel.gather_rows(self.local_replicas, local_rows, self.n_states)
+        U_kl = parallel.gather_rows(self.local_replicas, local_rows, self.n_states, row_length=self.n_states)
         U_kl = verify_and_sanitize_potential_matrix(U_kl, self.replica_idx_by_state)
         log_q_kl = -U_kl / self.kT
         self.replica_idx_by_state_by_iter.append(self.replica_idx_by_state.tolist())

@@ -736,6 +736,12 @@ class Context:
     def finalize(self):
         _check(_lib.tm_context_finalize(self._h))
 
+    def last_multiple_steps_ms(self):
+        """measurement aid (not in the reference surface): device time of the steps of the last multiple_steps call"""
+        ms = _c_double(0)
+        _check(_lib.tm_context_last_multiple_steps_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def multiple_steps(self, n_steps, store_x_interval=0):
         """-> (xs[F,N,3], boxes[F,3,3]), F = n_steps // (store_x_interval or n_steps); wrap_kernels.cpp:347-369."""
         if store_x_interval < 0:
@@ -893,6 +899,31 @@ def hilbert_lut():
     out = np.zeros(128 * 128 * 128, dtype=np.uint32)
     _check(_lib.tm_hilbert_lut(_ptr(out)))
     return out
+
+
+def es_force_table(beta):
+    """Host-only: [256, 6] polynomial coefficients of the f64 kernels' electrostatic force factor F(d^2) (nb_es_table.cuh)."""
+    out = np.zeros((256, 6), dtype=np.float64)
+    _check(_lib.tm_es_force_table(_c_double(float(beta)), _ptr(out)))
+    return out
+
+
+def hrex_run_neighbor_swaps(replica_idx_by_state, neighbor_pairs, log_q_kl, pair_idxs, uniform_samples):
+    """The swap chain of one HREX exchange step, in native code (timemachine/md/hrex.py:50-130 is a jitted lax.scan; a
+    Python loop over n_states**3 attempts costs 25 ms at 24 states).  -> (replica_idx_by_state, proposed, accepted)"""
+    perm = np.ascontiguousarray(replica_idx_by_state, dtype=np.int64)
+    pairs = np.ascontiguousarray(neighbor_pairs, dtype=np.int64).reshape(-1, 2)
+    log_q = np.ascontiguousarray(log_q_kl, dtype=np.float64)
+    idx = np.ascontiguousarray(pair_idxs, dtype=np.int64).reshape(-1)
+    uni = np.ascontiguousarray(uniform_samples, dtype=np.float64).reshape(-1)
+    if log_q.ndim != 2 or log_q.shape[1] != perm.size or idx.size != uni.size:
+        raise RuntimeError("run_neighbor_swaps: inconsistent shapes")
+    out = np.zeros(perm.size, dtype=np.int64)
+    proposed, accepted = np.zeros(len(pairs), dtype=np.uint32), np.zeros(len(pairs), dtype=np.uint32)
+    _check(_lib.tm_hrex_run_neighbor_swaps(
+        _c_int(log_q.shape[0]), _c_int(perm.size), _ptr(perm), _c_int(len(pairs)), _ptr(pairs), _ptr(log_q), _c_int(idx.size), _ptr(idx),
+        _ptr(uni), _ptr(out), _ptr(proposed), _ptr(accepted)))
+    return out, proposed, accepted
 
 
 def debug_float_to_fixed(values, precision, kind=0):

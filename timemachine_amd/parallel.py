@@ -5,7 +5,7 @@ with CUDA_VISIBLE_DEVICES and returns results by pickle (timemachine/parallel/cl
 sharded over the ranks of a torch.distributed job (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" on CPU) and
 the only inter-GPU traffic is the final gather of reduced potentials u[k, l] (a few KB): coordinates never move.
 """
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -15,57 +15,88 @@ def windows_for_rank(n_windows: int, world_size: int, rank: int) -> List[int]:
     return [k for k in range(n_windows) if k % world_size == rank]
 
 
-def gather_rows(local_windows: Sequence[int], local_rows: np.ndarray, n_windows: int) -> np.ndarray:
-    """All ranks contribute rows u[k, :] for their windows k; every rank returns the full [n_windows, L] matrix.
-    Uses all_gather on a padded buffer (RCCL all_gather over xGMI on GPUs; latency-bound at these sizes)."""
-    import torch
+def _dist():
     import torch.distributed as dist
 
-    local_rows = np.asarray(local_rows, dtype=np.float64).reshape(len(local_windows), -1)
-    L = local_rows.shape[1] if len(local_windows) else 0
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def _device(dist):
+    import torch
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_rows(local_windows: Sequence[int], local_rows: np.ndarray, n_windows: int, row_length: Optional[int] = None) -> np.ndarray:
+    """All ranks contribute rows u[k, :] for their windows k; every rank returns the full [n_windows, L] matrix.
+
+    ONE collective per call when the row length is known (``row_length``, or any rank-local row to read it from and the
+    round-robin placement of ``windows_for_rank``): an all_gather of a [ceil(n_windows / world), 1 + L] f64 block per rank
+    (RCCL over xGMI on GPUs; a 24 x 24 matrix is 4.8 KB -- latency-bound).  The block is filled with one host-side numpy
+    assignment and one host-to-device copy.  Ranks that cannot know L (no rows, no ``row_length``) trigger a small
+    extra all_gather of (L, count) first -- every rank must then take the same branch, so pass ``row_length`` whenever
+    some rank may be empty."""
+    import torch
+
+    local_windows = [int(k) for k in local_windows]
+    local_rows = np.asarray(local_rows, dtype=np.float64)
+    if row_length is not None:
+        L = int(row_length)
+    else:
+        L = int(local_rows.reshape(len(local_windows), -1).shape[1]) if len(local_windows) else -1
+    dist = _dist()
+    if dist is None:
+        L = max(L, 0)
         out = np.full((n_windows, L), np.nan)
-        out[list(local_windows)] = local_rows
+        out[local_windows] = local_rows.reshape(len(local_windows), L)
         return out
     world = dist.get_world_size()
-    use_cuda = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
-    # agree on L and on the per-rank capacity
-    meta = torch.tensor([L, len(local_windows)], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    L = int(max(m[0].item() for m in metas))
-    cap = int(max(m[1].item() for m in metas))
-    buf = torch.full((cap, L + 1), float("nan"), dtype=torch.float64, device=dev)
-    for r, (k, row) in enumerate(zip(local_windows, local_rows)):
-        buf[r, 0] = float(k)
-        buf[r, 1:] = torch.as_tensor(row, dtype=torch.float64, device=dev)
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
+    dev = _device(dist)
+    cap = -(-n_windows // world)
+    if row_length is None:
+        # agree on L and on the per-rank capacity (a rank without rows does not know L; placement may not be round-robin)
+        meta = torch.tensor([L, len(local_windows)], dtype=torch.int64, device=dev)
+        metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta)
+        metas = metas.cpu().numpy().reshape(world, 2)
+        L = int(metas[:, 0].max())
+        cap = max(cap, int(metas[:, 1].max()))
+    block = np.full((cap, 1 + L), np.nan)
+    block[: len(local_windows), 0] = local_windows
+    block[: len(local_windows), 1:] = local_rows.reshape(len(local_windows), L)
+    mine = torch.from_numpy(block).to(dev)
+    everyone = torch.empty((world * cap, 1 + L), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(everyone, mine)
+    everyone = everyone.cpu().numpy()
+    filled = np.isfinite(everyone[:, 0])
     out = np.full((n_windows, L), np.nan)
-    for b in bufs:
-        b = b.cpu().numpy()
-        for row in b:
-            if np.isfinite(row[0]):
-                out[int(row[0])] = row[1:]
+    out[everyone[filled, 0].astype(np.int64)] = everyone[filled, 1:]
     return out
 
 
 def max_over_ranks(value: float) -> float:
     import torch
-    import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    dist = _dist()
+    if dist is None:
         return value
-    use_cuda = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
-    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    t = torch.tensor([value], dtype=torch.float64, device=_device(dist))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def barrier():
-    import torch.distributed as dist
+def sum_over_ranks(value: float) -> float:
+    import torch
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist = _dist()
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def barrier():
+    dist = _dist()
+    if dist is not None:
         dist.barrier()
