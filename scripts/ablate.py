@@ -93,5 +93,24 @@ def driver():
         subprocess.run([sys.executable, __file__, "worker"], env=env)
 
 
+def make_frame():
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+    s = ts.dhfr_sized_water_box()
+    x, v = s.coords.copy(), np.zeros_like(s.coords)
+    for dt, friction, steps in ((0.1e-3, 100.0, 600), (0.5e-3, 50.0, 600), (1.0e-3, 10.0, 800), (2.5e-3, 1.0, 1000)):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+        ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, dt, friction, s.masses, 1).impl(), bps)
+        ctxt.multiple_steps(steps, 0)
+        x, v = ctxt.get_x_t(), ctxt.get_v_t()
+    np.save(FRAME, x)
+
+
 if __name__ == "__main__":
-    worker() if len(sys.argv) > 1 else driver()
+    if len(sys.argv) > 1 and sys.argv[1] == "frame":
+        make_frame()
+    elif len(sys.argv) > 1:
+        worker()
+    else:
+        driver()

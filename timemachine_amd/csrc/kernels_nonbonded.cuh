@@ -236,7 +236,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         u64 pi[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? TILE : 1];
         u64 pj[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? NB_CHUNK : 1];
         unsigned int rowatom[TILE];
-        unsigned short queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // up to 4 rounds are appended between drains
+        unsigned short queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // <= 63 left over in either queue + up to 4 rounds appended between drains
     };
     __shared__ WaveLds s_wave[WAVES];
     __shared__ unsigned int s_ticket; // next position of this workgroup's pool
@@ -571,10 +571,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                const unsigned short entry = static_cast<unsigned short>((ri[k] << 8) | lane);
                 const u64 mask = __ballot(hit[k]);
                 if (hit[k]) {
                     const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-                    s_queue[pos] = static_cast<unsigned short>((ri[k] << 8) | lane);
+                    s_queue[pos] = entry;
                 }
                 cnt += __popcll(mask);
             }
@@ -583,13 +584,14 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #endif
             // ---- phase 2: drain full batches (and everything after the last rounds)
             const bool last = round0 == TILE - 4;
-            while (cnt >= NB_CHUNK || (last && cnt > 0)) {
-                TM_T(t_h0);
-                const int n = cnt < NB_CHUNK ? cnt : NB_CHUNK;
-                const int base = cnt - n;
-                wave_lds_sync();
-                if (lane < n) {
-                    const unsigned int e = s_queue[base + lane];
+            // one batch: lane `lane` (if active) takes the pair queued at `slot`.
+            // (Measured and dropped: queueing the pairs without a Lennard-Jones term -- 8 of 9 in water -- apart from the
+            // others, so that their batches neither read sigma / epsilon nor run the LJ code: one more partial batch per item
+            // and two ballots per round cost more than that saved, 82 us against 72 us per launch.  Two pairs per lane per
+            // trip with branch-free code, for instruction-level parallelism: 81 us.)
+            auto pair_batch = [&](const bool active, const int slot) {
+                if (active) {
+                    const unsigned int e = s_queue[slot];
                     const int pi = e >> 8, pj = e & 0xff;
                     Real ddx = s_row[0][pi] - s_col[0][pj], ddy = s_row[1][pi] - s_col[1][pj], ddz = s_row[2][pi] - s_col[2][pj];
                     if (!raw_compact) { // wave-uniform; for a compact tile the three rint / fma pairs are exact no-ops
@@ -597,40 +599,29 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                         ddy = min_image(ddy, bx.y, bx.inv_y);
                         ddz = min_image(ddz, bx.z, bx.inv_z);
                     }
+                    // (skipping this read and the fma below it for items whose w are all equal -- every item of a
+                    // non-alchemical system -- measured 4 us SLOWER per launch: the wave-uniform branch costs more than two reads)
                     const Real ddw = s_row[3][pi] - s_col[3][pj];
                     const Real dd2 = pair_d2(ddx, ddy, ddz, ddw);
                     if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
                     const Real qi = s_row[4][pi], qj = s_col[4][pj];
-                    const Real eps_i = s_row[6][pi], eps_j = s_col[6][pj];
+                    const Real sig_i = s_row[5][pi], sig_j = s_col[5][pj], eps_i = s_row[6][pi], eps_j = s_col[6][pj];
                     PairOut<Real> o;
 #if defined(TM_ABLATE) && TM_ABLATE == 4
                     o.prefactor = dd2 * qi; o.u = qj; o.inv_dij = qi; o.ebd = qj; o.sig_grad = 0; o.eps_grad = 0; o.has_lj = false; // ablation: no math
-#elif defined(TM_ABLATE) && TM_ABLATE == 5
-                    nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o, EsTableConst{}); // ablation: no table reads
 #else
-                    nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, s_row[5][pi], s_col[5][pj], eps_i, eps_j, dd2, beta, o, es_tab);
+                    nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
 #endif
-#if defined(TM_ABLATE) && TM_ABLATE == 2
-                    if (o.prefactor == static_cast<Real>(1.2345e-30)) { energy += 1; } // ablation: math, no accumulation
-#else
                     if constexpr (COMPUTE_DU_DX) {
                         u64 fx, fy, fz;
                         pair_force_fixed(o.prefactor, ddx, ddy, ddz, fx, fy, fz);
-#if defined(TM_ABLATE) && TM_ABLATE == 6
-                        const int ai = lane & 31, aj = lane; // ablation: the six LDS atomics without any address conflict
-#elif defined(TM_ABLATE) && TM_ABLATE == 7
-                        const int ai = pi, aj = lane; // ablation: conflict-free column atomics only
-#else
-                        const int ai = pi, aj = pj;
-#endif
-                        lds_add(&s_fi[0][ai], fx);
-                        lds_add(&s_fi[1][ai], fy);
-                        lds_add(&s_fi[2][ai], fz);
-                        lds_sub(&s_fj[0][aj], fx); // FIX(-p d) == -FIX(p d)
-                        lds_sub(&s_fj[1][aj], fy);
-                        lds_sub(&s_fj[2][aj], fz);
+                        lds_add(&s_fi[0][pi], fx);
+                        lds_add(&s_fi[1][pi], fy);
+                        lds_add(&s_fi[2][pi], fz);
+                        lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
+                        lds_sub(&s_fj[1][pj], fy);
+                        lds_sub(&s_fj[2][pj], fz);
                     }
-#endif
                     if constexpr (COMPUTE_DU_DP) {
                         lds_add(&s_pi[0][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qj * o.inv_dij * o.ebd));
                         lds_add(&s_pj[0][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qi * o.inv_dij * o.ebd));
@@ -650,6 +641,13 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     }
                     } // exact cutoff test
                 }
+            };
+            while (cnt >= NB_CHUNK || (last && cnt > 0)) {
+                TM_T(t_h0);
+                const int n = cnt < NB_CHUNK ? cnt : NB_CHUNK;
+                const int base = cnt - n;
+                wave_lds_sync();
+                pair_batch(lane < n, base + lane);
                 cnt = base;
 #ifdef TM_TIMING
                 wave_lds_sync();

@@ -169,8 +169,17 @@ struct EsTableConst { // ablation builds only: no memory access at all
 };
 struct EsTableNone {}; // f32 kernels: analytic A&S erfc + hardware exp / sincos, no table
 
-// F(d2) such that the electrostatic force prefactor of a pair is charge_scale * q_i q_j * F(d2)
-template <typename Tab> __device__ __forceinline__ double es_force_factor(const double beta, const double d2, const Tab &tab) {
+// the analytic form for d2 below the table (clashing atoms).  Deliberately NOT inlined: its ~60 polynomial coefficients
+// would otherwise be hoisted out of the callers' hot loops and sit in registers there for good.
+__device__ __attribute__((noinline, cold)) double es_force_factor_below_table(const double beta, const double d2) {
+    const double inv = tm_rsqrt_f64(d2);
+    double damping;
+    return inv * real_es_factor(beta, d2 * inv, inv, inv * inv, damping);
+}
+
+// F(d2) such that the electrostatic force prefactor of a pair is charge_scale * q_i q_j * F(d2): the table part, without a
+// branch.  `below` says that d2 lies under the table (the caller owes the analytic form; the value returned is then 0).
+template <typename Tab> __device__ __forceinline__ double es_force_factor_table(const double d2, const Tab &tab, bool &below) {
     double t;
     unsigned int idx = es_tab_index(d2, t);
     const bool outside = idx >= static_cast<unsigned int>(ES_TAB_INTERVALS); // d2 < 2^-7 or d2 >= 2 (or NaN)
@@ -183,17 +192,39 @@ template <typename Tab> __device__ __forceinline__ double es_force_factor(const 
     p = __builtin_fma(p, t, c[1]);
     p = __builtin_fma(p, t, c[0]);
     const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
-    double f = (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+    below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
+    return (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+}
+
+template <typename Tab> __device__ __forceinline__ double es_force_factor(const double beta, const double d2, const Tab &tab) {
+    bool below;
+    double f = es_force_factor_table(d2, tab, below);
     // below the table: clashing atoms (d < 0.088 nm) only -- the analytic form, behind a wave-uniform branch
-    const bool below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
     if (__ballot(below) != 0ull) {
         if (below) {
-            const double inv = tm_rsqrt_f64(d2);
-            double damping;
-            f = inv * real_es_factor(beta, d2 * inv, inv, inv * inv, damping);
+            f = es_force_factor_below_table(beta, d2);
         }
     }
     return f;
+}
+
+// The branch-free core of the forces-only f64 pair function (see nb_pair<false> below: the same operations in the same
+// order, with selects where that one branches).  `below`: the electrostatic part still needs the analytic form.
+template <typename Tab>
+__device__ __forceinline__ double nb_pair_prefactor_nobranch(
+    const double qi, const double qj, const double sig_i, const double sig_j, const double eps_i, const double eps_j, const double d2ij,
+    const Tab &tab, bool &below) {
+    const double qij = qi * qj;
+    const double es_prefactor = qij * es_force_factor_table(d2ij, tab, below); // charge_scale == 1: 1 * qij is qij, bit for bit
+    const double inv_d2ij = tm_rcp_f64(d2ij);
+    const bool has_lj = (eps_i != 0 && eps_j != 0);
+    const double eps_ij = eps_i * eps_j;
+    const double sig_ij = sig_i + sig_j;
+    const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
+    const double sig4 = sig2 * sig2;
+    const double sig6 = sig4 * sig2;
+    const double lj_prefactor = eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24); // lj_scale == 1
+    return has_lj ? es_prefactor - lj_prefactor : es_prefactor;
 }
 
 // The f64 pair function.  WANT_U_DP = false (MD: forces only) never forms 1/d, erfc, exp or the switch function:
@@ -262,20 +293,27 @@ __device__ __forceinline__ float min_image(float delta, float box, float inv_box
 // Scaling by 2^36 is exact, so llrint((p * 2^36) * d) == llrint((p * d) * 2^36) bit for bit: one multiply by 2^36 per
 // pair instead of one per component; and llrint is odd, so g_j is the two's-complement negation of g_i (callers use
 // an integer subtract / LDS ds_sub for it) -- three conversions per pair instead of six.
-__device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
+__device__ __forceinline__ void pair_force_fixed_fast(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz, bool &big) {
     const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
     const double a = ps * dx, b = ps * dy, c = ps * dz;
     fx = static_cast<u64>(real_to_int64_fast(a));
     fy = static_cast<u64>(real_to_int64_fast(b));
     fz = static_cast<u64>(real_to_int64_fast(c));
+    big = !(__builtin_fabs(a) < TM_FIXED_FAST_LIMIT && __builtin_fabs(b) < TM_FIXED_FAST_LIMIT && __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
+}
+__device__ __forceinline__ void pair_force_fixed_slow(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
+    const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
+    fx = static_cast<u64>(llrint(ps * dx));
+    fy = static_cast<u64>(llrint(ps * dy));
+    fz = static_cast<u64>(llrint(ps * dz));
+}
+__device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
+    bool big;
+    pair_force_fixed_fast(prefactor, dx, dy, dz, fx, fy, fz, big);
     // one wave-uniform escape for all three components (see real_to_int64)
-    const bool big = !(__builtin_fabs(a) < TM_FIXED_FAST_LIMIT && __builtin_fabs(b) < TM_FIXED_FAST_LIMIT &&
-                       __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
     if (__ballot(big) != 0ull) {
         if (big) {
-            fx = static_cast<u64>(llrint(a));
-            fy = static_cast<u64>(llrint(b));
-            fz = static_cast<u64>(llrint(c));
+            pair_force_fixed_slow(prefactor, dx, dy, dz, fx, fy, fz);
         }
     }
 }
