@@ -72,6 +72,41 @@ template <typename Real, bool DU_DP> struct TileShape {
 // LDS traffic of the tile kernel is private to a wave: program order plus a compiler fence is all the synchronisation
 // there is (LDS serves one wave's requests in order).  Never a workgroup barrier -- the waves of a workgroup are at
 // unrelated points of unrelated items.
+#ifndef TM_LDS_SINGLE_READS
+#define TM_LDS_SINGLE_READS 1
+#endif
+// byte offset of an LDS object inside the workgroup's allocation
+template <typename T> __device__ __forceinline__ unsigned int lds_offset(const T *p) {
+    return static_cast<unsigned int>(reinterpret_cast<unsigned long>((__attribute__((address_space(3))) const void *)p));
+}
+// one ds_read_b64, issued and NOT waited for: the value is valid only after lds_wait14() on it
+template <int OFFSET> __device__ __forceinline__ double lds_read_f64_async(const unsigned int byte_offset) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_offset), "n"(OFFSET));
+    return v;
+}
+template <int C, int ROW_STRIDE, int COL_STRIDE> __device__ __forceinline__ void lds_read14(const unsigned int ra, const unsigned int ca, double (&ri)[7], double (&cj)[7]) {
+    if constexpr (C < 7) {
+        ri[C] = lds_read_f64_async<C * ROW_STRIDE>(ra);
+        cj[C] = lds_read_f64_async<C * COL_STRIDE>(ca);
+        lds_read14<C + 1, ROW_STRIDE, COL_STRIDE>(ra, ca, ri, cj);
+    }
+}
+template <int C, int ROW_STRIDE, int COL_STRIDE> __device__ __forceinline__ void lds_read14(const unsigned int, const unsigned int, float (&)[7], float (&)[7]) {}
+// waits for every outstanding LDS operation of the wave; the values pass through the statement so that no use of them can
+// be scheduled in front of it
+__device__ __forceinline__ void lds_wait14(double (&a)[7], double (&b)[7]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
+                   "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+}
+__device__ __forceinline__ void lds_wait14(float (&)[7], float (&)[7]) {}
+// one lane step to the left through the whole wave: lane l receives lane l + 1's value, lane 63 lane 0's (DPP wave_rol:1, a
+// VALU move: no LDS).  All 64 lanes must be enabled.  scripts/microbench/dpp_rotate.hip prints the mapping on the device.
+__device__ __forceinline__ float wave_rol1(const float v) {
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134, 0xf, 0xf, true));
+}
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -228,7 +263,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 
     constexpr int WAVES = TileShape<Real, COMPUTE_DU_DP>::waves;
     struct WaveLds { // one wave's private scratch
-        float4 rowf[TILE]; // phase-1 copy of the row atoms: (x, y, z, w) relative to the tile origin, f32
         Real row[7][TILE];
         Real col[7][NB_CHUNK];
         u64 fi[COMPUTE_DU_DX ? 3 : 1][COMPUTE_DU_DX ? TILE : 1]; // outputs that are not asked for take 8 bytes, not a row
@@ -247,7 +281,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const unsigned int global_wave = blockIdx.x * WAVES + wave, total_waves = gridDim.x * WAVES;
     WaveLds &lds = s_wave[wave];
-    auto &s_rowf = lds.rowf;
     auto &s_row = lds.row;
     auto &s_col = lds.col;
     auto &s_fi = lds.fi;
@@ -428,7 +461,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         const int rb = cur.rb;
         const unsigned int ja = cur.ja;
         wave_lds_sync(); // previous item's flush has finished reading LDS
-        float4 s_rowf_mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // lanes 0-31: this lane's row atom, as stored in s_rowf
+        float4 s_rowf_mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // lanes 0-31: this lane's row atom as phase 1 sees it
         TM_T(t_a2);
         if (lane < TILE) {
             s_rowatom[lane] = cur.ra;
@@ -441,7 +474,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             rf.y = static_cast<float>(min_image(cur.rr[1] - cur.oy, bx.y, bx.inv_y));
             rf.z = static_cast<float>(min_image(cur.rr[2] - cur.oz, bx.z, bx.inv_z));
             rf.w = cur.ra < uK ? static_cast<float>(cur.rr[3]) : 1e18f; // invalid row: never passes the filter
-            s_rowf[lane] = rf;
             s_rowf_mine = rf;
             if constexpr (COMPUTE_DU_DX) {
                 s_fi[0][lane] = 0;
@@ -512,6 +544,12 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         long long tm_p2_item = 0;
 #endif
         int cnt = 0; // wave-uniform number of queued pairs
+        // both halves of the wave start with row (lane & 31) in hand (the upper half gets its copy from the lower)
+        float4 rot;
+        rot.x = __shfl(s_rowf_mine.x, lane & (TILE - 1), 64);
+        rot.y = __shfl(s_rowf_mine.y, lane & (TILE - 1), 64);
+        rot.z = __shfl(s_rowf_mine.z, lane & (TILE - 1), 64);
+        rot.w = __shfl(s_rowf_mine.w, lane & (TILE - 1), 64);
         // measured (ns/day, f64 / f32): drawn at round 0: 2145 / 2900; 16: 2175 / 2905; 24: 2190 / 2897; 28: 2207 / 2925;
         // after the last round (descriptor load exposed): 2190 / 2965
 #ifdef TM_TICKET_ROUND
@@ -527,13 +565,20 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     it_next = items[item_next];
                 }
             }
-            // ---- phase 1: four conservative f32 distance filters per lane (four independent LDS reads in flight)
+            // ---- phase 1: four conservative f32 distance filters per lane.  The row a lane meets in round r is row
+            // (r + lane) & 31: its filter copy arrives by rotation -- `rot` moves one lane to the left per round (four DPP
+            // wave_rol:1 moves, VALU) -- not by an LDS read: the LDS pipe is what binds this kernel (rocprofv3 PMC: LDS array
+            // busy ~70 % of the launch, VALU ~50 %), and 32 ds_read_b128 per item were 8 % of its load.
             float4 rf[4];
             int ri[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 ri[k] = (round0 + k + lane) & (TILE - 1);
-                rf[k] = s_rowf[ri[k]];
+                rf[k] = rot;
+                rot.x = wave_rol1(rot.x);
+                rot.y = wave_rol1(rot.y);
+                rot.z = wave_rol1(rot.z);
+                rot.w = wave_rol1(rot.w);
             }
             bool hit[4];
             auto filter4 = [&](auto wrap, auto ordered) {
@@ -593,7 +638,22 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 if (active) {
                     const unsigned int e = s_queue[slot];
                     const int pi = e >> 8, pj = e & 0xff;
-                    Real ddx = s_row[0][pi] - s_col[0][pj], ddy = s_row[1][pi] - s_col[1][pj], ddz = s_row[2][pi] - s_col[2][pj];
+                    Real ri[7], cj[7]; // x, y, z, w, q, sig, eps of the pair's row / column atom
+                    if constexpr (sizeof(Real) == 8 && TM_LDS_SINGLE_READS) {
+                        // fourteen single ds_read_b64 (2 LDS cycles each; row reads are conflict free: 32 rows = 64 banks).  Left
+                        // to itself the compiler pairs them into ds_read2_b64, which the LDS serves at half that rate
+                        // (MI355X_MICROARCH.md, LDS table: 8 cycles per wave instruction against 2 + 2).
+                        const unsigned int ra = lds_offset(&s_row[0][pi]), ca = lds_offset(&s_col[0][pj]);
+                        lds_read14<0, TILE * 8, NB_CHUNK * 8>(ra, ca, ri, cj);
+                        lds_wait14(ri, cj);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 7; c++) {
+                            ri[c] = s_row[c][pi];
+                            cj[c] = s_col[c][pj];
+                        }
+                    }
+                    Real ddx = ri[0] - cj[0], ddy = ri[1] - cj[1], ddz = ri[2] - cj[2];
                     if (!raw_compact) { // wave-uniform; for a compact tile the three rint / fma pairs are exact no-ops
                         ddx = min_image(ddx, bx.x, bx.inv_x);
                         ddy = min_image(ddy, bx.y, bx.inv_y);
@@ -601,11 +661,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     }
                     // (skipping this read and the fma below it for items whose w are all equal -- every item of a
                     // non-alchemical system -- measured 4 us SLOWER per launch: the wave-uniform branch costs more than two reads)
-                    const Real ddw = s_row[3][pi] - s_col[3][pj];
+                    const Real ddw = ri[3] - cj[3];
                     const Real dd2 = pair_d2(ddx, ddy, ddz, ddw);
                     if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
-                    const Real qi = s_row[4][pi], qj = s_col[4][pj];
-                    const Real sig_i = s_row[5][pi], sig_j = s_col[5][pj], eps_i = s_row[6][pi], eps_j = s_col[6][pj];
+                    const Real qi = ri[4], qj = cj[4];
+                    const Real sig_i = ri[5], sig_j = cj[5], eps_i = ri[6], eps_j = cj[6];
                     PairOut<Real> o;
 #if defined(TM_ABLATE) && TM_ABLATE == 4
                     o.prefactor = dd2 * qi; o.u = qj; o.inv_dij = qi; o.ebd = qj; o.sig_grad = 0; o.eps_grad = 0; o.has_lj = false; // ablation: no math
