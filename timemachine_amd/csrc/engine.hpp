@@ -68,6 +68,15 @@ struct PregatherTarget {
     int *flag_clear = nullptr;      // flag of the call that has just been consumed
     u64 *g_du_dx = nullptr;         // the accumulator handed over in DeferredForces (to be zeroed slot by slot)
     int stride = 0;                 // its component stride
+    // "Sorted" hand-over (sorted_n > 0: every one of the sorted_n atoms has a slot, the list is the plain upper-triangular
+    // one): the consumer may walk the SLOTS in order (atom = perm[slot]; accumulator reads and record writes coalesced) and
+    // then also leaves behind what the producer's block-bounds kernel would have computed on a rebuild step -- the 32-atom
+    // blocks' bounding boxes, every step (two per wave, a handful of shuffles) -- and resets the neighbor-list counters
+    // whenever it raises the rebuild flag.  The producer then launches no bounds kernel at all on MD steps.
+    const unsigned int *perm = nullptr;
+    int sorted_n = 0;
+    void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(sorted_n / 32)][3]
+    unsigned int *nbl_counters = nullptr;        // kernels_nonbonded.cuh: NB_NUM_COUNTERS words
 };
 class Potential;
 struct DeferredForces {
@@ -129,7 +138,7 @@ public:
 
     // The consumer of DeferredForces has enqueued (on the same stream) a kernel that filled `next` for the coordinates
     // in d_x / d_box: the following execute_forces_deferred call with the same pointers may skip its gather.
-    virtual void pregather_committed(const double *d_x, const double *d_box) {}
+    virtual void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) {}
     // Anything a potential remembers about its inputs between calls (pre-gathered positions) is dropped.  Called when
     // coordinates, box or parameters change behind an unchanged pointer (set_params, Context::set_x_t, movers).
     virtual void invalidate_cached_inputs() {}
@@ -365,7 +374,10 @@ public:
     // `cost_cutoff` (<= cutoff) is the distance the work items' cost estimates count pairs within.
     void build_device(
         const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
-        const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream);
+        const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream,
+        // bounds_done: the column-block bounds are current and the counters have been reset with the flag by somebody else
+        // (PregatherTarget's sorted hand-over): no bounds kernel is launched, the list kernel takes the snapshot itself
+        const bool bounds_done = false);
 
     int get_num_row_idxs() const { return NR_; }
     int num_row_blocks() const { return ceil_divide(NR_, TILE); }
@@ -376,6 +388,9 @@ public:
 
     const unsigned int *row_idxs_or_null() const { return upper_triangular() ? nullptr : d_row_idxs_.data; }
     const unsigned int *d_counters() const { return d_counters_.data; }
+    unsigned int *d_counters_rw() { return d_counters_.data; }
+    Real *d_col_ctr() { return d_col_ctr_.data; }
+    Real *d_col_ext() { return d_col_ext_.data; }
     const int4 *d_items() const { return d_items_.data; }
     unsigned int items_cap() const { return static_cast<unsigned int>(items_cap_); }
     const unsigned int *d_col_atoms() const { return d_col_atoms_.data; }
@@ -413,7 +428,7 @@ public:
     int get_num_atom_idxs() const { return K_; }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
-    void pregather_committed(const double *d_x, const double *d_box) override;
+    void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
@@ -458,6 +473,7 @@ protected:
     // positions pre-gathered by the consumer of the last deferred call (see PregatherTarget): valid for exactly these
     // input pointers, dropped by any other call into the pipeline
     bool pre_valid_ = false;
+    bool pre_sorted_ = false; // the consumer also left the block bounds done and resets the list counters with the flag
     const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;

@@ -79,6 +79,16 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
     const GReal d2 = dx * dx + dy * dy + dz * dz;
     if (static_cast<double>(d2) > t.pad2_quarter) {
         *t.flag_set = 1; // benign race: every writer stores the same value
+        if (t.nbl_counters != nullptr) {
+            // sorted hand-over: whoever raises the flag also resets the list counters the coming build accumulates into
+            // (what the producer's bounds kernel does on the other paths; kernels_nblist.cuh).  Few atoms get here per step.
+            t.nbl_counters[0] = 0;
+            t.nbl_counters[1] = 0;
+            t.nbl_counters[2] = 0;
+            for (int k = 4; k < 4 + 64; k++) {
+                t.nbl_counters[k] = 0;
+            }
+        }
     }
     t.g_du_dx[0 * static_cast<size_t>(t.stride) + slot] = 0;
     t.g_du_dx[1 * static_cast<size_t>(t.stride) + slot] = 0;
@@ -167,6 +177,84 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
     }
 }
 
+// The same update, walking the producer's SORTED slots instead of the atoms (PregatherTarget's sorted hand-over: one
+// deferred producer whose order covers every atom).  Thread t owns slot t: atom = perm[t]; the producer's accumulator is
+// read and its record written coalesced, no slot_of_atom indirection; and since a 64-lane wave now holds two whole
+// 32-atom blocks of the producer's order, their bounding boxes (the input of a neighbor-list build) fall out of five
+// shuffle steps per dimension, every step -- the producer's bounds kernel is not launched on MD steps at all.
+// Same arithmetic, same Philox counters (keyed by atom) as the atom-order kernel: trajectories are bit-identical.
+template <typename Real, typename GReal>
+__global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
+    const int N, const Real ca, const Real *__restrict__ cbs, const Real *__restrict__ ccs, const unsigned long long seed,
+    const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t, u64 *__restrict__ du_dx,
+    u64 *__restrict__ du_dx_cm, const int cm_stride, const Real dt, const u64 *__restrict__ g0, const int stride0,
+    const double *__restrict__ box, const PregatherTarget pg) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *pg.flag_clear = 0; // the flag of the call just consumed becomes the one after next's
+    }
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const bool valid = slot < N;
+    GReal p[3] = {0, 0, 0}; // the new position as the producer's record stores it
+    if (valid) {
+        const int atom = static_cast<int>(pg.perm[slot]);
+        const Real cb = cbs[atom];
+        const Real cc = ccs[atom];
+        Real nz[3] = {0, 0, 0};
+        if (cc != 0) {
+            normal3(seed, step, static_cast<unsigned int>(atom), nz);
+        }
+        const Real half_dt = static_cast<Real>(0.5) * dt;
+        double xn[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            u64 f = du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+            if (du_dx != nullptr) {
+                f += du_dx[atom * 3 + d];
+                du_dx[atom * 3 + d] = 0;
+            }
+            f += g0[static_cast<size_t>(d) * stride0 + slot];
+            const Real force = -fixed_to_float<Real>(f);
+            const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
+            const Real v_new = ca * v_mid + cc * nz[d];
+            v_t[atom * 3 + d] = static_cast<double>(v_new);
+            xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
+            x_t[atom * 3 + d] = xn[d];
+            du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
+            p[d] = static_cast<GReal>(xn[d]);
+        }
+        pregather_atom_as<GReal>(pg, slot, atom, xn[0], xn[1], xn[2]);
+    }
+    // bounding boxes of the two 32-slot blocks of this wave: every atom imaged next to the block's first one, butterfly
+    // min / max (the arithmetic of k_block_bounds<Real, false>, kernels_nblist.cuh)
+    const GReal half = static_cast<GReal>(0.5);
+    const int first = lane & 32;
+    GReal lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const GReal b = static_cast<GReal>(box[d * 4]);
+        const GReal ib = 1 / b;
+        const GReal p0 = __shfl(p[d], first, 64);
+        const GReal img = valid ? p[d] - b * nearbyint((p[d] - p0) * ib) : p0;
+        GReal l = img, h = img;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            l = min(l, __shfl_xor(l, o, 64));
+            h = max(h, __shfl_xor(h, o, 64));
+        }
+        lo[d] = l;
+        hi[d] = h;
+    }
+    const int sub = lane & 31;
+    if (sub < 3 && (slot - sub) < N) { // lane `first + d` writes component d of its block
+        const int blk = slot >> 5;
+        const GReal l = sub == 0 ? lo[0] : (sub == 1 ? lo[1] : lo[2]);
+        const GReal h = sub == 0 ? hi[0] : (sub == 1 ? hi[1] : hi[2]);
+        static_cast<GReal *>(pg.blk_ctr)[blk * 3 + sub] = half * (h + l);
+        static_cast<GReal *>(pg.blk_ext)[blk * 3 + sub] = half * (h - l);
+    }
+}
+
 template <typename Real>
 LangevinIntegrator<Real>::LangevinIntegrator(
     const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed)
@@ -212,14 +300,30 @@ void LangevinIntegrator<Real>::step_fwd(
     // every atom moves (no local-MD index list): the update kernel can leave the producers' next gather done
     const PregatherTarget no_target;
     const bool pregather = d_idxs == nullptr;
-    k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
-        N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, d_du_dx_cm_.data, cm_stride_, dt_,
-        df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, pregather ? df0.next : no_target, pregather ? df1.next : no_target);
+    // one producer whose sorted order covers every atom: walk its slots (and leave its block bounds done as well)
+    const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n == N_ && df0.next.perm != nullptr;
+    if (sorted) {
+        u64 *dx = wrote_du_dx ? d_du_dx_.data : nullptr;
+        if (df0.next.real_bytes == 8) {
+            k_update_forward_baoab_sorted<Real, double><<<ceil_divide(N_, 64), 64, 0, stream>>>(
+                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+        } else {
+            k_update_forward_baoab_sorted<Real, float><<<ceil_divide(N_, 64), 64, 0, stream>>>(
+                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+        }
+    } else {
+        PregatherTarget t0 = pregather ? df0.next : no_target, t1 = pregather ? df1.next : no_target;
+        t0.nbl_counters = nullptr; // the atom-order kernel leaves no block bounds: the producer's own bounds kernel resets them
+        t1.nbl_counters = nullptr;
+        k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
+            N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, d_du_dx_cm_.data, cm_stride_, dt_,
+            df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1);
+    }
     HIP_CHECK(hipGetLastError());
     if (pregather) {
         for (const DeferredForces &df : deferred_) {
             if (df.owner != nullptr && df.next.gathered != nullptr) {
-                df.owner->pregather_committed(d_x_t, d_box_t);
+                df.owner->pregather_committed(d_x_t, d_box_t, sorted);
             }
         }
     }

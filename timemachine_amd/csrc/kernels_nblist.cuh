@@ -151,9 +151,24 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     unsigned int *__restrict__ counters, unsigned int *__restrict__ col_atoms, int4 *__restrict__ items,
     const unsigned int items_cap,    // capacity of each of the NB_SHARDS * NB_CLASSES item buckets
     int2 *__restrict__ row_segments, // per row block {start, count}
-    const int *__restrict__ flag, const int force) {
+    const int *__restrict__ flag, const int force,
+    // snap_x != nullptr: no bounds kernel ran in front of this launch (its boxes came with the sorted hand-over, see
+    // engine.hpp: PregatherTarget); its other duties on a rebuild fall to this kernel: the coordinate / box snapshot and the
+    // build count.  (The counter reset was made by whoever raised the flag.)
+    const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box) {
     if (!force && *flag == 0) {
         return;
+    }
+    if (snap_x != nullptr) {
+        for (int t = blockIdx.x * NBL_THREADS + threadIdx.x; t < n_snap; t += gridDim.x * NBL_THREADS) {
+            snap_x[t] = x[t];
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 9) {
+            snap_box[threadIdx.x] = box[threadIdx.x];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            counters[3] += 1;
+        }
     }
     __shared__ int s_list[NBL_CHUNK];
     __shared__ Real s_rx[TILE], s_ry[TILE], s_rz[TILE];

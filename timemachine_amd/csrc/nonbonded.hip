@@ -366,7 +366,8 @@ template <typename Real> unsigned int Neighborlist<Real>::num_builds() {
 template <typename Real>
 void Neighborlist<Real>::build_device(
     const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
-    const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream) {
+    const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream,
+    const bool bounds_done) {
     const bool ut = this->upper_triangular();
     const int ncb = this->num_column_blocks();
     const int nrb = this->num_row_blocks();
@@ -375,23 +376,32 @@ void Neighborlist<Real>::build_device(
     // one wave per block (4 per workgroup); the same threads also copy the coordinate snapshot grid-stride
     int grid = std::min(std::max(ceil_divide(total_blocks, tpb / 64), 1), 2048);
     const int dummy_flag_force = d_flag ? force : 1;
-    k_block_bounds<Real, false><<<grid, tpb, 0, stream>>>(
-        ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
-        d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
-        d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
-    HIP_CHECK(hipGetLastError());
-    TM_DEBUG_SYNC("k_block_bounds", stream);
+    if (bounds_done && (!ut || force || d_snap_x == nullptr)) {
+        throw std::runtime_error("Neighborlist::build_device: bounds_done needs the upper-triangular, flag-driven MD path");
+    }
+    if (!bounds_done) {
+        k_block_bounds<Real, false><<<grid, tpb, 0, stream>>>(
+            ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
+            d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+        HIP_CHECK(hipGetLastError());
+        TM_DEBUG_SYNC("k_block_bounds", stream);
+    }
+    // the list kernel's own snapshot duty (only when no bounds kernel ran)
+    const int ls_n = bounds_done ? n_snap : 0;
+    const double *ls_x = bounds_done ? d_x : nullptr;
+    double *ls_snap_x = bounds_done ? d_snap_x : nullptr, *ls_snap_box = bounds_done ? d_snap_box : nullptr;
     const size_t lds = 0;
     if (ut) {
         k_find_ixns<Real, true><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
             cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
-            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, ls_n, ls_x, ls_snap_x, ls_snap_box);
     } else {
         k_find_ixns<Real, false><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
             d_gathered, d_box, cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
-            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, ls_n, ls_x, ls_snap_x, ls_snap_box);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -615,12 +625,20 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
     out.next.g_du_dx = d_g_du_dx_.data;
     out.next.stride = acc_stride_;
+    if (K_ == N_ && group_rows_ == 0 && nblist_.upper_triangular()) { // plain all-pairs over every atom: see PregatherTarget
+        out.next.perm = d_perm_.data;
+        out.next.sorted_n = K_;
+        out.next.blk_ctr = nblist_.d_col_ctr();
+        out.next.blk_ext = nblist_.d_col_ext();
+        out.next.nbl_counters = nblist_.d_counters_rw();
+    }
     offer_p_ = d_p;
     return true;
 }
 
-template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const double *d_x, const double *d_box) {
+template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) {
     pre_valid_ = true;
+    pre_sorted_ = sorted_bounds_done;
     pre_x_ = d_x;
     pre_box_ = d_box;
     pre_p_ = offer_p_;
@@ -655,9 +673,14 @@ void NonbondedAllPairs<Real>::run_pipeline(
     hipStream_t stream, const bool pregathered) {
     const int tpb = DEFAULT_TPB;
     pre_valid_ = false; // consumed by this call or stale after it
+    // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker
+    // does that whenever it raises the rebuild flag, and the host cannot know): the list has to be rebuilt whatever the
+    // check below finds.
+    const bool sorted_pending = pre_sorted_;
+    pre_sorted_ = false;
 
     // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
-    int force = force_rebuild_ ? 1 : 0;
+    int force = (force_rebuild_ || (sorted_pending && !pregathered)) ? 1 : 0;
     if (calls_since_sort_ % steps_per_sort_ == 0) {
         if (!disable_hilbert_ && group_rows_ > 0) { // interaction group: each side keeps its own contiguous, sorted range
             hilbert_->sort_device(group_rows_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
@@ -688,7 +711,8 @@ void NonbondedAllPairs<Real>::run_pipeline(
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     nblist_.build_device(
-        d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream);
+        d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream,
+        pregathered && sorted_pending);
 
     TM_DEBUG_SYNC("list build", stream);
     // (d) K4: tile kernel
