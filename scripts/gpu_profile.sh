@@ -25,7 +25,10 @@ for f in glob.glob(out+'/**/*kernel_trace.csv', recursive=True):
     # the last 400 x 4 launches = the timed MD steps of the f64 run
     md=[r for r in rows if 'tmamd' in r['Kernel_Name']]
     names=collections.Counter(); dur=collections.defaultdict(float); gap=0.0; n=0
-    tiles=[i for i,r in enumerate(md) if 'k_nonbonded_tiles<double' in r['Kernel_Name']]
+    # the timed MD steps are the last long run of forces-only tile launches; take their element type from the last one
+    last=[r['Kernel_Name'] for r in md if 'k_nonbonded_tiles<' in r['Kernel_Name'] and ', false, true, false' in r['Kernel_Name']][-1]
+    real='k_nonbonded_tiles<double' if 'tiles<double' in last else 'k_nonbonded_tiles<float'
+    tiles=[i for i,r in enumerate(md) if real in r['Kernel_Name']]
     sel=md[tiles[len(tiles)//2]:tiles[-1]] if len(tiles)>10 else md
     for a,b in zip(sel[:-1],sel[1:]):
         g=int(b['Start_Timestamp'])-int(a['End_Timestamp'])

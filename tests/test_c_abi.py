@@ -133,9 +133,15 @@ def test_committed_bench_lines_follow_the_contract():
     import glob
     import json
 
-    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_v*_bench.json")))
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r0*_v*_bench.json")))
     assert paths, "no committed bench line"
     d = json.load(open(paths[-1]))
+    hrex = sorted(glob.glob(os.path.join(os.path.dirname(paths[-1]), "r0*_bench_hrex.json")))
+    if hrex:  # the replica-exchange mode reports the same top-level fields
+        h = json.load(open(hrex[-1]))
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+            assert key in h, key
+        assert "workload" in h["config"] and h["scaling"] == "strong"
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["unit"] == "ns/day" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
