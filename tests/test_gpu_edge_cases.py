@@ -244,6 +244,27 @@ def test_torsion_index_reversal_is_bitwise(co, P, precision):
     assert fwd[2] == rev[2]
 
 
+@pytest.mark.parametrize("cutoff", [1.0, 1.2, 1.4])
+def test_f64_forces_only_forms_agree_with_the_full_call_and_the_oracle(co, P, cutoff):
+    """The MD launch of the f64 tile kernel (forces only) has its own pair path: table-driven electrostatics with the rare
+    cases deferred, and -- for cutoffs up to the end of the switch at 1.2 nm -- a form without the beyond-the-switch select.
+    Below, at and beyond 1.2 nm its forces must equal the full call's (u + du_dx + du_dp, analytic damping function on the
+    side) bit for bit, and the oracle's within the f64 bar; beyond 1.2 nm pairs exist whose electrostatic term is exactly 0."""
+    from oracle import ref_potentials as rp
+
+    g = load("config1_pbc.npz")
+    x, p, box = g["x"], g["params"], g["box"]
+    pot = P.NonbondedAllPairs(256, 2.0, cutoff).to_gpu(np.float64).unbound_impl
+    only = pot.execute_raw(x, p, box, True, False, False)[0]
+    full = pot.execute_raw(x, p, box, True, True, True)[0]
+    with_u = pot.execute_raw(x, p, box, True, False, True)[0]
+    np.testing.assert_array_equal(only, full)
+    np.testing.assert_array_equal(only, with_u)
+    u_ref, du_dx_ref, _ = rp.nonbonded_all_pairs(x, p, box, 2.0, cutoff)
+    du_dx = pot.execute(x, p, box, True, False, False)[0]
+    assert_equal_vectors(du_dx_ref, du_dx, TOL[np.float64]["rtol"])
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # tests/test_energy_overflows.py:68-128,131-177,251-280 -- two atoms in the 100 nm vacuum box; summation overflow
 # ----------------------------------------------------------------------------------------------------------------

@@ -243,7 +243,10 @@ template <typename Real> struct TileRegs {
     Real ox, oy, oz;  // tile origin (first row atom)
 };
 
-template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP>
+// INSIDE_SWITCH (f64 forces-only launches): the host vouches for cutoff <= TM_ES_SWITCH_D -- every caller the reference has --
+// so no pair inside the cutoff lies beyond the end of the electrostatic switch.  A template parameter and not a branch in
+// the kernel: a second copy of the batch body inside the item loop cost 2 % of the launch, executed or not.
+template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP, bool INSIDE_SWITCH = false>
 __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (TileShape<Real, COMPUTE_DU_DP>::min_waves)) void k_nonbonded_tiles(
     const int K,                               // atoms in `gathered` (record K is an all-zero sentinel)
     const int NR,                              // number of row atoms
@@ -323,6 +326,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
+    // |prefactor * 2^36| below this: every force component of a pair inside the cutoff converts on the fast path
+    [[maybe_unused]] const double ps_limit = TM_FIXED_FAST_LIMIT / cutoff_d * 0.999999;
     const Real beta = static_cast<Real>(beta_d);
     i128 energy = 0;
     // phase-1 filter in f32: box, and a cutoff^2 padded far beyond the rounding error of the filter arithmetic
@@ -666,12 +671,29 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
                     const Real qi = ri[4], qj = cj[4];
                     const Real sig_i = ri[5], sig_j = cj[5], eps_i = ri[6], eps_j = cj[6];
+                    if constexpr (sizeof(Real) == 8 && !COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) {
+                        // MD: the prefactor only, and ONE wave-uniform escape for both rare cases -- d2 under the table
+                        // (clashing atoms: analytic electrostatics) and a product beyond the fast conversion's range
+                        bool below, big;
+                        const double prefactor = nb_pair_prefactor_deferred<INSIDE_SWITCH>(1.0, 1.0, qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, es_tab, below);
+                        u64 fx, fy, fz;
+                        pair_force_fixed_fast_bounded(prefactor, ddx, ddy, ddz, ps_limit, fx, fy, fz, big);
+                        const bool rare = below || big;
+                        if (__ballot(rare) != 0ull) {
+                            if (rare) {
+                                const double p = below ? nb_pair_prefactor_below_table(1.0, 1.0, qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta) : prefactor;
+                                pair_force_fixed_slow(p, ddx, ddy, ddz, fx, fy, fz);
+                            }
+                        }
+                        lds_add(&s_fi[0][pi], fx);
+                        lds_add(&s_fi[1][pi], fy);
+                        lds_add(&s_fi[2][pi], fz);
+                        lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
+                        lds_sub(&s_fj[1][pj], fy);
+                        lds_sub(&s_fj[2][pj], fz);
+                    } else {
                     PairOut<Real> o;
-#if defined(TM_ABLATE) && TM_ABLATE == 4
-                    o.prefactor = dd2 * qi; o.u = qj; o.inv_dij = qi; o.ebd = qj; o.sig_grad = 0; o.eps_grad = 0; o.has_lj = false; // ablation: no math
-#else
                     nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
-#endif
                     if constexpr (COMPUTE_DU_DX) {
                         u64 fx, fy, fz;
                         pair_force_fixed(o.prefactor, ddx, ddy, ddz, fx, fy, fz);
@@ -699,13 +721,16 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     if constexpr (COMPUTE_U) {
                         energy += float_to_fixed_energy<Real>(o.u);
                     }
+                    } // forces only / everything else
                     } // exact cutoff test
                 }
             };
             while (cnt >= NB_CHUNK || (last && cnt > 0)) {
                 TM_T(t_h0);
-                const int n = cnt < NB_CHUNK ? cnt : NB_CHUNK;
-                const int base = cnt - n;
+                // scalar on purpose: the compiler's own form of this is a VALU clamp + readfirstlane per batch
+                int base;
+                asm("s_sub_i32 %0, %1, 64\n\ts_max_i32 %0, %0, 0" : "=&s"(base) : "s"(cnt) : "scc");
+                const int n = cnt - base;
                 wave_lds_sync();
                 pair_batch(lane < n, base + lane);
                 cnt = base;

@@ -179,11 +179,17 @@ __device__ __attribute__((noinline, cold)) double es_force_factor_below_table(co
 
 // F(d2) such that the electrostatic force prefactor of a pair is charge_scale * q_i q_j * F(d2): the table part, without a
 // branch.  `below` says that d2 lies under the table (the caller owes the analytic form; the value returned is then 0).
-template <typename Tab> __device__ __forceinline__ double es_force_factor_table(const double d2, const Tab &tab, bool &below) {
+// INSIDE_SWITCH: the caller knows d2 < TM_ES_SWITCH_D^2 (its cutoff is not beyond the end of the switch): d2 can then only
+// leave the table downwards, and the value returned for such a lane is garbage instead of 0 -- three selects less.
+template <bool INSIDE_SWITCH = false, typename Tab> __device__ __forceinline__ double es_force_factor_table(const double d2, const Tab &tab, bool &below) {
     double t;
     unsigned int idx = es_tab_index(d2, t);
     const bool outside = idx >= static_cast<unsigned int>(ES_TAB_INTERVALS); // d2 < 2^-7 or d2 >= 2 (or NaN)
-    idx = outside ? 0u : idx;
+    if constexpr (INSIDE_SWITCH) {
+        idx = idx < static_cast<unsigned int>(ES_TAB_INTERVALS) ? idx : static_cast<unsigned int>(ES_TAB_INTERVALS - 1);
+    } else {
+        idx = outside ? 0u : idx;
+    }
     double c[ES_TAB_COEFFS];
     tab.load(idx, c);
     double p = __builtin_fma(c[5], t, c[4]);
@@ -191,9 +197,14 @@ template <typename Tab> __device__ __forceinline__ double es_force_factor_table(
     p = __builtin_fma(p, t, c[2]);
     p = __builtin_fma(p, t, c[1]);
     p = __builtin_fma(p, t, c[0]);
-    const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
-    below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
-    return (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+    if constexpr (INSIDE_SWITCH) {
+        below = outside;
+        return p;
+    } else {
+        const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
+        below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
+        return (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+    }
 }
 
 template <typename Tab> __device__ __forceinline__ double es_force_factor(const double beta, const double d2, const Tab &tab) {
@@ -208,23 +219,46 @@ template <typename Tab> __device__ __forceinline__ double es_force_factor(const 
     return f;
 }
 
-// The branch-free core of the forces-only f64 pair function (see nb_pair<false> below: the same operations in the same
-// order, with selects where that one branches).  `below`: the electrostatic part still needs the analytic form.
-template <typename Tab>
-__device__ __forceinline__ double nb_pair_prefactor_nobranch(
-    const double qi, const double qj, const double sig_i, const double sig_j, const double eps_i, const double eps_j, const double d2ij,
-    const Tab &tab, bool &below) {
+// The forces-only f64 pair function with its two rare cases left to the caller (the tile kernel folds them into ONE
+// wave-uniform escape together with the fixed-point overflow case): the operations of nb_pair<false> below in the same
+// order, so the same bits.  `below`: d2 lies under the table, the value returned is not to be used --
+// nb_pair_prefactor_below_table() gives the prefactor then.
+template <bool INSIDE_SWITCH, typename Tab>
+__device__ __forceinline__ double nb_pair_prefactor_deferred(
+    const double charge_scale, const double lj_scale, const double qi, const double qj, const double sig_i, const double sig_j,
+    const double eps_i, const double eps_j, const double d2ij, const Tab &tab, bool &below) {
     const double qij = qi * qj;
-    const double es_prefactor = qij * es_force_factor_table(d2ij, tab, below); // charge_scale == 1: 1 * qij is qij, bit for bit
+    const double es_prefactor = charge_scale * qij * es_force_factor_table<INSIDE_SWITCH>(d2ij, tab, below);
     const double inv_d2ij = tm_rcp_f64(d2ij);
-    const bool has_lj = (eps_i != 0 && eps_j != 0);
-    const double eps_ij = eps_i * eps_j;
-    const double sig_ij = sig_i + sig_j;
-    const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
-    const double sig4 = sig2 * sig2;
-    const double sig6 = sig4 * sig2;
-    const double lj_prefactor = eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24); // lj_scale == 1
-    return has_lj ? es_prefactor - lj_prefactor : es_prefactor;
+    double prefactor = es_prefactor;
+    if (eps_i != 0 && eps_j != 0) {
+        const double eps_ij = eps_i * eps_j;
+        const double sig_ij = sig_i + sig_j;
+        const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
+        const double sig4 = sig2 * sig2;
+        const double sig6 = sig4 * sig2;
+        const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24);
+        prefactor -= lj_prefactor;
+    }
+    return prefactor;
+}
+__device__ __attribute__((noinline, cold)) double nb_pair_prefactor_below_table(
+    const double charge_scale, const double lj_scale, const double qi, const double qj, const double sig_i, const double sig_j,
+    const double eps_i, const double eps_j, const double d2ij, const double beta) {
+    const double qij = qi * qj;
+    const double es_prefactor = charge_scale * qij * es_force_factor_below_table(beta, d2ij);
+    const double inv_d2ij = tm_rcp_f64(d2ij);
+    double prefactor = es_prefactor;
+    if (eps_i != 0 && eps_j != 0) {
+        const double eps_ij = eps_i * eps_j;
+        const double sig_ij = sig_i + sig_j;
+        const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
+        const double sig4 = sig2 * sig2;
+        const double sig6 = sig4 * sig2;
+        const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24);
+        prefactor -= lj_prefactor;
+    }
+    return prefactor;
 }
 
 // The f64 pair function.  WANT_U_DP = false (MD: forces only) never forms 1/d, erfc, exp or the switch function:
@@ -300,6 +334,17 @@ __device__ __forceinline__ void pair_force_fixed_fast(double prefactor, double d
     fy = static_cast<u64>(real_to_int64_fast(b));
     fz = static_cast<u64>(real_to_int64_fast(c));
     big = !(__builtin_fabs(a) < TM_FIXED_FAST_LIMIT && __builtin_fabs(b) < TM_FIXED_FAST_LIMIT && __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
+}
+// The same for a caller that knows a bound on the displacement: with |dx|, |dy|, |dz| < cutoff (they are components of a
+// vector that passed d2 < cutoff^2) and ps_limit = 2^51 / cutoff less a hair, |ps| < ps_limit implies that all three products
+// are in the fast conversion's range -- one comparison instead of three.  `big` is then a superset of the exact condition;
+// the slow path is exact for every value, so the bits do not depend on which path converts.
+__device__ __forceinline__ void pair_force_fixed_fast_bounded(double prefactor, double dx, double dy, double dz, double ps_limit, u64 &fx, u64 &fy, u64 &fz, bool &big) {
+    const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
+    fx = static_cast<u64>(real_to_int64_fast(ps * dx));
+    fy = static_cast<u64>(real_to_int64_fast(ps * dy));
+    fz = static_cast<u64>(real_to_int64_fast(ps * dz));
+    big = !(__builtin_fabs(ps) < ps_limit);
 }
 __device__ __forceinline__ void pair_force_fixed_slow(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
     const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);

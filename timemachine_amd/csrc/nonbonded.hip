@@ -717,9 +717,9 @@ void NonbondedAllPairs<Real>::run_pipeline(
     TM_DEBUG_SYNC("list build", stream);
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
-#define TM_LAUNCH_TILES(U, X, PP)                                                                                      \
+#define TM_LAUNCH_TILES(U, X, PP, ...)                                                                                 \
     launched_waves = n_cus * TileShape<Real, PP>::waves_per_cu;                                                        \
-    k_nonbonded_tiles<Real, U, X, PP><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
+    k_nonbonded_tiles<Real, U, X, PP, ##__VA_ARGS__><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
         d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, piggyback_acc_, piggyback_atom_stride_, piggyback_comp_stride_, \
@@ -740,7 +740,17 @@ void NonbondedAllPairs<Real>::run_pipeline(
     switch (sel) {
     case 0: TM_LAUNCH_TILES(false, false, false); break;
     case 1: TM_LAUNCH_TILES(false, false, true); break;
-    case 2: TM_LAUNCH_TILES(false, true, false); break;
+    case 2:
+        // MD: the f64 kernel has a form for cutoffs that do not reach beyond the end of the electrostatic switch (all of the
+        // reference's callers: cutoff == 1.2 nm); see INSIDE_SWITCH
+        if constexpr (sizeof(Real) == 8) {
+            if (cutoff_ <= TM_ES_SWITCH_D) {
+                TM_LAUNCH_TILES(false, true, false, true);
+                break;
+            }
+        }
+        TM_LAUNCH_TILES(false, true, false);
+        break;
     case 3: TM_LAUNCH_TILES(false, true, true); break;
     case 4: TM_LAUNCH_TILES(true, false, false); break;
     case 5: TM_LAUNCH_TILES(true, false, true); break;
