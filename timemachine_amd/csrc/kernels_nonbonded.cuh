@@ -584,10 +584,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             // wave_rol:1 moves, VALU) -- not by an LDS read: the LDS pipe is what binds this kernel (rocprofv3 PMC: LDS array
             // busy ~70 % of the launch, VALU ~50 %), and 32 ds_read_b128 per item were 8 % of its load.
             float4 rf[4];
-            int ri[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                ri[k] = (round0 + k + lane) & (TILE - 1);
                 rf[k] = rot;
                 rot.x = wave_rol1(rot.x);
                 rot.y = wave_rol1(rot.y);
@@ -612,7 +610,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     bool ok = fd2 < fcut2;
                     if constexpr (decltype(ordered)::value) {
                         // upper-triangular launches keep only row < col (sorted indices; the row index is row_first + i)
-                        ok = ok && (row_first + static_cast<unsigned int>(ri[k])) < ja;
+                        const unsigned int ri = static_cast<unsigned int>(round0 + k + lane) & (TILE - 1);
+                        ok = ok && (row_first + ri) < ja;
                     }
                     hit[k] = ok;
                     hit_mask[k] = __ballot(ok);
@@ -634,7 +633,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const unsigned short entry = static_cast<unsigned short>((ri[k] << 8) | lane);
+                // a queue entry names the ROUND, not the row: (round * 8) << 8 | column lane -- a wave-uniform high byte, so one
+                // v_or here; phase 2 recovers the row's byte offset as (round * 8 + column * 8) & 0xf8
+                const unsigned short entry = static_cast<unsigned short>(((round0 + k) << 11) | lane);
                 const u64 mask = hit_mask[k];
                 if (hit[k]) {
                     // lanes below this one that also hit: v_mbcnt_lo + v_mbcnt_hi
@@ -656,7 +657,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             auto pair_batch = [&](const bool active, const int slot) {
                 if (active) {
                     const unsigned int e = s_queue[slot];
-                    const int pi = e >> 8, pj = e & 0xff;
+                    const unsigned int pj = e & 0xffu;
+                    const unsigned int pi = (((pj << 3) + (e >> 8)) & 0xf8u) >> 3; // (round + column) & 31
                     Real ri[7], cj[7]; // x, y, z, w, q, sig, eps of the pair's row / column atom
                     if constexpr (sizeof(Real) == 8 && TM_LDS_SINGLE_READS) {
                         // fourteen single ds_read_b64 (2 LDS cycles each; row reads are conflict free: 32 rows = 64 banks).  Left
