@@ -69,8 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["md", "hrex"], default="md")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cutoff", type=float, default=1.2)
-    ap.add_argument("--padding", type=float, default=0.15, help="nblist_padding of the nonbonded potential: a speed knob of the potential's constructor, "
-                    "results do not depend on it bit for bit (reference default 0.1; 0.15 measured fastest here, DESIGN.md section 6)")
+    ap.add_argument("--padding", type=float, default=0.18, help="nblist_padding of the nonbonded potential: a speed knob of the potential's constructor, "
+                    "results do not depend on it bit for bit (reference default 0.1; 0.18 measured fastest here, DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=400)
     ap.add_argument("--windows", type=int, default=None, help="lambda windows (md: rows of the end-of-run u_kl gather, default 8; hrex: states, default 24)")
