@@ -399,7 +399,13 @@ def run_md(args, rank, local_rank, world, backend):
             total_ms, launches = co.profile_read("nonbonded_tiles")
             co.profile_set_enabled(False)
             co.profile_reset()
-            prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": nb.get_tile_ixn_count(),
+            tiles = nb.get_tile_ixn_count()
+            for _ in range(8):  # the list counters read 0 between the step that asked for a rebuild and the rebuild itself
+                if tiles:
+                    break
+                ctxt.multiple_steps(1, 0)
+                tiles = nb.get_tile_ixn_count()
+            prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": tiles,
                     "run_ms": ctxt.last_multiple_steps_ms(), "steps": profile_steps, "builds": nb.get_build_count() - builds0}
         return dev_s, host_s, xf, bps, prof
 

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python $ROOT/bench.py --steps 400 --warmup 100 --no-cpu-baseline --profile-steps 0 "$@" > $OUT/run.log 2>&1
 cd $ROOT
-python - "$OUT" <<'PY'
+python - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections
 out=sys.argv[1]
 for f in glob.glob(out+'/**/*kernel_stats.csv', recursive=True):
@@ -25,11 +25,12 @@ for f in glob.glob(out+'/**/*kernel_trace.csv', recursive=True):
     # the last 400 x 4 launches = the timed MD steps of the f64 run
     md=[r for r in rows if 'tmamd' in r['Kernel_Name']]
     names=collections.Counter(); dur=collections.defaultdict(float); gap=0.0; n=0
-    # the timed MD steps are the last long run of forces-only tile launches; take their element type from the last one
-    last=[r['Kernel_Name'] for r in md if 'k_nonbonded_tiles<' in r['Kernel_Name'] and ', false, true, false' in r['Kernel_Name']][-1]
-    real='k_nonbonded_tiles<double' if 'tiles<double' in last else 'k_nonbonded_tiles<float'
+    # the timed MD steps: the last 350 forces-only tile launches of the benchmarked precision (the other precision's short
+    # leg may follow them in the trace)
+    real='k_nonbonded_tiles<float, false, true, false' if 'f32' in sys.argv[2:] else 'k_nonbonded_tiles<double, false, true, false'
     tiles=[i for i,r in enumerate(md) if real in r['Kernel_Name']]
-    sel=md[tiles[len(tiles)//2]:tiles[-1]] if len(tiles)>10 else md
+    names=collections.Counter(); dur=collections.defaultdict(float); gap=0.0; n=0
+    sel=md[tiles[-351]:tiles[-1]] if len(tiles)>400 else md
     for a,b in zip(sel[:-1],sel[1:]):
         g=int(b['Start_Timestamp'])-int(a['End_Timestamp'])
         gap+=max(g,0); n+=1
@@ -37,7 +38,7 @@ for f in glob.glob(out+'/**/*kernel_trace.csv', recursive=True):
         k=r['Kernel_Name'].split('(')[0].replace('void tmamd::','')[:40]
         names[k]+=1; dur[k]+=int(r['End_Timestamp'])-int(r['Start_Timestamp'])
     steps=sum(1 for r in sel if 'k_nonbonded_tiles' in r['Kernel_Name'])
-    print(f"-- second half of the trace: {steps} steps; per step (us):")
+    print(f"-- the last {steps} timed MD steps of the trace; per step (us):")
     for k in sorted(dur,key=lambda k:-dur[k]):
         print(f"   {k:42s} {dur[k]/steps/1e3:7.2f}  ({names[k]/steps:.2f} launches/step, {dur[k]/names[k]/1e3:.2f} us each)")
     print(f"   idle between kernels                       {gap/steps/1e3:7.2f}")

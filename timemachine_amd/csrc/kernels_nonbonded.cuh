@@ -581,8 +581,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             }
             // ---- phase 1: four conservative f32 distance filters per lane.  The row a lane meets in round r is row
             // (r + lane) & 31: its filter copy arrives by rotation -- `rot` moves one lane to the left per round (four DPP
-            // wave_rol:1 moves, VALU) -- not by an LDS read: the LDS pipe is what binds this kernel (rocprofv3 PMC: LDS array
-            // busy ~70 % of the launch, VALU ~50 %), and 32 ds_read_b128 per item were 8 % of its load.
+            // wave_rol:1 moves, VALU) -- not by an LDS read (32 ds_read_b128 per item; 68.3 -> 66.9 us per launch when it
+            // went in).  The kernel is bound by VALU issue (every wave instruction costs four cycles, f32 or f64; ~65 % busy),
+            // so what counts in this loop is the instruction count per round: see DESIGN.md section 4.2.
             float4 rf[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
