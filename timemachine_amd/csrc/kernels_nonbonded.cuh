@@ -115,6 +115,21 @@ template <bool ON> __device__ __forceinline__ bool hint(const bool c, const bool
         return c;
     }
 }
+// max over lanes 0-31 of non-negative values (lanes 32-63 must hold 0), returned wave-uniform.  Five DPP row operations
+// (prefix max within each 16-lane row by row_shr 1, 2, 4, 8 -- sources beyond the row read 0 -- then row 0's total into
+// row 1 by row_bcast:15) and one v_readlane: VALU only.  All 64 lanes must be enabled.
+__device__ __forceinline__ float wave_max_low_half_nonneg(float v) {
+    int x = __float_as_int(v);
+#define TM_DPP_MAX_STEP(CTRL, ROW_MASK)                                                                                \
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, true))))
+    TM_DPP_MAX_STEP(0x111, 0xf); // row_shr:1
+    TM_DPP_MAX_STEP(0x112, 0xf); // row_shr:2
+    TM_DPP_MAX_STEP(0x114, 0xf); // row_shr:4
+    TM_DPP_MAX_STEP(0x118, 0xf); // row_shr:8
+    TM_DPP_MAX_STEP(0x142, 0xa); // row_bcast:15 into rows 1 and 3
+#undef TM_DPP_MAX_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(x, 31));
+}
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -533,9 +548,15 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 const float4 r4 = s_rowf_mine;
                 rfrac = fmaxf(fabsf(r4.x) * fibx, fmaxf(fabsf(r4.y) * fiby, fabsf(r4.z) * fibz));
             }
+            if constexpr (F64) {
+                // (the f64 kernels sit at their 168-VGPR limit: the DPP form below needs one register more at this point and
+                // put three scratch accesses into the item loop -- 3.6 % slower -- so they keep the shuffle butterfly)
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                rfrac = fmaxf(rfrac, __shfl_xor(rfrac, o, 64));
+                for (int o = 32; o > 0; o >>= 1) {
+                    rfrac = fmaxf(rfrac, __shfl_xor(rfrac, o, 64));
+                }
+            } else {
+                rfrac = wave_max_low_half_nonneg(rfrac); // VALU only; the butterfly is six dependent LDS round trips per item (f32: +1.9 %)
             }
             compact = __ballot(!(cfrac + rfrac < 0.49f)) == 0ull;
             needs_order = upper_triangular && __ballot(col_live && ja <= row_first + (TILE - 1)) != 0ull;
