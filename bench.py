@@ -320,6 +320,43 @@ def cpu_baseline_configs():
     return out
 
 
+def gpu_configs_1_2():
+    """The same two workloads as cpu_baseline_configs() on the GPU (f64 potentials), so that every CPU figure has its
+    device counterpart in the line: config 1 = ms per MD step of the 256-atom cluster in either box (launch-latency
+    bound: three kernels per step), config 2 = seconds per u + du_dx + du_dp evaluation of all four terms (host API:
+    includes the host <-> device copies of every call, as the reference's execute() does)."""
+    from timemachine_amd import potentials as P
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+    out = {"precision": "f64"}
+    for tag, L in (("vacuum_100nm", 100.0), ("pbc_3nm", 3.0)):
+        s = ts.config1_water_cluster(L)
+        bps = [bp.to_gpu(np.float64).bound_impl for bp in ts.bound_potentials(s, np.float64)]
+        ctxt = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(TEMPERATURE, 1.0e-3, FRICTION, s.masses, 7).impl(), bps)
+        ctxt.multiple_steps(500, 0)
+        ctxt.multiple_steps(5000, 0)
+        out[f"config1_{tag}_ms_per_step"] = ctxt.last_multiple_steps_ms() / 5000
+    s = ts.small_solvated_ligand(lamb=0.3)
+    pots = [
+        (P.Nonbonded(s.num_atoms, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(np.float64).unbound_impl, s.nb_params),
+        (P.HarmonicBond(s.bond_idxs).to_gpu(np.float64).unbound_impl, s.bond_params),
+        (P.HarmonicAngle(s.angle_idxs).to_gpu(np.float64).unbound_impl, s.angle_params),
+        (P.PeriodicTorsion(s.torsion_idxs).to_gpu(np.float64).unbound_impl, s.torsion_params),
+    ]
+    times = []
+    for rep in range(12):
+        co.device_synchronize()
+        t0 = time.time()
+        for pot, prm in pots:
+            pot.execute(s.coords, prm, s.box, True, True, True)
+        co.device_synchronize()
+        times.append(time.time() - t0)
+    out["config2_seconds_mean"] = float(np.mean(times[2:]))
+    out["config2_seconds_min"] = float(np.min(times[2:]))
+    return out
+
+
 # k_nonbonded_tiles<Real, false, true, false>, per dispatch: (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 -- the gfx950
 # correction of MI355X_MICROARCH.md's HBM section doubles FETCH_SIZE.  Fallback when profiles/pmc_traffic.json is absent.
 PMC_TRAFFIC = {
@@ -519,6 +556,8 @@ def run_md(args, rank, local_rank, world, backend):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, xf, args.cutoff)
             out["cpu_baseline_configs"] = cpu_baseline_configs()
+            if not args.stub:
+                out["cpu_baseline_configs"]["gpu_beside"] = gpu_configs_1_2()
 
     print(json.dumps(out))
 
