@@ -333,19 +333,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
         }
     };
-#ifdef TM_ES_TAB_GLOBAL // experiment: the table through the vector L1 instead of LDS
-    using TileTab = std::conditional_t<sizeof(Real) == 8, EsTableGlobal, EsTableNone>;
-    TileTab es_tab{};
-    if constexpr (sizeof(Real) == 8) {
-        es_tab.tab = es_table;
-    }
-#else
     using TileTab = std::conditional_t<sizeof(Real) == 8, EsTableLds, EsTableNone>;
     TileTab es_tab{};
     if constexpr (sizeof(Real) == 8) {
         es_tab.tab = s_es_tab;
     }
-#endif
     constexpr bool F64 = sizeof(Real) == 8;
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);

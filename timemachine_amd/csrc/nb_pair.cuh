@@ -160,13 +160,6 @@ struct EsTableGlobal {
         c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
     }
 };
-struct EsTableConst { // ablation builds only: no memory access at all
-    __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
-        for (int k = 0; k < ES_TAB_COEFFS; k++) {
-            c[k] = 0.5 + idx;
-        }
-    }
-};
 struct EsTableNone {}; // f32 kernels: analytic A&S erfc + hardware exp / sincos, no table
 
 // the analytic form for d2 below the table (clashing atoms).  Deliberately NOT inlined: its ~60 polynomial coefficients
