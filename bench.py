@@ -84,6 +84,31 @@ def parse_args(argv=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# stdout carries exactly ONE line, the JSON record: libraries print banners there (RCCL: "Librccl path : ..." -- it came
+# out AFTER the record in a one-rank test), so file descriptor 1 is pointed at stderr for the whole run and the record is
+# written to the saved descriptor at the very end
+# ---------------------------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit_json(record):
+    line = json.dumps(record) + "\n"
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line.encode())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # launch
 # ---------------------------------------------------------------------------------------------------------------------
 def maybe_self_launch(args):
@@ -110,7 +135,7 @@ def init_distributed(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     backend = None
-    if world > 1:
+    if world > 1 or os.environ.get("TM_AMD_FORCE_COLLECTIVES"):  # (the variable: one-rank test of the RCCL path on a 1-GPU box)
         import torch
         import torch.distributed as dist
 
@@ -119,9 +144,9 @@ def init_distributed(args):
             backend = "nccl" if (torch.cuda.is_available() and not args.stub) else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     return rank, local_rank, world, backend
 
@@ -559,7 +584,7 @@ def run_md(args, rank, local_rank, world, backend):
             if not args.stub:
                 out["cpu_baseline_configs"]["gpu_beside"] = gpu_configs_1_2()
 
-    print(json.dumps(out))
+    emit_json(out)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -657,7 +682,7 @@ def run_hrex(args, rank, local_rank, world, backend):
     md_steps = n_frames * steps_per_frame
     accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
     proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
-    print(json.dumps({
+    emit_json({
         "metric": "ns/day aggregate over all lambda windows, HREX (BASELINE config 5 shape)",
         "value": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3,
         "unit": "ns/day",
@@ -683,12 +708,13 @@ def run_hrex(args, rank, local_rank, world, backend):
         "world_size": world,
         "backend": backend,
         "device": "stub" if args.stub else co.device_name(),
-    }))
+    })
 
 
 def main(argv=None):
     args = parse_args(argv)
     maybe_self_launch(args)
+    protect_stdout()
     rank, local_rank, world, backend = init_distributed(args)
     try:
         if args.mode == "hrex":
@@ -696,7 +722,7 @@ def main(argv=None):
         else:
             run_md(args, rank, local_rank, world, backend)
     finally:
-        if world > 1:
+        if world > 1 or os.environ.get("TM_AMD_FORCE_COLLECTIVES"):
             import torch.distributed as dist
 
             if dist.is_initialized():

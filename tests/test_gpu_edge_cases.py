@@ -5,6 +5,8 @@ device fixed-point conversions bit for bit.  Every call goes Python -> ctypes ->
 Fixtures: tests/golden/*.npz written by tests/golden/generate_golden_next.py in the build container (reference energies;
 oracle gradients after energy-equality + finite-difference checks against the reference).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -495,3 +497,59 @@ def test_config5_sized_hrex_iteration(co, P):
         bound[i].set_params(params_by_state[new_state[r]].reshape(-1))
         ctxts[i].multiple_steps(5, 0)
         assert np.all(np.isfinite(ctxts[i].get_x_t()))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the RCCL code path of timemachine_amd.parallel on the one GPU a test box has: a one-rank "nccl" group
+# ----------------------------------------------------------------------------------------------------------------
+_NCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from timemachine_amd import parallel
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rows = np.arange(12, dtype=np.float64).reshape(3, 4) + 0.25
+full = parallel.gather_rows([0, 1, 2], rows, 3, row_length=4)
+assert full.shape == (3, 4) and np.array_equal(full, rows), full
+full = parallel.gather_rows([2, 0], rows[:2], 3)  # row length agreed by the extra collective; window 1 stays NaN
+assert np.array_equal(full[2], rows[0]) and np.array_equal(full[0], rows[1]) and np.all(np.isnan(full[1])), full
+assert parallel.max_over_ranks(3.5) == 3.5 and parallel.sum_over_ranks(1.25) == 1.25
+parallel.barrier()
+dist.destroy_process_group()
+print("NCCL_ONE_RANK_OK")
+"""
+
+
+def test_parallel_collectives_run_over_rccl_on_one_rank():
+    """gather_rows / max_over_ranks / sum_over_ranks / barrier through backend "nccl" (= RCCL) with device tensors: what the
+    N > 1 bench does between GPUs, as far as a single-GPU box can exercise it (tensor device, dtype and shape handling)."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", TM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_ONE_RANK, repo], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("mode", ["md", "hrex"])
+def test_bench_modes_run_with_rccl_collectives_on_one_rank(mode):
+    """bench.py end to end with its collectives forced on (one-rank "nccl" group): the barrier / max-over-ranks timing, the
+    u_kl gather (md) and the per-frame energy-row gather (hrex) go through RCCL with device tensors; one JSON line comes out."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29654" if mode == "md" else "29655", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               TM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--mode", mode, "--no-cpu-baseline", "--profile-steps", "0", "--equil-scale", "0.1"]
+    cmd += ["--steps", "100", "--warmup", "20"] if mode == "md" else ["--steps", "40", "--warmup", "20", "--steps-per-frame", "20", "--windows", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["backend"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
+    if mode == "md":
+        assert line["mbar_gather_ok"] is True

@@ -16,9 +16,15 @@ def windows_for_rank(n_windows: int, world_size: int, rank: int) -> List[int]:
 
 
 def _dist():
+    """torch.distributed when a job of more than one rank is running (a one-rank group counts only if
+    TM_AMD_FORCE_COLLECTIVES is set: the GPU test of the RCCL code path on a single-GPU box), else None."""
+    import os
+
     import torch.distributed as dist
 
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist if (dist.get_world_size() > 1 or os.environ.get("TM_AMD_FORCE_COLLECTIVES")) else None
 
 
 def _device(dist):
