@@ -553,3 +553,100 @@ def test_bench_modes_run_with_rccl_collectives_on_one_rank(mode):
     assert line["backend"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
     if mode == "md":
         assert line["mbar_gather_ok"] is True
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# tests/test_determinism.py:19-118 -- re-computed frame energies are bitwise identical, and the fixed-point energies of the
+# separate bound potentials add up (uint64 wrap-around) to the SummedPotential's, with and without a barostat in the loop
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,rtol,atol", [(np.float64, 1e-8, 1e-8), (np.float32, 1e-4, 1e-6)])
+def test_deterministic_energies_of_md_frames(co, P, precision, rtol, atol):
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    N = s.num_atoms
+    groups = [list(range(3 * k, 3 * k + 3)) for k in range((N - 20) // 3)] + [list(range(N - 20, N))]
+    bound = ts.bound_potentials(s, precision)
+    bps = [bp.to_gpu(precision).bound_impl for bp in bound]
+    summed = P.SummedPotential([bp.potential for bp in bound], [bp.params for bp in bound]).to_gpu(precision)
+    ref_pot = summed.bind_params_list([bp.params for bp in bound]).bound_impl
+    # relax the lattice start first (NVT, strong friction), as the reference minimises before this test
+    relax = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, s.masses, 1).impl(), bps)
+    relax.multiple_steps(1000, 0)
+    x0, v0 = relax.get_x_t(), relax.get_v_t()
+    num_steps = 200
+    for with_barostat in (False, True):
+        movers = None
+        if with_barostat:
+            baro = MonteCarloBarostat(N, 1.0, 300.0, groups, 25, 1234).impl(bps)
+            baro.set_step(0)
+            assert baro.get_interval() <= num_steps
+            movers = [baro]
+        ctxt = co.Context(x0, v0, s.box, LangevinIntegrator(300.0, 1.5e-3, 1.0, s.masses, 1234).impl(), bps, movers=movers)
+        xs, boxes = ctxt.multiple_steps(num_steps, 10)
+        assert len(xs) == num_steps // 10
+        for x, b in zip(xs, boxes):
+            ref_du_dx, ref_U = ref_pot.execute(x, b)
+            assert np.all(np.isfinite(ref_du_dx)) and np.linalg.norm(ref_du_dx, axis=1).max() < 25000.0  # minimizer.check_force_norm's bound
+            ref_fixed = ref_pot.execute_fixed(x, b)
+            test_u, test_fixed = 0.0, np.uint64(0)
+            for bp in bps:
+                U_fixed = bp.execute_fixed(x, b)
+                assert int(U_fixed[0]) != (1 << 63) - 1  # not overflowed
+                with np.errstate(over="ignore"):
+                    test_fixed = test_fixed + U_fixed[0]
+                _, U = bp.execute(x, b)
+                test_u += U
+                _, U_again = bp.execute(x, b)  # the same frame again: the same bits
+                assert U == U_again
+                np.testing.assert_array_equal(bp.execute_fixed(x, b), U_fixed)
+            assert test_fixed == ref_fixed[0]  # integer energies add exactly
+            np.testing.assert_allclose(ref_U, test_u, rtol=rtol, atol=atol)
+            again_du_dx, again_U = ref_pot.execute(x, b)
+            assert again_U == ref_U
+            np.testing.assert_array_equal(again_du_dx, ref_du_dx)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# tests/test_bonded_stable.py:59-80 and tests/test_harmonic_angle_32bit.py -- the angle term near its singular geometries
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_harmonic_angle_finite_force_with_vanishing_bond_length(co, P, precision):
+    """A bond of 1e-9 nm inside an angle: with the stabiliser eps = 1 the forces stay finite (< 1e7), with eps = 0 they blow up
+    (the reference marks that case as an expected failure of the same assertion)."""
+    angle_idxs = np.array([[0, 1, 2]], dtype=np.int32)
+    coords = np.array([(0.0, 0.0, 0.0), (1e-9, 0.0, 0.0), (0.0, 1.0, 0.0)])
+    box = np.eye(3) * 100.0
+    impl = P.HarmonicAngle(angle_idxs).to_gpu(precision).unbound_impl
+    du_dx, _, _ = impl.execute(coords, np.array([(1.0, 1.0, 1.0)]), box, True, False, False)
+    assert np.all(np.isfinite(du_dx)) and np.all(np.abs(du_dx) < 1e7)
+    du_dx0, _, _ = impl.execute(coords, np.array([(1.0, 1.0, 0.0)]), box, True, False, False)
+    assert not (np.all(np.isfinite(du_dx0)) and np.all(np.abs(du_dx0) < 1e7))
+
+
+def test_linear_triatomic_is_stable_in_f32(co, P):
+    """tests/test_harmonic_angle_32bit.py: a nitrile-like H-C-N with an equilibrium angle of pi, 110 000 f32 Langevin steps at
+    1 fs: the mean angle stays above 3.0 rad and no coordinate leaves the neighbourhood (the f32 angle force near theta = pi
+    is where a naive acos / sin formulation loses everything).  Parameters: typical GAFF-like magnitudes (the reference takes
+    them from its force field files at run time)."""
+    from timemachine_amd.lib import LangevinIntegrator
+
+    def kahan_angle(a, b, c):  # bonded.py:82-97 with eps = 0
+        u, v = a - b, c - b
+        nu, nv = np.linalg.norm(u), np.linalg.norm(v)
+        return 2 * np.arctan2(np.linalg.norm(nv * u - nu * v), np.linalg.norm(nv * u + nu * v))
+
+    x0 = np.array([(-0.107, 0.0, 0.0), (0.0, 0.0, 0.0), (0.1157, 0.0, 0.0)]) + 5.0  # H, C, N on a line
+    masses = np.array([1.008 * 2, 12.011 - 1.008, 14.007])  # hydrogen mass repartitioning as in the reference test
+    bonds = P.HarmonicBond(np.array([[0, 1], [1, 2]], dtype=np.int32)).bind(np.array([(310000.0, 0.107), (700000.0, 0.1157)]))
+    angle = P.HarmonicAngle(np.array([[0, 1, 2]], dtype=np.int32)).bind(np.array([(400.0, np.pi, 0.0)]))
+    bps = [bonds.to_gpu(np.float32).bound_impl, angle.to_gpu(np.float32).bound_impl]
+    box = np.eye(3) * 10.0
+    ctxt = co.Context(x0, np.zeros_like(x0), box, LangevinIntegrator(300.0, 1.0e-3, 1.0, masses, 2024).impl(), bps)
+    ctxt.multiple_steps(10_000, 0)  # burn-in
+    xs, _ = ctxt.multiple_steps(100_000, 1000)
+    assert len(xs) == 100
+    angles = [kahan_angle(x[0], x[1], x[2]) for x in xs]
+    assert np.mean(angles) > 3.0, np.mean(angles)
+    assert np.amax(np.abs(xs - 5.0)) < 15.0 and np.all(np.isfinite(xs))
