@@ -311,3 +311,21 @@ def test_execute_batch_sparse_validation_and_values(co, harmonic_bond):
         np.testing.assert_array_equal(du_dx[k], r[0])
         np.testing.assert_array_equal(du_dp[k], r[1])
         assert u[k] == r[2]
+
+
+def test_context_without_nonbonded_potentials_performs_no_box_check(co, P):
+    """tests/test_md.py:946-976: the box-vs-cutoff validation belongs to the nonbonded all-pairs potentials a Context finds among
+    its bound potentials; with bonded terms only, a tiny box is accepted.  Plus the set_v_t size message (:118-120)."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = ts.add_chain_ligand(ts.build_water_box(64, 2.7, seed=3), 8, lamb=0.0)
+    bonded = [bp for bp in ts.bound_potentials(s) if not isinstance(bp.potential, (P.Nonbonded, P.NonbondedInteractionGroup))]
+    assert 2 <= len(bonded) < len(ts.bound_potentials(s))
+    bps = [bp.to_gpu(np.float32).bound_impl for bp in bonded]
+    ctxt = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.5e-3, 0.0, s.masses, 2022).impl(), bps)
+    ctxt.set_box(s.box * 0.01)
+    _, boxes = ctxt.multiple_steps(1)
+    assert len(boxes) == 1
+    with pytest.raises(RuntimeError, match="number of new velocities disagree with current coords"):
+        ctxt.set_v_t(np.zeros((s.num_atoms - 1, 3)))
