@@ -150,3 +150,80 @@ def test_hilbert_sort_makes_compact_blocks(co, block_size):
     perm = co.HilbertSort(len(coords)).sort(coords, s.box)
     assert sorted(perm.tolist()) == list(range(len(coords)))
     assert mean_max_block_distance(coords[perm]) < 0.6 * mean_max_block_distance(coords)
+
+
+@pytest.mark.parametrize("tiles", [2, 10, 100])
+def test_nblist_max_interactions(co, tiles):
+    """tests/test_nblist.py:366-383: every atom within the cutoff of every other -- the list fills its worst-case buffers exactly."""
+    rng = np.random.default_rng(2023)
+    block_size, cutoff = 32, 10.0
+    coords = rng.random(size=(block_size * tiles, 3))
+    box = np.eye(3) * 100.0
+    nblist = co.Neighborlist_f32(coords.shape[0])
+    max_ixn_count = nblist.get_max_ixn_count()
+    ixn_list = nblist.get_nblist(coords, box, cutoff)
+    assert len(ixn_list) == tiles
+    n = len(coords)
+    for i, cols in enumerate(ixn_list):
+        # upper-triangular list: row block i sees its own block's and every later block's atoms, all of them
+        assert sorted(cols) == list(range(i * block_size, n))
+    assert nblist.get_tile_ixn_count() * block_size == max_ixn_count
+
+
+@pytest.mark.parametrize("num_atoms", [35, 129, 1025])
+def test_nblist_row_indices_are_order_independent(co, num_atoms):
+    """tests/test_nblist.py:188-233: the same row subset in a different order lists the same interactions (as a set; the
+    per-block lists follow the order given), in both precisions."""
+    from oracle import nblist as onblist
+
+    rng = np.random.default_rng(1234)
+    coords = rng.uniform(0, 1, size=(num_atoms, 3)) * (num_atoms / 100.0) ** (1 / 3)  # water-like number density
+    box = np.diag(coords.max(0) - coords.min(0) + 0.1 + 2.2)  # > 2 * cutoff in every dimension
+    rows = rng.choice(num_atoms, num_atoms // 2, replace=False).astype(np.uint32)
+    shuffled = rows.copy()
+    rng.shuffle(shuffled)
+    assert not np.all(shuffled == rows)
+    ref = onblist.brute_force_ixn_list_rows(coords, box, 1.0, rows)
+    ref_shuffled = onblist.brute_force_ixn_list_rows(coords, box, 1.0, shuffled)
+    all_ref = set(np.concatenate([np.asarray(b, dtype=np.int64) for b in ref]).tolist())
+    assert all_ref == set(np.concatenate([np.asarray(b, dtype=np.int64) for b in ref_shuffled]).tolist())
+    for cls in (co.Neighborlist_f32, co.Neighborlist_f64):
+        nb = cls(num_atoms)
+        for idxs, expect in ((rows, ref), (shuffled, ref_shuffled)):
+            nb.set_row_idxs(idxs)
+            test = nb.get_nblist(coords, box, 1.0)
+            assert len(test) == len(expect)
+            for a, b in zip(expect, test):
+                assert sorted(a) == sorted(b)
+
+
+@pytest.mark.parametrize("cutoff", [1.0, 1.2])
+def test_nblist_density_of_a_dhfr_sized_box(co, cutoff):
+    """tests/test_nblist.py:459-472: in Hilbert order the mean fraction of a listed 32 x 32 tile's slots that are inside the
+    cutoff is above 10 % (DHFR-sized synthetic water box; measured here: about 30 %), and well above the unsorted value."""
+    from timemachine_amd import testsystems as ts
+
+    s = ts.dhfr_sized_water_box()
+    rng = np.random.default_rng(5)
+    mol_order = rng.permutation(s.num_atoms // 3)
+    coords = s.coords.reshape(-1, 3, 3)[mol_order].reshape(-1, 3)
+    L = np.diagonal(s.box)
+    nblist = co.Neighborlist_f32(len(coords))
+
+    def mean_tile_density(x):
+        lists = nblist.get_nblist(x, s.box, cutoff)
+        dens = []
+        for i in list(range(0, len(lists), 37)):  # a sample of the row blocks keeps the numpy side in seconds
+            cols = np.asarray(lists[i], dtype=np.int64)
+            rows = x[i * 32:(i + 1) * 32]
+            for cb in np.unique(cols // 32):
+                c = cols[cols // 32 == cb]
+                d = rows[:, None, :] - x[c][None, :, :]
+                d -= L * np.rint(d / L)
+                dens.append(((d ** 2).sum(-1) < cutoff * cutoff).sum() / 1024.0)
+        return float(np.mean(dens))
+
+    unsorted = mean_tile_density(coords)
+    perm = co.HilbertSort(len(coords)).sort(coords, s.box)
+    density = mean_tile_density(coords[perm])
+    assert density > 0.10 and density > 2.0 * unsorted, (density, unsorted)
