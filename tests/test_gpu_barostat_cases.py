@@ -175,3 +175,39 @@ def test_molecular_ideal_gas(co, relaxed):
             vols.append(np.prod(np.diagonal(ctxt.get_box())))
         actual.append(np.mean(vols[len(vols) // 2:]))
     np.testing.assert_allclose(actual, expected, rtol=1e-2)
+
+
+def test_barostat_scaling_behavior(co, relaxed):
+    """tests/test_barostat.py:579-665: the volume scale factor can be read and set; adaptation shrinks an absurd factor,
+    leaves a zero factor at zero when switched off, and moves it again when switched back on; the constructor's initial
+    factor and flag are kept."""
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s, groups, x, v = relaxed
+    u_impls = make_bps(s)
+    baro = co.MonteCarloBarostat(s.num_atoms, 1.013, 300.0, groups, 3, u_impls, 2021, True, 0.0)
+    assert baro.get_volume_scale_factor() == 0.0
+    assert baro.get_adaptive_scaling()
+    ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, 1.5e-3, 1.0, s.masses, 2021).impl(), u_impls, movers=[baro])
+    ctxt.multiple_steps(15)
+    scaling = baro.get_volume_scale_factor()
+    assert scaling > 0
+    bad = 0.5 * volume(s.box)
+    baro.set_volume_scale_factor(bad)
+    assert baro.get_volume_scale_factor() == bad
+    ctxt.multiple_steps(100)
+    assert bad > baro.get_volume_scale_factor()
+    baro.set_volume_scale_factor(scaling)
+    assert scaling == baro.get_volume_scale_factor()
+    baro.set_volume_scale_factor(0.0)
+    baro.set_adaptive_scaling(False)
+    assert not baro.get_adaptive_scaling()
+    ctxt.multiple_steps(100)
+    assert baro.get_volume_scale_factor() == 0.0
+    baro.set_adaptive_scaling(True)
+    assert baro.get_adaptive_scaling()
+    ctxt.multiple_steps(100)
+    assert baro.get_volume_scale_factor() != 0.0
+    baro = co.MonteCarloBarostat(s.num_atoms, 1.013, 300.0, groups, 3, u_impls, 2021, False, 1.23)
+    assert not baro.get_adaptive_scaling()
+    assert baro.get_volume_scale_factor() == 1.23
