@@ -502,6 +502,14 @@ def test_config5_sized_hrex_iteration(co, P):
 # ----------------------------------------------------------------------------------------------------------------
 # the RCCL code path of timemachine_amd.parallel on the one GPU a test box has: a one-rank "nccl" group
 # ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 _NCCL_ONE_RANK = r"""
 import os, sys
 import numpy as np
@@ -529,7 +537,7 @@ def test_parallel_collectives_run_over_rccl_on_one_rank():
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", TM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), TM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _NCCL_ONE_RANK, repo], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "NCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -543,7 +551,7 @@ def test_bench_modes_run_with_rccl_collectives_on_one_rank(mode):
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29654" if mode == "md" else "29655", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                TM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--mode", mode, "--no-cpu-baseline", "--profile-steps", "0", "--equil-scale", "0.1"]
     cmd += ["--steps", "100", "--warmup", "20"] if mode == "md" else ["--steps", "40", "--warmup", "20", "--steps-per-frame", "20", "--windows", "4"]
