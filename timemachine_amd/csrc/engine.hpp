@@ -105,6 +105,9 @@ public:
     bool run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
              std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0, u64 *d_du_dx_cm = nullptr,
              const int cm_stride = 0);
+    // after run(): did anything go to d_du_dx_cm?  (false when every table rode on a potential that took it into its own
+    // accumulator: the consumer can skip reading and re-zeroing the array)
+    bool cm_written() const { return cm_written_; }
 
 private:
     FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
@@ -112,6 +115,7 @@ private:
     bool uploaded_valid_[2] = {false, false};
     DeviceBuffer<FusedTable> d_table_[2];
     std::vector<Rest> rest_;
+    bool cm_written_ = true;
 };
 
 class Potential {
@@ -128,6 +132,9 @@ public:
         const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) {
         return false;
     }
+    // after an accepted offer: will the table's forces land in this potential's own accumulator (delivered with its own
+    // forces) instead of `acc`?  The plan then reports `acc` as untouched.
+    virtual bool piggyback_lands_in_own_accumulator() const { return false; }
     // Forces-only evaluation that leaves the result in the potential's own accumulator (see DeferredForces) instead of
     // adding it to a du_dx array.  A piggy-backed table still accumulates into d_du_dx.  false = not supported.
     virtual bool execute_forces_deferred(
@@ -427,6 +434,7 @@ public:
     std::vector<int> get_atom_idxs();
     int get_num_atom_idxs() const { return K_; }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
+    bool piggyback_lands_in_own_accumulator() const override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
@@ -479,6 +487,7 @@ protected:
     int piggyback_blocks_ = 0;
     u64 *piggyback_acc_ = nullptr; // where the piggy-backed table's forces go, and its layout
     int piggyback_atom_stride_ = 3, piggyback_comp_stride_ = 1;
+    bool piggyback_redirect_ = false; // the pending table accumulates into g_du_dx through slot_of_atom
 };
 
 // reference: cpp/src/nonbonded_interaction_group.{hpp,cu}.  Row atoms x column atoms (disjoint sets); both groups are

@@ -44,6 +44,7 @@ bool ForcePlan::run(
     const ForceLayout table_fl = d_du_dx_cm ? ForceLayout{1, cm_stride} : ForceLayout{3, 1};
     // 1. tables to the device (only when they changed since the last step)
     bool pending[2] = {false, false};
+    bool table_went_to_acc = false; // a table's forces were (or will be) added to table_acc
     for (int prec = 0; prec < 2; prec++) {
         FusedTable &t = host_[prec];
         if (t.n == 0) {
@@ -72,6 +73,7 @@ bool ForcePlan::run(
             if (pending[prec] &&
                 r.pot->piggyback_forces(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4, table_acc, table_fl.atom, table_fl.comp)) {
                 pending[prec] = false;
+                table_went_to_acc = table_went_to_acc || !r.pot->piggyback_lands_in_own_accumulator();
             }
         }
     }
@@ -97,6 +99,7 @@ bool ForcePlan::run(
         if (!pending[prec]) {
             continue;
         }
+        table_went_to_acc = true;
         const int blocks = host_[prec].block_end[host_[prec].n - 1];
         const int prof = Profiler::get().begin("fused_forces", stream);
         if (prec == 1) {
@@ -107,8 +110,10 @@ bool ForcePlan::run(
         HIP_CHECK(hipGetLastError());
         Profiler::get().end("fused_forces", prof, stream);
     }
-    // the table's terms (piggy-backed or launched above) went to table_acc
-    return wrote_du_dx || table_acc == d_du_dx;
+    // the table's terms (piggy-backed or launched above) went to table_acc -- unless a potential took them into its own
+    // accumulator
+    cm_written_ = table_went_to_acc && table_acc == d_du_dx_cm && d_du_dx_cm != nullptr;
+    return wrote_du_dx || (table_went_to_acc && table_acc == d_du_dx);
 }
 
 } // namespace tmamd

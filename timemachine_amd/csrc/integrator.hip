@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 // wrapping integer sum: same bits as a scatter-add of every contribution into one array would give
-                u64 f = du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+                u64 f = 0;
+                if (du_dx_cm != nullptr) { // nullptr: nothing was added to it this step (ForcePlan::cm_written)
+                    f = du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+                    du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
+                }
                 if (du_dx != nullptr) { // nullptr: nothing was added to the [N, 3] array this step (it stays zero)
                     f += du_dx[atom * 3 + d];
                     du_dx[atom * 3 + d] = 0; // consumed: the next force evaluation accumulates from zero
@@ -161,7 +165,6 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 v_t[atom * 3 + d] = static_cast<double>(v_new);
                 xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
                 x_t[atom * 3 + d] = xn[d];
-                du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
             }
             pregather_atom(pg0, s0, atom, xn[0], xn[1], xn[2]);
             pregather_atom(pg1, s1, atom, xn[0], xn[1], xn[2]);
@@ -171,7 +174,9 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
                 if (du_dx != nullptr) {
                     du_dx[kidx * 3 + d] = 0;
                 }
-                du_dx_cm[static_cast<size_t>(d) * cm_stride + kidx] = 0;
+                if (du_dx_cm != nullptr) {
+                    du_dx_cm[static_cast<size_t>(d) * cm_stride + kidx] = 0;
+                }
             }
         }
     }
@@ -208,19 +213,21 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
         double xn[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            u64 f = du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+            u64 f = g0[static_cast<size_t>(d) * stride0 + slot];
+            if (du_dx_cm != nullptr) { // nullptr: nothing was added to it this step (ForcePlan::cm_written)
+                f += du_dx_cm[static_cast<size_t>(d) * cm_stride + atom];
+                du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
+            }
             if (du_dx != nullptr) {
                 f += du_dx[atom * 3 + d];
                 du_dx[atom * 3 + d] = 0;
             }
-            f += g0[static_cast<size_t>(d) * stride0 + slot];
             const Real force = -fixed_to_float<Real>(f);
             const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
             const Real v_new = ca * v_mid + cc * nz[d];
             v_t[atom * 3 + d] = static_cast<double>(v_new);
             xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
             x_t[atom * 3 + d] = xn[d];
-            du_dx_cm[static_cast<size_t>(d) * cm_stride + atom] = 0;
             p[d] = static_cast<GReal>(xn[d]);
         }
         pregather_atom_as<GReal>(pg, slot, atom, xn[0], xn[1], xn[2]);
@@ -290,6 +297,7 @@ void LangevinIntegrator<Real>::step_fwd(
     }
     deferred_.clear();
     const bool wrote_du_dx = plan_.run(N_, d_x_t, d_box_t, d_du_dx_.data, stream, &deferred_, 2, d_du_dx_cm_.data, cm_stride_);
+    u64 *cm = plan_.cm_written() ? d_du_dx_cm_.data : nullptr; // untouched this step: the update kernels skip it
     const DeferredForces none;
     const DeferredForces &df0 = deferred_.size() > 0 ? deferred_[0] : none;
     const DeferredForces &df1 = deferred_.size() > 1 ? deferred_[1] : none;
@@ -306,17 +314,17 @@ void LangevinIntegrator<Real>::step_fwd(
         u64 *dx = wrote_du_dx ? d_du_dx_.data : nullptr;
         if (df0.next.real_bytes == 8) {
             k_update_forward_baoab_sorted<Real, double><<<ceil_divide(N_, 64), 64, 0, stream>>>(
-                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
         } else {
             k_update_forward_baoab_sorted<Real, float><<<ceil_divide(N_, 64), 64, 0, stream>>>(
-                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, d_du_dx_cm_.data, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
         }
     } else {
         PregatherTarget t0 = pregather ? df0.next : no_target, t1 = pregather ? df1.next : no_target;
         t0.nbl_counters = nullptr; // the atom-order kernel leaves no block bounds: the producer's own bounds kernel resets them
         t1.nbl_counters = nullptr;
         k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
-            N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, d_du_dx_cm_.data, cm_stride_, dt_,
+            N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, cm, cm_stride_, dt_,
             df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1);
     }
     HIP_CHECK(hipGetLastError());

@@ -27,11 +27,16 @@ template <typename Real> __device__ __forceinline__ void store_wave_energy(i128 
 // Potential interface; the integrators' own accumulator is component-major {1, stride}: lanes working on neighbouring
 // atoms then share cache lines, and memory-side atomics are served one 64-byte line request at a time
 // (scripts/microbench/atomic_scope.hip: 64 lanes on 64 different lines cost 6.6x what 64 lanes on 8 lines cost).
+// `remap` (optional): the accumulator is indexed by remap[atom] instead of atom -- a nonbonded potential that covers every atom
+// takes the step's bonded terms into its own Hilbert-ordered accumulator (remap = its slot_of_atom), and the integrator then
+// finds the whole force of an atom in one place.
 struct ForceLayout {
     int atom, comp;
+    const int *remap = nullptr;
+    __device__ __forceinline__ size_t row(const int a) const { return static_cast<size_t>(remap ? remap[a] : a) * atom; }
 };
 __device__ __forceinline__ void force_add(u64 *__restrict__ du_dx, const ForceLayout fl, const int atom, const int d, const u64 v) {
-    atomicAdd(du_dx + static_cast<size_t>(atom) * fl.atom + static_cast<size_t>(d) * fl.comp, v);
+    atomicAdd(du_dx + fl.row(atom) + static_cast<size_t>(d) * fl.comp, v);
 }
 
 // term `b` of the list; returns its energy in fixed point (0 unless want_u)

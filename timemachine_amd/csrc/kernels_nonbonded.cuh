@@ -250,8 +250,10 @@ __device__ __forceinline__ i128 nonbonded_pair_list_term(
 
 // One 256-term block of a ForcePlan table (engine.hpp): bonded terms and pair lists, forces only.  Defined at the end of
 // this header; called by k_fused_forces and by the tail of the tile kernel.
+// (a real call, not inlined: inside the tile kernel its registers would be allocated together with the item loop's, and the
+// f64 kernels sit at their 168-VGPR limit -- with the bonded terms inlined, any change to them moved spills into that loop)
 template <typename Real>
-__device__ __forceinline__ void fused_dispatch(
+__device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
     const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl);
 
@@ -284,7 +286,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
     const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
-    const int out_atom_stride, const int out_comp_stride, // layout of out_du_dx (ForceLayout)
+    const int out_atom_stride, const int out_comp_stride, const int *__restrict__ out_remap, // layout of out_du_dx (ForceLayout)
     long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
 
     constexpr int WAVES = TileShape<Real, COMPUTE_DU_DP>::waves;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             // costs nothing, the others 8-10 us per launch).
             // slice t goes to workgroup t % G, wave (t / G) % WAVES: every CU takes the same share
             for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
-                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride});
+                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride, out_remap});
             }
         }
     }
@@ -526,7 +528,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         // min_image without changing a bit.
         bool compact, needs_order, raw_compact;
         {
-            const Real rbx = static_cast<Real>(0.245) * bx.x, rby = static_cast<Real>(0.245) * bx.y, rbz = static_cast<Real>(0.245) * bx.z;
+            // (the factor goes through an empty asm so that the three products are formed here, once per item, instead of being
+            // hoisted out of the item loop into six registers that the f64 kernels do not have to spare)
+            Real quarter = static_cast<Real>(0.245);
+            asm volatile("" : "+v"(quarter));
+            const Real rbx = quarter * bx.x, rby = quarter * bx.y, rbz = quarter * bx.z;
             bool raw_far = ja < uK && !(fabs(cur.cj[0] - cur.ox) < rbx && fabs(cur.cj[1] - cur.oy) < rby && fabs(cur.cj[2] - cur.oz) < rbz);
             if (lane < TILE && cur.ra < uK) {
                 raw_far = raw_far || !(fabs(cur.rr[0] - cur.ox) < rbx && fabs(cur.rr[1] - cur.oy) < rby && fabs(cur.rr[2] - cur.oz) < rbz);
@@ -916,12 +922,13 @@ do {                                                                            
         if (du_dx) {
             u64 fx, fy, fz;
             pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
-            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 0 * static_cast<size_t>(fl.comp), fx);
-            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 1 * static_cast<size_t>(fl.comp), fy);
-            TM_ACC(du_dx + static_cast<size_t>(ia) * fl.atom + 2 * static_cast<size_t>(fl.comp), fz);
-            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 0 * static_cast<size_t>(fl.comp), 0ull - fx);
-            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 1 * static_cast<size_t>(fl.comp), 0ull - fy);
-            TM_ACC(du_dx + static_cast<size_t>(ja) * fl.atom + 2 * static_cast<size_t>(fl.comp), 0ull - fz);
+            const size_t ri = fl.row(ia), rj = fl.row(ja);
+            TM_ACC(du_dx + ri + 0 * static_cast<size_t>(fl.comp), fx);
+            TM_ACC(du_dx + ri + 1 * static_cast<size_t>(fl.comp), fy);
+            TM_ACC(du_dx + ri + 2 * static_cast<size_t>(fl.comp), fz);
+            TM_ACC(du_dx + rj + 0 * static_cast<size_t>(fl.comp), 0ull - fx);
+            TM_ACC(du_dx + rj + 1 * static_cast<size_t>(fl.comp), 0ull - fy);
+            TM_ACC(du_dx + rj + 2 * static_cast<size_t>(fl.comp), 0ull - fz);
         }
         if (du_dp) {
             TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
@@ -1054,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_nonbonded_precomputed(
 }
 
 template <typename Real>
-__device__ __forceinline__ void fused_dispatch(
+__device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
     const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl) {
     const int n = table->n;

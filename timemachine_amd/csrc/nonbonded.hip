@@ -584,8 +584,14 @@ bool NonbondedAllPairs<Real>::piggyback_forces(
     piggyback_acc_ = acc;
     piggyback_atom_stride_ = atom_stride;
     piggyback_comp_stride_ = comp_stride;
+    // A potential that covers every atom takes the table's forces into its own Hilbert-ordered accumulator: whoever consumes
+    // that accumulator (the un-permute pass, or the integrator through a deferred hand-over) then finds bonded and
+    // nonbonded forces of an atom in one place, and the caller's accumulator is not touched.
+    piggyback_redirect_ = K_ == N_ && group_rows_ == 0;
     return true;
 }
+
+template <typename Real> bool NonbondedAllPairs<Real>::piggyback_lands_in_own_accumulator() const { return piggyback_table_ != nullptr && piggyback_redirect_; }
 
 template <typename Real> std::vector<long long> NonbondedAllPairs<Real>::debug_timing() {
     std::vector<long long> raw(static_cast<size_t>(grid_) * 8);
@@ -722,7 +728,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     k_nonbonded_tiles<Real, U, X, PP, ##__VA_ARGS__><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
-        d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, piggyback_acc_, piggyback_atom_stride_, piggyback_comp_stride_, \
+        d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, pig_acc, pig_atom_stride, pig_comp_stride, pig_remap, \
         d_timing_.data)
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
     int launched_waves = 0; // waves of this launch = energy partials it writes
@@ -731,6 +737,10 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // back to its owner's stand-alone path by never having accepted it (the plan only offers it for forces-only calls)
     const FusedTable *pig_table = sel == 2 ? piggyback_table_ : nullptr;
     const int pig_blocks = sel == 2 ? piggyback_blocks_ : 0;
+    const bool pig_redirect = pig_table != nullptr && piggyback_redirect_;
+    u64 *pig_acc = pig_redirect ? d_g_du_dx_.data : piggyback_acc_;
+    const int pig_atom_stride = pig_redirect ? 1 : piggyback_atom_stride_, pig_comp_stride = pig_redirect ? acc_stride_ : piggyback_comp_stride_;
+    const int *pig_remap = pig_redirect ? d_slot_of_atom_.data : nullptr;
     if (piggyback_table_ != nullptr && sel != 2) {
         throw std::runtime_error("NonbondedAllPairs: a piggy-backed force table is pending but this call is not forces-only");
     }
