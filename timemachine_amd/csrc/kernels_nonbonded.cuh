@@ -546,16 +546,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 const float4 r4 = s_rowf_mine;
                 rfrac = fmaxf(fabsf(r4.x) * fibx, fmaxf(fabsf(r4.y) * fiby, fabsf(r4.z) * fibz));
             }
-            if constexpr (F64) {
-                // (the f64 kernels sit at their 168-VGPR limit: the DPP form below needs one register more at this point and
-                // put three scratch accesses into the item loop -- 3.6 % slower -- so they keep the shuffle butterfly)
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    rfrac = fmaxf(rfrac, __shfl_xor(rfrac, o, 64));
-                }
-            } else {
-                rfrac = wave_max_low_half_nonneg(rfrac); // VALU only; the butterfly is six dependent LDS round trips per item (f32: +1.9 %)
-            }
+            rfrac = wave_max_low_half_nonneg(rfrac); // VALU only; the shuffle butterfly it replaces was six dependent LDS round trips per item
             compact = __ballot(!(cfrac + rfrac < 0.49f)) == 0ull;
             needs_order = upper_triangular && __ballot(col_live && ja <= row_first + (TILE - 1)) != 0ull;
         }
