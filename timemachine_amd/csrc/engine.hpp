@@ -85,6 +85,9 @@ struct DeferredForces {
     const int *slot_of_atom = nullptr;
     PregatherTarget next;       // gathered == nullptr: the producer does not take pre-gathered positions
     Potential *owner = nullptr; // to be told (pregather_committed) once a kernel filling `next` has been enqueued
+    // this call consumed a SORTED hand-over: inputs, parameters and the order (perm) are exactly what the consumer that
+    // filled it last left behind -- a consumer that keeps per-slot state of its own may trust it for this step
+    bool consumed_sorted_pregather = false;
 };
 class ForcePlan {
 public:
@@ -547,6 +550,8 @@ public:
     virtual void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
     virtual void initialize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
     virtual void finalize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
+    // coordinates or velocities were changed behind the integrator's back (Context setters, movers): drop derived state
+    virtual void invalidate_state_cache() {}
 };
 
 template <typename Real> class LangevinIntegrator : public Integrator {
@@ -556,6 +561,7 @@ public:
     void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
     void initialize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
     void finalize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
+    void invalidate_state_cache() override { state_cache_valid_ = false; }
 private:
     const int N_;
     const double temperature_;
@@ -565,6 +571,15 @@ private:
     unsigned long long seed_;
     unsigned long long step_;
     DeviceBuffer<Real> d_cbs_, d_ccs_;
+    // x, v, cb, cc once more in the SLOT order of the nonbonded producer whose sorted hand-over the update kernel walks
+    // (k_update_forward_baoab_sorted): written every sorted step, read instead of the atom-order arrays -- one dependent
+    // memory hop less per atom -- whenever the producer confirms that nothing changed since (DeferredForces::
+    // consumed_sorted_pregather) and nobody touched x / v behind the integrator's back
+    DeviceBuffer<double> d_xs_, d_vs_;
+    DeviceBuffer<Real> d_cbs_s_, d_ccs_s_;
+    bool state_cache_valid_ = false;
+    const void *cache_owner_ = nullptr;
+    const double *cache_x_ = nullptr, *cache_v_ = nullptr;
     DeviceBuffer<u64> d_du_dx_;    // [N, 3]: what potentials that launch their own kernels add to
     int cm_stride_;
     DeviceBuffer<u64> d_du_dx_cm_; // component-major [3][cm_stride_]: what the fused table's terms add to

@@ -188,12 +188,16 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
 // 32-atom blocks of the producer's order, their bounding boxes (the input of a neighbor-list build) fall out of five
 // shuffle steps per dimension, every step -- the producer's bounds kernel is not launched on MD steps at all.
 // Same arithmetic, same Philox counters (keyed by atom) as the atom-order kernel: trajectories are bit-identical.
-template <typename Real, typename GReal>
+// FROM_CACHE: x, v, cb, cc come from the integrator's slot-ordered copies (xs, vs, cbs_s, ccs_s; see LangevinIntegrator) instead
+// of the atom-order arrays behind perm: every load of the update is then one coalesced hop; perm is still read, in parallel,
+// for the noise key and the scattered stores.  The copies are (re)written on every launch.
+template <typename Real, typename GReal, bool FROM_CACHE>
 __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
     const int N, const Real ca, const Real *__restrict__ cbs, const Real *__restrict__ ccs, const unsigned long long seed,
     const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t, u64 *__restrict__ du_dx,
     u64 *__restrict__ du_dx_cm, const int cm_stride, const Real dt, const u64 *__restrict__ g0, const int stride0,
-    const double *__restrict__ box, const PregatherTarget pg) {
+    const double *__restrict__ box, const PregatherTarget pg, double *__restrict__ xs, double *__restrict__ vs,
+    Real *__restrict__ cbs_s, Real *__restrict__ ccs_s) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *pg.flag_clear = 0; // the flag of the call just consumed becomes the one after next's
     }
@@ -203,8 +207,27 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
     GReal p[3] = {0, 0, 0}; // the new position as the producer's record stores it
     if (valid) {
         const int atom = static_cast<int>(pg.perm[slot]);
-        const Real cb = cbs[atom];
-        const Real cc = ccs[atom];
+        Real cb, cc;
+        double xo[3], vo[3];
+        if constexpr (FROM_CACHE) {
+            cb = cbs_s[slot];
+            cc = ccs_s[slot];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                xo[d] = xs[slot * 3 + d];
+                vo[d] = vs[slot * 3 + d];
+            }
+        } else {
+            cb = cbs[atom];
+            cc = ccs[atom];
+            cbs_s[slot] = cb;
+            ccs_s[slot] = cc;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                xo[d] = x_t[atom * 3 + d];
+                vo[d] = v_t[atom * 3 + d];
+            }
+        }
         Real nz[3] = {0, 0, 0};
         if (cc != 0) {
             normal3(seed, step, static_cast<unsigned int>(atom), nz);
@@ -223,11 +246,13 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
                 du_dx[atom * 3 + d] = 0;
             }
             const Real force = -fixed_to_float<Real>(f);
-            const Real v_mid = static_cast<Real>(v_t[atom * 3 + d] + static_cast<double>(cb * force));
+            const Real v_mid = static_cast<Real>(vo[d] + static_cast<double>(cb * force));
             const Real v_new = ca * v_mid + cc * nz[d];
             v_t[atom * 3 + d] = static_cast<double>(v_new);
-            xn[d] = x_t[atom * 3 + d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
+            vs[slot * 3 + d] = static_cast<double>(v_new);
+            xn[d] = xo[d] + static_cast<double>(half_dt) * (static_cast<double>(v_mid) + static_cast<double>(v_new));
             x_t[atom * 3 + d] = xn[d];
+            xs[slot * 3 + d] = xn[d];
             p[d] = static_cast<GReal>(xn[d]);
         }
         pregather_atom_as<GReal>(pg, slot, atom, xn[0], xn[1], xn[2]);
@@ -266,7 +291,7 @@ template <typename Real>
 LangevinIntegrator<Real>::LangevinIntegrator(
     const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed)
     : N_(N), temperature_(temperature), dt_(static_cast<Real>(dt)), friction_(friction), seed_(static_cast<unsigned long long>(static_cast<long long>(seed))),
-      step_(0), d_cbs_(N), d_ccs_(N), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7), d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
+      step_(0), d_cbs_(N), d_ccs_(N), d_xs_(static_cast<size_t>(N) * 3), d_vs_(static_cast<size_t>(N) * 3), d_cbs_s_(N), d_ccs_s_(N), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7), d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
     ca_ = static_cast<Real>(std::exp(-friction * dt));
     const double kT = BOLTZ * temperature;
     const double ccs_adjustment = std::sqrt(1 - std::exp(-2 * friction * dt));
@@ -312,17 +337,37 @@ void LangevinIntegrator<Real>::step_fwd(
     const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n == N_ && df0.next.perm != nullptr;
     if (sorted) {
         u64 *dx = wrote_du_dx ? d_du_dx_.data : nullptr;
+        // the slot-ordered copies of x, v, cb, cc are current iff the last launch here wrote them for this producer and these
+        // arrays, the producer has just consumed the hand-over that launch left (same inputs, same order), and nobody has
+        // touched x / v since (invalidate_state_cache)
+        const bool from_cache = state_cache_valid_ && df0.consumed_sorted_pregather && cache_owner_ == df0.owner && cache_x_ == d_x_t && cache_v_ == d_v_t;
+#define TM_LAUNCH_SORTED(GREAL, CACHE)                                                                                 \
+    k_update_forward_baoab_sorted<Real, GREAL, CACHE><<<ceil_divide(N_, 64), 64, 0, stream>>>(                           \
+        N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next, \
+        d_xs_.data, d_vs_.data, d_cbs_s_.data, d_ccs_s_.data)
         if (df0.next.real_bytes == 8) {
-            k_update_forward_baoab_sorted<Real, double><<<ceil_divide(N_, 64), 64, 0, stream>>>(
-                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+            if (from_cache) {
+                TM_LAUNCH_SORTED(double, true);
+            } else {
+                TM_LAUNCH_SORTED(double, false);
+            }
         } else {
-            k_update_forward_baoab_sorted<Real, float><<<ceil_divide(N_, 64), 64, 0, stream>>>(
-                N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next);
+            if (from_cache) {
+                TM_LAUNCH_SORTED(float, true);
+            } else {
+                TM_LAUNCH_SORTED(float, false);
+            }
         }
+#undef TM_LAUNCH_SORTED
+        state_cache_valid_ = true;
+        cache_owner_ = df0.owner;
+        cache_x_ = d_x_t;
+        cache_v_ = d_v_t;
     } else {
         PregatherTarget t0 = pregather ? df0.next : no_target, t1 = pregather ? df1.next : no_target;
         t0.nbl_counters = nullptr; // the atom-order kernel leaves no block bounds: the producer's own bounds kernel resets them
         t1.nbl_counters = nullptr;
+        state_cache_valid_ = false; // this kernel does not maintain the slot-ordered copies
         k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
             N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, cm, cm_stride_, dt_,
             df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1);
@@ -518,6 +563,7 @@ void Context::invalidate_potential_inputs() {
     for (auto &bp : bps_) {
         bp->potential->invalidate_cached_inputs();
     }
+    intg_->invalidate_state_cache(); // coordinates (setters, movers) changed behind the integrator's back as well
 }
 
 void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box) {
@@ -576,7 +622,10 @@ void Context::set_x_t(const double *in) {
     d_x_t_.copy_from(in);
     this->invalidate_potential_inputs();
 }
-void Context::set_v_t(const double *in) { d_v_t_.copy_from(in); }
+void Context::set_v_t(const double *in) {
+    d_v_t_.copy_from(in);
+    intg_->invalidate_state_cache();
+}
 void Context::set_box(const double *in) {
     d_box_t_.copy_from(in);
     this->invalidate_potential_inputs();

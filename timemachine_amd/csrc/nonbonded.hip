@@ -618,6 +618,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     // these inputs and the order they were written in still stands (no re-sort, no forced rebuild on this call)
     const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
                              calls_since_sort_ % steps_per_sort_ != 0;
+    out.consumed_sorted_pregather = pregathered && pre_sorted_;
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream, pregathered);
     out.g_du_dx = d_g_du_dx_.data;
     out.stride = acc_stride_;
