@@ -136,7 +136,10 @@ static const int NBL_TRIP = TM_NBL_TRIP; // rows tested per trip of the fine pas
 #endif
 static const int NBL_COST_STRIDE = TM_NBL_COST_STRIDE; // cost estimates sample every 4th row (lane-staggered start)
 static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
-static const int NBL_CAND_CAP = 3072; // accepted column atoms per row block staged in LDS (48 KB; a 1.3 nm list at water density holds ~2100)
+#ifndef TM_NBL_CAND_CAP
+#define TM_NBL_CAND_CAP 3072
+#endif
+static const int NBL_CAND_CAP = TM_NBL_CAND_CAP; // accepted column atoms per row block staged in LDS (48 KB; a 1.3 nm list at water density holds ~2100)
 #ifndef TM_NBL_THREADS
 #define TM_NBL_THREADS 1024
 #endif
