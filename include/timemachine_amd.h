@@ -244,7 +244,7 @@ int tm_hilbert_lut(uint32_t *out);
 int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
-/* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.cuh):
+/* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.hip.hpp):
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
  * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */
 int tm_es_force_table(double beta, double *out);

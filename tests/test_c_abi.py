@@ -161,7 +161,7 @@ def test_committed_bench_lines_follow_the_contract():
 
 def test_es_force_table_matches_the_analytic_function():
     """The f64 kernels' tabulated electrostatic force factor F(d^2) = (D'(d)/d - D(d)/d^2)/d, D = erfc(beta d) S(d)
-    (csrc/nb_es_table.cuh) against the analytic form in numpy/scipy: <= 1e-11 relative over d in [0.0884, 1.2) nm, exactly
+    (csrc/nb_es_table.hip.hpp) against the analytic form in numpy/scipy: <= 1e-11 relative over d in [0.0884, 1.2) nm, exactly
     the interval layout the device indexes with the bits of d^2."""
     from scipy.special import erfc
 

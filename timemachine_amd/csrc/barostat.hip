@@ -6,8 +6,8 @@
 // the two uniforms come from a counter-based Philox4x32-10 keyed on (seed; attempt) inside the kernels instead of a
 // cuRAND batch buffer (statistically equivalent, reproducible per seed on this implementation only).
 #include "engine.hpp"
-#include "fixed_point.cuh"
-#include "philox.cuh"
+#include "fixed_point.hip.hpp"
+#include "philox.hip.hpp"
 
 #include <algorithm>
 #include <iostream>

@@ -1,6 +1,6 @@
-// HarmonicBond / HarmonicAngle / PeriodicTorsion host classes (device code: kernels_bonded.cuh).
+// HarmonicBond / HarmonicAngle / PeriodicTorsion host classes (device code: kernels_bonded.hip.hpp).
 // reference: cpp/src/harmonic_bond.cu, harmonic_angle.cu, periodic_torsion.cu
-#include "kernels_bonded.cuh"
+#include "kernels_bonded.hip.hpp"
 
 namespace tmamd {
 

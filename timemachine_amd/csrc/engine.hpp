@@ -4,7 +4,7 @@
 // C ABI in include/timemachine_amd.h is a 1:1 door onto it.  Everything device-side is HIP for gfx950.
 #pragma once
 #include "common.hpp"
-#include "nb_es_table.cuh"
+#include "nb_es_table.hip.hpp"
 
 #include <memory>
 #include <optional>
@@ -44,7 +44,7 @@ struct FusedSegment {
     const double *scales; // pair lists: [count][2]
     double beta, cutoff;  // pair lists
     const int *aux;       // chiral bond restraints: signs [count]
-    const double *es_table = nullptr; // pair lists, f64 kernels: the electrostatic force-factor table of `beta` (nb_es_table.cuh)
+    const double *es_table = nullptr; // pair lists, f64 kernels: the electrostatic force-factor table of `beta` (nb_es_table.hip.hpp)
 };
 struct FusedTable {
     int n;
@@ -76,7 +76,7 @@ struct PregatherTarget {
     const unsigned int *perm = nullptr;
     int sorted_n = 0;
     void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(sorted_n / 32)][3]
-    unsigned int *nbl_counters = nullptr;        // kernels_nonbonded.cuh: NB_NUM_COUNTERS words
+    unsigned int *nbl_counters = nullptr;        // kernels_nonbonded.hip.hpp: NB_NUM_COUNTERS words
 };
 class Potential;
 struct DeferredForces {

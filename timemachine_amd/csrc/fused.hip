@@ -1,10 +1,10 @@
 // ForcePlan: all bonded terms and pair lists of a step in one kernel launch per precision (see engine.hpp).
-// The per-term device functions are the ones the stand-alone kernels call (kernels_bonded.cuh, kernels_nonbonded.cuh),
+// The per-term device functions are the ones the stand-alone kernels call (kernels_bonded.hip.hpp, kernels_nonbonded.hip.hpp),
 // so a fused launch produces the same bits as separate launches.
 #include <cstring>
 
-#include "kernels_bonded.cuh"
-#include "kernels_nonbonded.cuh"
+#include "kernels_bonded.hip.hpp"
+#include "kernels_nonbonded.hip.hpp"
 #include "profiler.hpp"
 
 namespace tmamd {

@@ -9,8 +9,8 @@
 //    (ccs == 0) and statistically otherwise -- same contract as the reference's own tests (tests/test_md.py:142-247).
 //  * BOLTZ is the C++ value (cpp/src/constants.hpp:5), not the python one (timemachine/constants.py:5-8).
 #include "engine.hpp"
-#include "fixed_point.cuh"
-#include "philox.cuh"
+#include "fixed_point.hip.hpp"
+#include "philox.hip.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -81,7 +81,7 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
         *t.flag_set = 1; // benign race: every writer stores the same value
         if (t.nbl_counters != nullptr) {
             // sorted hand-over: whoever raises the flag also resets the list counters the coming build accumulates into
-            // (what the producer's bounds kernel does on the other paths; kernels_nblist.cuh).  Few atoms get here per step.
+            // (what the producer's bounds kernel does on the other paths; kernels_nblist.hip.hpp).  Few atoms get here per step.
             t.nbl_counters[0] = 0;
             t.nbl_counters[1] = 0;
             t.nbl_counters[2] = 0;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
         pregather_atom_as<GReal>(pg, slot, atom, xn[0], xn[1], xn[2]);
     }
     // bounding boxes of the two 32-slot blocks of this wave: every atom imaged next to the block's first one, butterfly
-    // min / max (the arithmetic of k_block_bounds<Real, false>, kernels_nblist.cuh)
+    // min / max (the arithmetic of k_block_bounds<Real, false>, kernels_nblist.hip.hpp)
     const GReal half = static_cast<GReal>(0.5);
     const int first = lane & 32;
     GReal lo[3], hi[3];

@@ -8,7 +8,7 @@
 // index-reversal bitwise symmetry the reference gets from __dmul_rn/__dadd_rn (cpp/src/gpu_utils.cuh:111-121).
 #pragma once
 #include "engine.hpp"
-#include "fixed_point.cuh"
+#include "fixed_point.hip.hpp"
 
 namespace tmamd {
 

@@ -14,7 +14,7 @@
 // "trim compaction" kernel); 64-wide ballots; every row block owns a fixed, worst-case-sized segment of the pool, so
 // its columns are contiguous and neither per-tile atomics nor a counting pass are needed.
 #pragma once
-#include "kernels_nonbonded.cuh"
+#include "kernels_nonbonded.hip.hpp"
 
 namespace tmamd {
 

@@ -24,8 +24,8 @@
 // Integer accumulation is associative, so none of this reordering changes a single bit of the result.
 #pragma once
 #include <type_traits>
-#include "kernels_bonded.cuh"
-#include "nb_pair.cuh"
+#include "kernels_bonded.hip.hpp"
+#include "nb_pair.hip.hpp"
 
 namespace tmamd {
 
@@ -281,7 +281,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const unsigned int items_cap,                  // bucket capacity: bucket b lives at items[b * items_cap ...]
     const int4 *__restrict__ items, const unsigned int *__restrict__ col_atoms,
     const Real *__restrict__ gathered, const double *__restrict__ box, const double beta_d, const double cutoff_d,
-    const double *__restrict__ es_table, // f64: the electrostatic force-factor table of beta (nb_es_table.cuh); f32: unused
+    const double *__restrict__ es_table, // f64: the electrostatic force-factor table of beta (nb_es_table.hip.hpp); f32: unused
     u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, const int acc_stride, i128 *__restrict__ u_partials,
     // piggy-backed ForcePlan table (forces-only launches; nullptr otherwise): every few waves run a 64-term slice of its
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)

@@ -12,7 +12,7 @@
 //   * degree-5 Chebyshev interpolants (6 coefficients = 48 B per interval, 256 intervals = 12 KB: lives in LDS in the
 //     tile kernel, L1/L2-resident global memory in the pair-list kernels); fitted on the host in long double from the
 //     analytic form above, continued smoothly through d = 1.2 (the kernels then select 0 for s >= 1.44, as the analytic
-//     code does), to <= 5e-12 relative -- tighter than the 3e-11 polynomials of the analytic f64 path (nb_math.cuh);
+//     code does), to <= 5e-12 relative -- tighter than the 3e-11 polynomials of the analytic f64 path (nb_math.hip.hpp);
 //   * s below the table (d < 0.088 nm: clashing atoms only) takes the analytic form behind a wave-uniform branch.
 // Every kernel that evaluates a pair (tiles, pair lists, exclusions, fused plan) goes through es_force_factor() with a
 // table made by the same host routine from the same beta, so excluded pairs still cancel bit for bit.  Energies and

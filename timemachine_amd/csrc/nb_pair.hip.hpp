@@ -14,9 +14,9 @@
 //   lj_prefactor = s_lj eps_ij s6 inv2 (48 s6 - 24);  u_lj = s_lj 4 eps_ij (s6 - 1) s6
 //   prefactor = es_prefactor - lj_prefactor
 #pragma once
-#include "fixed_point.cuh"
-#include "nb_es_table.cuh"
-#include "nb_math.cuh"
+#include "fixed_point.hip.hpp"
+#include "nb_es_table.hip.hpp"
+#include "nb_math.hip.hpp"
 
 namespace tmamd {
 
@@ -149,7 +149,7 @@ __device__ __forceinline__ void nb_pair(
     o.ebd = damping;
 }
 
-// ---------------- f64: electrostatic force factor from the table (nb_es_table.cuh) ----------------
+// ---------------- f64: electrostatic force factor from the table (nb_es_table.hip.hpp) ----------------
 // Where a kernel keeps the table: LDS (tile kernel: a copy made at kernel start) or global memory (pair lists).  Both
 // hold the same doubles and feed the same arithmetic, so the two give identical bits.
 struct EsTableGlobal {

@@ -4,7 +4,7 @@
 #include "engine.hpp"
 #include <cstdio>
 #include <cstdlib>
-#include "kernels_nblist.cuh"
+#include "kernels_nblist.hip.hpp"
 #include "profiler.hpp"
 
 #include <rocprim/rocprim.hpp>
@@ -34,7 +34,7 @@
 namespace tmamd {
 
 // =============================================================================================================
-// Electrostatic force-factor table (nb_es_table.cuh)
+// Electrostatic force-factor table (nb_es_table.hip.hpp)
 // =============================================================================================================
 // F(s) continued smoothly through d = 1.2 (no clamp: the kernels select 0 there), in long double
 static long double es_force_factor_reference(const long double beta, const long double s) {
@@ -126,7 +126,7 @@ static const int HILBERT_N_BITS = 8;
 
 // Hilbert index of a 3-D integer point, `nbits` bits per axis (Butz's algorithm; bit-compatible with the
 // hilbert_c2i(3, nbits, ...) the reference uses to fill its LUT, cpp/src/hilbert_sort.cu:18-31 -- pinned by
-// tests/test_oracle_hilbert.py against that C code compiled into oracle/_ref).
+// tests/test_oracle.py against that C code compiled into oracle/_ref).
 static unsigned int hilbert_index_3d(unsigned int c0, unsigned int c1, unsigned int c2, int nbits) {
     unsigned long long index = 0;
     unsigned int rot = 0, flip = 0, prev = 0;

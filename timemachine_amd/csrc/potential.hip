@@ -1,7 +1,7 @@
 // Potential base-class host entry points, BoundPotential, Summed / Fanout composition, the signed-128 reduction.
 // reference: cpp/src/potential.cu, bound_potential.cu, summed_potential.cu, fanout_summed_potential.cu, stream_manager.cu
 #include "engine.hpp"
-#include "fixed_point.cuh"
+#include "fixed_point.hip.hpp"
 
 #include <algorithm>
 #include <numeric>

@@ -902,7 +902,7 @@ def hilbert_lut():
 
 
 def es_force_table(beta):
-    """Host-only: [256, 6] polynomial coefficients of the f64 kernels' electrostatic force factor F(d^2) (nb_es_table.cuh)."""
+    """Host-only: [256, 6] polynomial coefficients of the f64 kernels' electrostatic force factor F(d^2) (nb_es_table.hip.hpp)."""
     out = np.zeros((256, 6), dtype=np.float64)
     _check(_lib.tm_es_force_table(_c_double(float(beta)), _ptr(out)))
     return out
