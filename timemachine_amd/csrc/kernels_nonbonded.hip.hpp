@@ -318,14 +318,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     auto &s_rowatom = lds.rowatom;
     auto &s_queue = lds.queue;
     if (threadIdx.x == 0) {
-        s_ticket = 0;
+        s_ticket = WAVES; // tickets 0 .. WAVES-1 are the waves' first items: drawn without the counter, before the barrier
     }
-    if constexpr (sizeof(Real) == 8) {
-        for (int i = threadIdx.x; i < ES_TAB_DOUBLES; i += WAVES * 64) {
-            s_es_tab[i] = es_table[i];
-        }
-    }
-    __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
+    // (the table copy and the workgroup's one barrier come further down, behind the request for the first item: the
+    // copy's L2 round trip then runs alongside the three dependent hops of that fetch instead of in front of them)
     // how phase 2 reaches the table: f64 reads the LDS copy with three ds_read_b128 per pair
     struct EsTableLds {
         const double *tab;
@@ -402,6 +398,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         const unsigned int w = (r & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
         return r * gridDim.x + w;
     };
+    auto position_of_ticket = [&](const unsigned int r) -> unsigned int {
+        const unsigned int w = (r & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        return r * gridDim.x + w;
+    };
     auto position_to_slot = [&](unsigned int g) -> unsigned int {
         if (g >= n_items_total) {
             return NO_ITEM;
@@ -447,13 +447,19 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #define TM_T(var)
 #endif
 
-    // prologue: first item fetched the slow way
-    unsigned int item = position_to_slot(next_position());
+    // prologue: first item fetched the slow way (ticket = wave index)
+    unsigned int item = position_to_slot(position_of_ticket(static_cast<unsigned int>(wave)));
     TileRegs<Real> cur;
     if (item != NO_ITEM) {
         load_indices(items[item], cur);
         load_records(cur);
     }
+    if constexpr (sizeof(Real) == 8) {
+        for (int i = threadIdx.x; i < ES_TAB_DOUBLES; i += WAVES * 64) {
+            s_es_tab[i] = es_table[i];
+        }
+    }
+    __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
 
     if constexpr (!COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) {
         if (fused) {
