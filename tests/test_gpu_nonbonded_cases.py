@@ -227,3 +227,27 @@ def test_nblist_density_of_a_dhfr_sized_box(co, cutoff):
     perm = co.HilbertSort(len(coords)).sort(coords, s.box)
     density = mean_tile_density(coords[perm])
     assert density > 0.10 and density > 2.0 * unsorted, (density, unsorted)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_nblist_rebuild(co, P, precision):
+    """tests/nonbonded/test_nonbonded.py:67-116: a potential that keeps its padded list (displacements stay within padding / 2,
+    so no rebuild is triggered) gives the same bits as one with padding 0, which lists afresh on every call -- through
+    execute and through execute_du_dx.  (The reference passes this in f64 only; integer accumulation makes it hold in f32 too.)"""
+    from timemachine_amd import testsystems as ts
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    N = s.num_atoms
+    rng = np.random.default_rng(2021)
+    padding = 0.1
+    ref = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, nblist_padding=0.0).to_gpu(precision).unbound_impl
+    test = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, nblist_padding=padding).to_gpu(precision).unbound_impl
+    deltas = (rng.random((N, 3)) - 0.5) / (0.5 * (2 * np.sqrt(3)) / padding)  # |delta| < padding / 2: no rebuild
+    assert np.all(np.linalg.norm(deltas, axis=1) < padding / 2)
+    for x in (s.coords, s.coords + deltas):
+        a = ref.execute(x, s.nb_params, s.box)
+        b = test.execute(x, s.nb_params, s.box)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        np.testing.assert_array_equal(ref.execute_du_dx(x, s.nb_params, s.box), test.execute_du_dx(x, s.nb_params, s.box))
