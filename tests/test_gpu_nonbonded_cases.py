@@ -251,3 +251,87 @@ def test_nblist_rebuild(co, P, precision):
         np.testing.assert_array_equal(a[1], b[1])
         assert a[2] == b[2]
         np.testing.assert_array_equal(ref.execute_du_dx(x, s.nb_params, s.box), test.execute_du_dx(x, s.nb_params, s.box))
+
+
+def _ig_system(rng, num_atoms, box_len=3.0):
+    conf = rng.uniform(0, box_len, size=(num_atoms, 3))
+    params = np.stack([rng.normal(size=num_atoms), rng.uniform(0.05, 0.15, num_atoms), rng.uniform(0.2, 1, num_atoms), np.zeros(num_atoms)], 1)
+    return conf, params, box_len * np.eye(3)
+
+
+@pytest.mark.parametrize("precision,rtol,atol", [(np.float64, 1e-8, 1e-8), (np.float32, 1e-4, 5e-4)])
+@pytest.mark.parametrize("num_atoms,num_atoms_ligand", [(50, 1), (50, 15), (231, 15)])
+@pytest.mark.parametrize("num_col_atoms", [1, 10, 33])
+def test_nonbonded_interaction_group_neighborlist_rebuild(co, P, precision, rtol, atol, num_atoms, num_atoms_ligand, num_col_atoms):
+    """tests/nonbonded/test_nonbonded_interaction_group.py:121-166: moving the column atoms far enough triggers a list rebuild;
+    energies and forces agree with the oracle before and after, for every 4D-offset pattern."""
+    from oracle import ref_potentials as rp
+
+    rng = np.random.default_rng(7 * num_atoms + num_atoms_ligand + 100 * num_col_atoms)
+    beta, cutoff = 2.0, 1.1
+    conf, params0, box = _ig_system(rng, num_atoms)
+    ligand_idxs = rng.choice(num_atoms, size=(num_atoms_ligand,), replace=False).astype(np.int32)
+    host_idxs = np.setdiff1d(np.arange(num_atoms), ligand_idxs).astype(np.int32)
+    col_atom_idxs = rng.choice(host_idxs, size=(num_col_atoms,), replace=False).astype(np.int32)
+    impl = P.NonbondedInteractionGroup(num_atoms, ligand_idxs, beta, cutoff, col_atom_idxs=col_atom_idxs).to_gpu(precision).unbound_impl
+
+    def check(x, prm):
+        u_ref, du_dx_ref, du_dp_ref = rp.value_and_grads(
+            lambda xx, pp: rp.nonbonded_interaction_group_energy(xx, pp, rp._t(box), ligand_idxs, col_atom_idxs, beta, cutoff), x, prm)
+        du_dx, du_dp, u = impl.execute(x, prm, box)
+        np.testing.assert_allclose(u, u_ref, rtol=rtol, atol=atol)
+        scale = max(1.0, np.abs(du_dx_ref).max())
+        np.testing.assert_allclose(du_dx, du_dx_ref, rtol=rtol * 10, atol=atol * scale)
+        np.testing.assert_allclose(du_dp, du_dp_ref, rtol=rtol * 100, atol=atol * 10 * max(1.0, np.abs(du_dp_ref).max()))
+
+    for params in params_with_4d_offsets(rng, params0, cutoff):
+        check(conf, params)
+        conf[col_atom_idxs] += rng.random(size=(len(col_atom_idxs), 3)) * (cutoff**2)
+        check(conf, params)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("num_atoms,num_atoms_ligand", [(33, 1), (33, 15), (231, 15)])
+def test_nonbonded_interaction_group_set_atom_idxs(co, P, precision, num_atoms, num_atoms_ligand):
+    """tests/nonbonded/test_nonbonded_interaction_group.py:365-413: set_atom_idxs makes the object the same, bit for bit, as a
+    fresh one with those groups, and setting the original groups again (in another order) restores the original bits."""
+    rng = np.random.default_rng(31 * num_atoms + num_atoms_ligand)
+    beta, cutoff = 2.0, 1.1
+    box = 3.0 * np.eye(3)
+    conf = rng.uniform(0, cutoff * 10, size=(num_atoms, 3))
+    params = rng.uniform(0, 1, size=(num_atoms, 4))
+    ligand_idxs = rng.choice(num_atoms, size=(num_atoms_ligand,), replace=False).astype(np.int32)
+    other_idxs = np.setdiff1d(np.arange(num_atoms), ligand_idxs)
+    secondary = rng.choice(other_idxs, size=(1,), replace=False).astype(np.int32)
+    pot = P.NonbondedInteractionGroup(num_atoms, ligand_idxs, beta, cutoff).to_gpu(precision).unbound_impl
+    ref = pot.execute(conf, params, box)
+    pot.set_atom_idxs(secondary, np.setdiff1d(np.arange(num_atoms), secondary).astype(np.int32))
+    diff = pot.execute(conf, params, box)
+    assert np.any(diff[0] != ref[0]) and np.any(diff[1] != ref[1]) and not np.allclose(ref[2], diff[2], equal_nan=False)
+    fresh = P.NonbondedInteractionGroup(num_atoms, secondary, beta, cutoff).to_gpu(precision).unbound_impl.execute(conf, params, box)
+    np.testing.assert_array_equal(fresh[0], diff[0])
+    np.testing.assert_array_equal(fresh[1], diff[1])
+    np.testing.assert_equal(fresh[2], diff[2])  # NaN (overflowed energy) equals NaN here, as in the reference
+    rng.shuffle(ligand_idxs)
+    pot.set_atom_idxs(ligand_idxs, np.setdiff1d(np.arange(num_atoms), ligand_idxs).astype(np.int32))
+    again = pot.execute(conf, params, box)
+    np.testing.assert_array_equal(again[0], ref[0])
+    np.testing.assert_array_equal(again[1], ref[1])
+    np.testing.assert_equal(again[2], ref[2])
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("num_atoms,num_atoms_ligand", [(33, 1), (33, 15), (231, 1), (231, 15)])
+def test_nonbonded_ixn_group_order_independent(co, P, precision, num_atoms, num_atoms_ligand):
+    """tests/nonbonded/test_nonbonded_interaction_group.py:417-449: with and without the Hilbert sort, bit for bit"""
+    rng = np.random.default_rng(17 * num_atoms + num_atoms_ligand)
+    beta, cutoff = 2.0, 1.1
+    conf, params0, box = _ig_system(rng, num_atoms)
+    ligand_idxs = rng.choice(num_atoms, size=(num_atoms_ligand,), replace=False).astype(np.int32)
+    a = P.NonbondedInteractionGroup(num_atoms, ligand_idxs, beta, cutoff).to_gpu(precision).unbound_impl
+    b = P.NonbondedInteractionGroup(num_atoms, ligand_idxs, beta, cutoff, disable_hilbert_sort=True).to_gpu(precision).unbound_impl
+    for params in params_with_4d_offsets(rng, params0, cutoff):
+        ra, rb = a.execute(conf, params, box), b.execute(conf, params, box)
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
+        assert ra[2] == rb[2]
