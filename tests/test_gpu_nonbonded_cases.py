@@ -335,3 +335,26 @@ def test_nonbonded_ixn_group_order_independent(co, P, precision, num_atoms, num_
         np.testing.assert_array_equal(ra[0], rb[0])
         np.testing.assert_array_equal(ra[1], rb[1])
         assert ra[2] == rb[2]
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("select_atom_indices", [False, True])
+@pytest.mark.parametrize("num_atoms", [33, 65, 231, 1050])
+def test_nonbonded_correctness_on_prefixes_and_subsets(co, P, precision, select_atom_indices, num_atoms):
+    """tests/nonbonded/test_nonbonded.py:124-156: the first num_atoms atoms of a solvated system with the exclusions that lie
+    inside the prefix, optionally restricted to a random half of the atoms (atom_idxs) -- u, du_dx, du_dp against the oracle,
+    all eight flag combinations, each executed twice and compared bitwise (compare_forces)."""
+    from oracle import ref_potentials as rp
+    from test_gpu_parity import compare_forces
+    from timemachine_amd import testsystems as ts
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    rng = np.random.default_rng(num_atoms)
+    x = s.coords[:num_atoms].astype(np.float32).astype(np.float64)
+    params = s.nb_params[:num_atoms]
+    keep = np.all(s.exclusion_idxs < num_atoms, axis=1)
+    excl, scales = np.ascontiguousarray(s.exclusion_idxs[keep]), np.ascontiguousarray(s.scale_factors[keep])
+    atom_idxs = np.array(rng.choice(num_atoms, num_atoms // 2, replace=False), dtype=np.int32) if select_atom_indices else None
+    pot = P.Nonbonded(num_atoms, excl, scales, s.beta, s.cutoff, atom_idxs=atom_idxs)
+    u, du_dx, du_dp = rp.nonbonded(x, params, s.box, excl, scales, s.beta, s.cutoff, atom_idxs=atom_idxs)
+    compare_forces(pot.to_gpu(precision).unbound_impl, x, params, s.box, float(u), du_dx, du_dp, precision)
