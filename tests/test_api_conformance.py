@@ -100,3 +100,27 @@ def test_local_md_methods_raise_by_name(co):
         fn = getattr(co.Context, mname)
         with pytest.raises(NotImplementedError, match=mname):
             fn(object.__new__(co.Context))
+
+
+def test_array_arguments_convert_like_the_binding_layer(co):
+    """The reference's binding layer takes `py::array_t<T, c_style>` without forcecast
+    (wrap_kernels.cpp:1-60 and every constructor below it): ndarrays convert only through safe casts,
+    Python sequences convert element by element. Its tests rely on both halves: int64 ndarrays are a
+    TypeError, `[0]` and `[(0, 0)]` are accepted index arrays."""
+    import numpy as np
+
+    assert co._i32([0]).dtype == np.int32
+    assert co._i32([(0, 0)]).shape == (1, 2)
+    assert co._u32([1, 2]).dtype == np.uint32
+    assert co._f64([1, 2]).dtype == np.float64
+    assert co._f64(np.arange(3, dtype=np.float32)).dtype == np.float64
+    assert co._i32(np.arange(3, dtype=np.int16)).dtype == np.int32
+    for bad in (
+        lambda: co._i32([0.5]),
+        lambda: co._i32(np.array([1], dtype=np.int64)),
+        lambda: co._u32([-1]),
+        lambda: co._i32([2**40]),
+        lambda: co._f64(np.array([1j])),
+    ):
+        with pytest.raises(TypeError):
+            bad()

@@ -358,3 +358,71 @@ def test_nonbonded_correctness_on_prefixes_and_subsets(co, P, precision, select_
     pot = P.Nonbonded(num_atoms, excl, scales, s.beta, s.cutoff, atom_idxs=atom_idxs)
     u, du_dx, du_dp = rp.nonbonded(x, params, s.box, excl, scales, s.beta, s.cutoff, atom_idxs=atom_idxs)
     compare_forces(pot.to_gpu(precision).unbound_impl, x, params, s.box, float(u), du_dx, du_dp, precision)
+
+
+def test_pair_list_constructor_validation(co, P):
+    """tests/nonbonded/test_nonbonded_pair_list.py:10-24 and test_nonbonded_precomputed.py:10-19"""
+    with pytest.raises(RuntimeError) as e:
+        P.NonbondedPairList([0], [0], 2.0, 1.1).to_gpu(np.float32).unbound_impl
+    assert "pair_idxs.size() must be even, but got 1" in str(e)
+    with pytest.raises(RuntimeError) as e:
+        P.NonbondedPairList([(0, 0)], [(1, 1)], 2.0, 1.1).to_gpu(np.float32).unbound_impl
+    assert "illegal pair with src == dst: 0, 0" in str(e)
+    with pytest.raises(RuntimeError) as e:
+        P.NonbondedPairList([(0, 1)], [(1, 1), (2, 2)], 2.0, 1.1).to_gpu(np.float32).unbound_impl
+    assert "expected same number of pairs and scale tuples, but got 1 != 2" in str(e)
+    with pytest.raises(RuntimeError) as e:
+        P.NonbondedPairListPrecomputed([0], 2.0, 1.1).to_gpu(np.float32).unbound_impl
+    assert "idxs.size() must be exactly 2*B" in str(e)
+    with pytest.raises(RuntimeError) as e:
+        P.NonbondedPairListPrecomputed([(0, 0)], 2.0, 1.1).to_gpu(np.float32).unbound_impl
+    assert "illegal pair with src == dst: 0, 0" in str(e)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("ixn_group_size", [2, 33, 231])
+def test_nonbonded_pair_list_correctness(co, P, precision, ixn_group_size):
+    """tests/nonbonded/test_nonbonded_pair_list.py:31-60: all pairs between two disjoint random groups, random rescale masks,
+    the three 4D-offset patterns -- against the oracle, all flag combinations (compare_forces)."""
+    from oracle import ref_potentials as rp
+    from test_gpu_parity import compare_forces
+    from timemachine_amd import testsystems as ts
+
+    s = ts.small_solvated_ligand(lamb=0.0)
+    rng = np.random.default_rng(ixn_group_size)
+    x = s.coords.astype(np.float32).astype(np.float64)
+    beta, cutoff = 2.0, 1.1
+    atom_idxs = rng.choice(s.num_atoms, size=(2, ixn_group_size), replace=False).astype(np.int32)
+    pair_idxs = np.ascontiguousarray(np.stack(np.meshgrid(atom_idxs[0], atom_idxs[1])).reshape(2, -1).T.astype(np.int32))
+    rescale = rng.uniform(0, 1, size=(len(pair_idxs), 2))
+    impl = P.NonbondedPairList(pair_idxs, rescale, beta, cutoff).to_gpu(precision).unbound_impl
+    for params in params_with_4d_offsets(rng, s.nb_params, cutoff):
+        u, du_dx, du_dp = rp.nonbonded_pair_list(x, params, s.box, pair_idxs, rescale, beta, cutoff)
+        compare_forces(impl, x, params, s.box, float(u), du_dx, du_dp, precision)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("cutoff", [1.1, 10000.0])
+@pytest.mark.parametrize("ixn_group_size", [4, 33, 231])
+def test_nonbonded_pair_list_precomputed_correctness(co, P, precision, cutoff, ixn_group_size):
+    """tests/nonbonded/test_nonbonded_precomputed.py:27-60: random pairs of a 25 358-atom configuration with per-pair
+    parameters (q_ij, sig_ij, eps_ij, w offset >= 0), a box that the potential must ignore... it does not: the reference's
+    kernel applies the minimum image like every other nonbonded term; finite and infinite cutoff."""
+    from oracle import ref_potentials as rp
+    from test_gpu_parity import compare_forces
+
+    num_atoms = 25358
+    rng = np.random.default_rng(1000 + ixn_group_size)
+    pair_idxs = np.array([rng.choice(num_atoms, 2, replace=False) for _ in range(ixn_group_size)], dtype=np.int32)
+    params0 = rng.uniform(0, 1, size=(ixn_group_size, 4))
+    params0[:, 0] -= 0.5
+    params0[:, 1] /= 5
+    conf = (rng.uniform(0, 1, size=(num_atoms, 3)) * 3).astype(np.float32).astype(np.float64)
+    box = np.diag(1 + rng.uniform(0, 1, size=3) * 3)
+    impl = P.NonbondedPairListPrecomputed(pair_idxs, 2.0, cutoff).to_gpu(precision).unbound_impl
+    wcut = min(cutoff, 2.0)
+    for w in (np.zeros(ixn_group_size), rng.uniform(0, wcut, ixn_group_size), wcut * (np.arange(ixn_group_size) % 2)):
+        params = params0.copy()
+        params[:, 3] = w
+        u, du_dx, du_dp = rp.nonbonded_pair_list_precomputed(conf, params, box, pair_idxs, 2.0, cutoff)
+        compare_forces(impl, conf, params, box, float(u), du_dx, du_dp, precision)

@@ -60,8 +60,23 @@ def _ptr(a):
 
 
 def _as(a, dtype, what):
-    """py::array_t<T, c_style> semantics: safe casts are converted, unsafe ones are a TypeError."""
-    arr = np.asarray(a)
+    """py::array_t<T, c_style> semantics: safe casts are converted, unsafe ones are a TypeError.
+
+    Python sequences and scalars (not ndarrays) are converted element by element, as numpy does
+    for the binding layer of the reference: a list of Python ints becomes int32/uint32 when every
+    value fits (the reference's own tests pass `[0]` and `[(0, 0)]` as index arrays), a list holding
+    a float does not become an integer array."""
+    if not isinstance(a, np.ndarray):
+        probe = np.asarray(a)
+        target = np.dtype(dtype)
+        if probe.dtype.kind in "iub" and target.kind in "iu":
+            try:
+                return np.ascontiguousarray(np.array(a, dtype=target))
+            except OverflowError as e:
+                raise TypeError(f"{what}: value out of range for {target}") from e
+        arr = probe
+    else:
+        arr = a
     if arr.dtype != dtype and not np.can_cast(arr.dtype, dtype, "safe"):
         raise TypeError(f"{what}: incompatible array dtype {arr.dtype}, expected {np.dtype(dtype)}")
     return np.ascontiguousarray(arr, dtype=dtype)
