@@ -208,6 +208,24 @@ int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, dou
 /* measurement aid (bench.py): device time, in ms, of the steps of the last tm_context_multiple_steps call -- HIP events
  * on the context's stream around the first .. last step (the final frame's device-to-host copy is outside) */
 int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms);
+/* ---- local MD                                   wrap_kernels.cpp:399-631; context.cu:90-213; local_md_potentials.cu ----
+ * Context.setup_local_md(temperature, freeze_reference): idempotent for equal arguments, "local md configured with
+ * different parameters, ..." otherwise. */
+int tm_context_setup_local_md(tm_context_t ctxt, double temperature, int freeze_reference);
+/* Context.multiple_steps_local(n_steps, local_idxs, store_x_interval=0, radius=1.2, k=10000.0, seed=2022).
+ * Validation and messages of the binding (wrap_kernels.cpp:408-420): "local steps must be at least one",
+ * "store_x_interval must be greater than or equal to zero", verify_local_md_parameters, verify_atom_idxs.
+ * xs[n_samples,N,3], boxes[n_samples,3,3] with n_samples = n_steps / (store_x_interval ? store_x_interval : n_steps). */
+int tm_context_multiple_steps_local(tm_context_t ctxt, int n_steps, const int *local_idxs, int num_local_idxs,
+                                    int store_x_interval, double radius, double k, int seed, double *xs, double *boxes);
+/* Context.multiple_steps_local_selection(n_steps, reference_idx, selection_idxs, store_x_interval=0, radius=1.2,
+ * k=10000.0)                                                                          wrap_kernels.cpp:502-556 */
+int tm_context_multiple_steps_local_selection(tm_context_t ctxt, int n_steps, int reference_idx, const int *selection_idxs,
+                                              int num_selection_idxs, int store_x_interval, double radius, double k,
+                                              double *xs, double *boxes);
+/* diagnostic (not in the reference surface): the reference atom the last local-MD setup picked and the [N] index array it
+ * handed the integrator (i = atom i moves, N = frozen); reference_idx = -1 before the first local-MD call */
+int tm_context_local_md_last_selection(tm_context_t ctxt, int *reference_idx, unsigned int *free_idxs);
 int tm_context_get_x_t(tm_context_t ctxt, double *out);
 int tm_context_get_v_t(tm_context_t ctxt, double *out);
 int tm_context_get_box(tm_context_t ctxt, double *out);

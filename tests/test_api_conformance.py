@@ -1,7 +1,7 @@
 """The drop-in boundary, pinned: timemachine_amd.lib.custom_ops must offer every class, method, argument name, argument
 order and default-ness that the reference's type stubs declare (timemachine/lib/custom_ops.pyi, parsed in the build
 container into tests/golden/custom_ops_api.json by tests/golden/generate_api_fixture.py), except for the names listed
-below as out of the hot path's scope (local MD, the exchange movers and their helpers)."""
+below as out of the hot path's scope (the exchange movers and their helpers)."""
 import inspect
 import json
 import os
@@ -21,8 +21,7 @@ OUT_OF_SCOPE_FUNCTIONS = {
     "rotate_and_translate_mol_f32", "rotate_and_translate_mol_f64", "rotate_coords_f32", "rotate_coords_f64",
     "translations_inside_and_outside_sphere_host_f32", "translations_inside_and_outside_sphere_host_f64",
 }
-# local MD (not built; the methods exist and raise NotImplementedError)
-OUT_OF_SCOPE_METHODS = {("Context", "multiple_steps_local"), ("Context", "multiple_steps_local_selection"), ("Context", "setup_local_md")}
+OUT_OF_SCOPE_METHODS = set()  # (local MD was listed here until it was built: round 2)
 
 
 @pytest.fixture(scope="module")
@@ -93,13 +92,6 @@ def test_method_signatures_match(api, co):
             elif has_default != ref["has_default"]:
                 problems.append(f"{cname}.{mname}: defaults {has_default} != reference {ref['has_default']}")
     assert not problems, "\n".join(problems)
-
-
-def test_local_md_methods_raise_by_name(co):
-    for _, mname in sorted(OUT_OF_SCOPE_METHODS):
-        fn = getattr(co.Context, mname)
-        with pytest.raises(NotImplementedError, match=mname):
-            fn(object.__new__(co.Context))
 
 
 def test_array_arguments_convert_like_the_binding_layer(co):

@@ -248,6 +248,19 @@ FlatBottomBond<Real, Log>::FlatBottomBond(const std::vector<int> &bond_idxs, con
     d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
 }
 
+template <typename Real, bool Log> void FlatBottomBond<Real, Log>::set_bonds(const std::vector<int> &bond_idxs) {
+    if (bond_idxs.size() % 2 != 0) {
+        throw std::runtime_error("bond_idxs.size() must be exactly 2*k!");
+    }
+    HIP_CHECK(hipDeviceSynchronize()); // a launch still reading the old list must finish before it is replaced
+    B_ = static_cast<int>(bond_idxs.size() / 2);
+    d_idxs_.reserve(static_cast<size_t>(B_) * 2);
+    if (B_ > 0) {
+        d_idxs_.copy_from(bond_idxs.data(), static_cast<size_t>(B_) * 2);
+    }
+    d_u_partials_.reserve(ceil_divide(B_, 256) * 4 + 1);
+}
+
 template <typename Real, bool Log> void FlatBottomBond<Real, Log>::check_size(const int P) const {
     if (P != 3 * B_) {
         throw std::runtime_error(

@@ -15,7 +15,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtimemachine_amd.so")
-SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "potential.hip", "c_api.cpp"]
+SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "local_md.hip", "potential.hip", "c_api.cpp"]
 HEADERS = [
     "common.hpp", "engine.hpp", "fixed_point.hip.hpp", "nb_pair.hip.hpp", "kernels_nonbonded.hip.hpp", "kernels_nblist.hip.hpp", "kernels_bonded.hip.hpp", "philox.hip.hpp", "nb_math.hip.hpp", "nb_math_coeffs.h", "nb_es_table.hip.hpp",
     "profiler.hpp", "../../include/timemachine_amd.h",

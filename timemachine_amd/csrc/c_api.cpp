@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "profiler.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <limits>
@@ -625,6 +626,58 @@ int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, dou
 int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms) {
     TM_TRY
     *ms = ctxt->p->last_multiple_steps_ms();
+    TM_CATCH
+}
+int tm_context_setup_local_md(tm_context_t ctxt, double temperature, int freeze_reference) {
+    TM_TRY
+    ctxt->p->setup_local_md(temperature, freeze_reference != 0);
+    TM_CATCH
+}
+static int local_md_num_samples(int n_steps, int store_x_interval) {
+    // wrap_kernels.cpp:408-426
+    if (n_steps <= 0) {
+        throw std::runtime_error("local steps must be at least one");
+    }
+    if (store_x_interval < 0) {
+        throw std::runtime_error("store_x_interval must be greater than or equal to zero");
+    }
+    const int x_interval = store_x_interval == 0 ? n_steps : store_x_interval;
+    return n_steps / x_interval;
+}
+int tm_context_multiple_steps_local(
+    tm_context_t ctxt, int n_steps, const int *local_idxs, int num_local_idxs, int store_x_interval, double radius, double k, int seed,
+    double *xs, double *boxes) {
+    TM_TRY
+    const int n_samples = local_md_num_samples(n_steps, store_x_interval);
+    verify_local_md_parameters(radius, k);
+    const std::vector<int> idxs(local_idxs, local_idxs + num_local_idxs);
+    verify_atom_idxs(ctxt->p->num_atoms(), idxs);
+    ctxt->p->multiple_steps_local(n_steps, idxs, n_samples, radius, k, seed, xs, boxes);
+    TM_CATCH
+}
+int tm_context_multiple_steps_local_selection(
+    tm_context_t ctxt, int n_steps, int reference_idx, const int *selection_idxs, int num_selection_idxs, int store_x_interval,
+    double radius, double k, double *xs, double *boxes) {
+    TM_TRY
+    const int n_samples = local_md_num_samples(n_steps, store_x_interval);
+    verify_local_md_parameters(radius, k);
+    const int N = ctxt->p->num_atoms();
+    if (reference_idx < 0 || reference_idx >= N) {
+        throw std::runtime_error("reference idx must be at least 0 and less than " + std::to_string(N));
+    }
+    const std::vector<int> idxs(selection_idxs, selection_idxs + num_selection_idxs);
+    verify_atom_idxs(N, idxs);
+    if (std::find(idxs.begin(), idxs.end(), reference_idx) != idxs.end()) {
+        throw std::runtime_error("reference idx must not be in selection idxs");
+    }
+    ctxt->p->multiple_steps_local_selection(n_steps, reference_idx, idxs, n_samples, radius, k, xs, boxes);
+    TM_CATCH
+}
+int tm_context_local_md_last_selection(tm_context_t ctxt, int *reference_idx, unsigned int *free_idxs) {
+    TM_TRY
+    *reference_idx = ctxt->p->local_md_last_reference();
+    const std::vector<unsigned int> f = ctxt->p->local_md_last_free_idxs();
+    std::copy(f.begin(), f.end(), free_idxs);
     TM_CATCH
 }
 int tm_context_get_x_t(tm_context_t ctxt, double *out) {

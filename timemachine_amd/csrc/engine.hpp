@@ -198,6 +198,8 @@ public:
 
     void set_params(const std::vector<double> &params);
     void set_params_device(const int size, const double *d_p, hipStream_t stream);
+    // the first params.size() values of the buffer become the parameters (size <= the constructor's): local MD's restraints
+    void set_params_prefix(const std::vector<double> &params);
     void execute_device(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream);
     void execute_host(const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
     void execute_batch_host(const int coord_batch_size, const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
@@ -299,6 +301,10 @@ private:
 template <typename Real, bool Log> class FlatBottomBond : public Potential {
 public:
     FlatBottomBond(const std::vector<int> &bond_idxs, const double beta);
+    // local MD re-targets its restraints on every call (reference: set_bonds_device, flat_bottom_bond.cu); no src != dst
+    // re-validation here either -- the caller builds the pairs
+    void set_bonds(const std::vector<int> &bond_idxs);
+    int num_bonds() const { return B_; }
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
 private:
@@ -426,6 +432,12 @@ class NonbondedAllPairsBase : public Potential {
 public:
     virtual double get_cutoff() const = 0;
     virtual double get_nblist_padding() const = 0;
+    virtual double get_beta() const = 0;
+    virtual int precision_bytes() const = 0;
+    virtual bool is_interaction_group() const { return false; } // NonbondedInteractionGroup shares the all-pairs pipeline
+    // local MD narrows an all-pairs potential to the free atoms for the length of a call and widens it again afterwards
+    virtual void narrow_to(const std::vector<int> &atom_idxs) = 0;
+    virtual std::vector<int> current_atom_idxs() = 0;
 };
 
 template <typename Real> class NonbondedAllPairs : public NonbondedAllPairsBase {
@@ -435,7 +447,11 @@ public:
 
     void set_atom_idxs(const std::vector<int> &atom_idxs);
     std::vector<int> get_atom_idxs();
+    void narrow_to(const std::vector<int> &atom_idxs) override { this->set_atom_idxs(atom_idxs); }
+    std::vector<int> current_atom_idxs() override { return this->get_atom_idxs(); }
     int get_num_atom_idxs() const { return K_; }
+    double get_beta() const override { return beta_; }
+    int precision_bytes() const override { return static_cast<int>(sizeof(Real)); }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool piggyback_lands_in_own_accumulator() const override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
@@ -499,6 +515,7 @@ template <typename Real> class NonbondedInteractionGroup : public NonbondedAllPa
 public:
     NonbondedInteractionGroup(const int N, const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding);
     void set_atom_idxs(const std::vector<int> &row_atom_idxs, const std::vector<int> &col_atom_idxs);
+    bool is_interaction_group() const override { return true; }
     int get_num_row_idxs() const { return this->group_rows_; }
     int get_num_col_idxs() const { return this->empty_ ? n_cols_ : this->K_ - this->group_rows_; }
 private:
@@ -670,6 +687,50 @@ private:
     void reset_counters();
 };
 
+// reference: cpp/src/local_md_potentials.{hpp,cu}, local_md_utils.cu, kernels/k_local_md.cuh.
+// Local MD: for the length of one multiple_steps_local* call only the "free" atoms move -- those selected around a
+// reference atom -- held near it by a flat-bottom restraint, while the rest of the system stays frozen.  The context's
+// own potentials are kept; the one NonbondedAllPairs among them is narrowed to free x free, a NonbondedInteractionGroup of
+// the same parameters adds free x frozen (frozen x frozen forces move nobody), and the restraints are appended.
+// Unlike the reference (a chain of index kernels + two device partitions + a D2H count), the selection flags are computed
+// by one kernel, read back once, and the row / column / bond lists are laid out on the host: it is a per-call setup
+// (hundreds of steps follow), the lists have to be known to the host anyway (sizes, validation, neighbor-list resize),
+// and every list comes out in ascending atom order -- deterministic, where the reference's partition order is not.
+class LocalMDPotentials {
+public:
+    LocalMDPotentials(const int N, const std::vector<std::shared_ptr<BoundPotential>> &bps, const bool freeze_reference, const double temperature);
+    // reference atom = local_idxs[mt19937(seed) draw]; atom i is free with probability exp(-U_flat_bottom(r_i) / kT)
+    void setup_from_idxs(const double *d_x_t, const double *d_box_t, const std::vector<int> &local_idxs, const int seed, const double radius, const double k, hipStream_t stream);
+    // the caller chose the free atoms
+    void setup_from_selection(const int reference_idx, const std::vector<int> &selection_idxs, const double radius, const double k, hipStream_t stream);
+    std::vector<std::shared_ptr<BoundPotential>> &get_potentials() { return all_potentials_; }
+    unsigned int *get_free_idxs() { return d_free_idxs_.data; } // [N]: i if atom i is free, N otherwise
+    void reset_potentials(); // the all-pairs potential gets its own atom set back
+    const bool freeze_reference;
+    const double temperature;
+    // what the last setup decided (tests / diagnostics)
+    int last_reference_idx() const { return last_reference_; }
+    const std::vector<unsigned int> &last_free_idxs() const { return h_free_; }
+
+private:
+    const int N_;
+    std::vector<std::shared_ptr<BoundPotential>> all_potentials_;
+    std::shared_ptr<NonbondedAllPairsBase> all_pairs_;
+    std::vector<int> all_pairs_idxs_;      // its atom set outside local MD
+    std::vector<char> in_all_pairs_;       // [N] membership
+    std::shared_ptr<NonbondedAllPairsBase> ixn_group_;
+    std::shared_ptr<FlatBottomBond<float, false>> free_restraint_;
+    std::shared_ptr<BoundPotential> bound_free_restraint_;
+    std::shared_ptr<FlatBottomBond<float, true>> frozen_restraint_;
+    std::shared_ptr<BoundPotential> bound_frozen_restraint_;
+    DeviceBuffer<unsigned int> d_free_idxs_;
+    std::vector<unsigned int> h_free_;
+    int last_reference_ = -1;
+    void setup_given_free_flags(const int reference_idx, const double radius, const double k, hipStream_t stream);
+};
+
+void verify_local_md_parameters(const double radius, const double k);
+
 // reference: cpp/src/context.{hpp,cu}
 class Context {
 public:
@@ -680,6 +741,13 @@ public:
     void initialize();
     void finalize();
     void multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box);
+    // reference: context.cu:90-213.  Movers do not run during local MD (context.cu:268).
+    void setup_local_md(const double temperature, const bool freeze_reference);
+    void multiple_steps_local(const int n_steps, const std::vector<int> &local_idxs, const int n_samples, const double radius, const double k, const int seed, double *h_x, double *h_box);
+    void multiple_steps_local_selection(const int n_steps, const int reference_idx, const std::vector<int> &selection_idxs, const int n_samples, const double radius, const double k, double *h_x, double *h_box);
+    // diagnostics of the last local-MD setup: the reference atom and the [N] free-index array the integrator was given
+    int local_md_last_reference() const;
+    std::vector<unsigned int> local_md_last_free_idxs() const;
     int num_atoms() const { return N_; }
     void set_x_t(const double *in);
     void set_v_t(const double *in);
@@ -706,7 +774,11 @@ private:
     std::vector<std::shared_ptr<BoundPotential>> bps_;
     std::vector<double> nb_cutoffs_with_padding_;
     hipStream_t stream_;
+    std::unique_ptr<LocalMDPotentials> local_md_pots_;
     void _step(hipStream_t stream);
+    double _get_temperature() const;
+    void _ensure_local_md_initialized();
+    void _run_local_steps(const int n_steps, const int n_samples, double *h_x, double *h_box);
     void invalidate_potential_inputs();
     void _verify_coords_and_box(const double *coords, const double *box, hipStream_t stream);
 };

@@ -310,11 +310,6 @@ template <typename Real>
 void LangevinIntegrator<Real>::step_fwd(
     std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs,
     hipStream_t stream) {
-    if (d_idxs != nullptr) {
-        // the kernels carry the reference's index-list branches (k_integrator.cuh:12-22), but no local-MD driver exists
-        // here to exercise them: refuse rather than run untested code
-        throw std::runtime_error("LangevinIntegrator: local MD (an atom index list) is not built in timemachine_amd");
-    }
     // forces only: every bound potential describes itself to one plan, so short per-term kernels share a launch
     plan_.clear();
     for (auto &bp : bps) {
@@ -440,9 +435,6 @@ VelocityVerletIntegrator::VelocityVerletIntegrator(const int N, const double dt,
 void VelocityVerletIntegrator::forces_then_update(
     const int mode, std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t,
     unsigned int *d_idxs, hipStream_t stream) {
-    if (d_idxs != nullptr) {
-        throw std::runtime_error("VelocityVerletIntegrator: local MD (an atom index list) is not built in timemachine_amd");
-    }
     plan_.clear();
     for (auto &bp : bps) {
         bp->potential->plan_forces(N_, bp->size, bp->size > 0 ? bp->d_p.data : nullptr, plan_);
@@ -601,6 +593,116 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     }
     intg_->finalize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+double Context::_get_temperature() const {
+    // reference: context.cu:80-88 (only a Langevin thermostat knows a temperature)
+    if (auto li = std::dynamic_pointer_cast<LangevinIntegrator<float>>(intg_)) {
+        return li->get_temperature();
+    }
+    if (auto li = std::dynamic_pointer_cast<LangevinIntegrator<double>>(intg_)) {
+        return li->get_temperature();
+    }
+    throw std::runtime_error("integrator must be LangevinIntegrator.");
+}
+
+void Context::setup_local_md(const double temperature, const bool freeze_reference) {
+    if (local_md_pots_ != nullptr) {
+        if (local_md_pots_->temperature != temperature || local_md_pots_->freeze_reference != freeze_reference) {
+            throw std::runtime_error(
+                "local md configured with different parameters, current parameters: Temperature " +
+                std::to_string(local_md_pots_->temperature) + " Freeze Reference " + std::to_string(local_md_pots_->freeze_reference));
+        }
+        return;
+    }
+    local_md_pots_.reset(new LocalMDPotentials(N_, bps_, freeze_reference, temperature));
+}
+
+void Context::_ensure_local_md_initialized() {
+    if (local_md_pots_ == nullptr) {
+        this->setup_local_md(this->_get_temperature(), true);
+    }
+}
+
+int Context::local_md_last_reference() const { return local_md_pots_ ? local_md_pots_->last_reference_idx() : -1; }
+
+std::vector<unsigned int> Context::local_md_last_free_idxs() const {
+    return local_md_pots_ ? local_md_pots_->last_free_idxs() : std::vector<unsigned int>();
+}
+
+// the steps of a local-MD call, after its setup: only the free atoms are integrated, movers stay out (context.cu:268)
+void Context::_run_local_steps(const int n_steps, const int n_samples, double *h_x, double *h_box) {
+    const int store_x_interval = n_samples > 0 ? n_steps / n_samples : n_steps + 1;
+    hipStream_t stream = stream_;
+    unsigned int *d_free_idxs = local_md_pots_->get_free_idxs();
+    std::vector<std::shared_ptr<BoundPotential>> &local_pots = local_md_pots_->get_potentials();
+    // whatever the global-MD steps before this call left with the potentials / the integrator (pre-gathered positions,
+    // slot-ordered state) describes another atom set
+    this->invalidate_potential_inputs();
+    try {
+        intg_->initialize(local_pots, d_x_t_.data, d_v_t_.data, d_box_t_.data, d_free_idxs, stream);
+        for (int i = 1; i <= n_steps; i++) {
+            intg_->step_fwd(local_pots, d_x_t_.data, d_v_t_.data, d_box_t_.data, d_free_idxs, stream);
+            step_ += 1;
+            if (i % store_x_interval == 0) {
+                double *box_ptr = h_box + static_cast<size_t>(i / store_x_interval - 1) * 9;
+                double *coord_ptr = h_x + static_cast<size_t>(i / store_x_interval - 1) * N_ * 3;
+                HIP_CHECK(hipMemcpyAsync(coord_ptr, d_x_t_.data, static_cast<size_t>(N_) * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipMemcpyAsync(box_ptr, d_box_t_.data, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                this->_verify_coords_and_box(coord_ptr, box_ptr, stream);
+            }
+        }
+        intg_->finalize(local_pots, d_x_t_.data, d_v_t_.data, d_box_t_.data, d_free_idxs, stream);
+    } catch (...) {
+        (void)hipStreamSynchronize(stream);
+        local_md_pots_->reset_potentials();
+        this->invalidate_potential_inputs();
+        throw;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+    local_md_pots_->reset_potentials();
+    this->invalidate_potential_inputs();
+}
+
+void Context::multiple_steps_local(
+    const int n_steps, const std::vector<int> &local_idxs, const int n_samples, const double radius, const double k, const int seed,
+    double *h_x, double *h_box) {
+    if (n_samples < 0) {
+        throw std::runtime_error("n_samples < 0");
+    }
+    const int store_x_interval = n_samples > 0 ? n_steps / n_samples : n_steps + 1;
+    if (n_steps % store_x_interval != 0) {
+        std::cout << "warning:: n_steps modulo store_x_interval does not equal zero" << std::endl;
+    }
+    this->_ensure_local_md_initialized();
+    try {
+        local_md_pots_->setup_from_idxs(d_x_t_.data, d_box_t_.data, local_idxs, seed, radius, k, stream_);
+    } catch (...) {
+        local_md_pots_->reset_potentials(); // a setup that threw half-way may already have narrowed the all-pairs potential
+        throw;
+    }
+    this->_run_local_steps(n_steps, n_samples, h_x, h_box);
+}
+
+void Context::multiple_steps_local_selection(
+    const int n_steps, const int reference_idx, const std::vector<int> &selection_idxs, const int n_samples, const double radius,
+    const double k, double *h_x, double *h_box) {
+    if (n_samples < 0) {
+        throw std::runtime_error("n_samples < 0");
+    }
+    const int store_x_interval = n_samples > 0 ? n_steps / n_samples : n_steps + 1;
+    if (n_steps % store_x_interval != 0) {
+        std::cout << "warning:: n_steps modulo store_x_interval does not equal zero" << std::endl;
+    }
+    this->_ensure_local_md_initialized();
+    try {
+        local_md_pots_->setup_from_selection(reference_idx, selection_idxs, radius, k, stream_);
+    } catch (...) {
+        local_md_pots_->reset_potentials();
+        throw;
+    }
+    this->_run_local_steps(n_steps, n_samples, h_x, h_box);
 }
 
 void Context::step() {

@@ -473,7 +473,10 @@ __device__ __forceinline__ i128 flat_bottom_bond_term(
     if constexpr (LOG) {
         const Real beta = static_cast<Real>(beta_d);
         const Real e = exp(-beta * nrg);
-        chain = -e / (1 - e);
+        // inside the flat region (U_fb = 0, or so small that exp rounds to 1) the log restraint's derivative is -inf * 0:
+        // the reference's f32 kernel turns that NaN into a zero force in its float -> fixed conversion (PTX cvt of NaN
+        // is 0; k_fixed_point.cuh:10-24) -- local MD relies on it for frozen atoms inside the radius.  Said explicitly here.
+        chain = (1 - e) > 0 ? -e / (1 - e) : static_cast<Real>(0);
         if (want_u) {
             const Real x = beta * nrg; // -log(1 - exp(-x)), evaluated stably on both sides of log 2
             const Real l = x < static_cast<Real>(0.693147180559945309417232121) ? log(-expm1(-x)) : log1p(-exp(-x));

@@ -193,6 +193,18 @@ void BoundPotential::set_params(const std::vector<double> &params) {
     this->potential->invalidate_cached_inputs(); // new values behind the same device pointer
 }
 
+void BoundPotential::set_params_prefix(const std::vector<double> &params) {
+    if (params.size() > d_p.length) {
+        throw std::runtime_error(
+            "parameter size is greater than device buffer size: " + std::to_string(params.size()) + " > " + std::to_string(d_p.length));
+    }
+    if (params.size() > 0) {
+        d_p.copy_from(params.data(), params.size());
+    }
+    this->size = params.size();
+    this->potential->invalidate_cached_inputs();
+}
+
 void BoundPotential::set_params_device(const int new_size, const double *d_new_params, hipStream_t stream) {
     if (static_cast<size_t>(new_size) > d_p.length) {
         throw std::runtime_error(

@@ -769,6 +769,55 @@ class Context:
         _check(_lib.tm_context_multiple_steps(self._h, _c_int(n_steps), _c_int(n_samples), _ptr(xs), _ptr(boxes)))
         return xs, boxes
 
+    # ---- local MD (wrap_kernels.cpp:399-631; context.cu:90-213) ----
+    def setup_local_md(self, temperature, freeze_reference):
+        """Builds the potentials local MD adds (restraints, free x frozen interaction group).  Done implicitly, with the
+        Langevin integrator's temperature and a frozen reference, by the first local-MD call; idempotent for equal
+        arguments, RuntimeError for different ones."""
+        _check(_lib.tm_context_setup_local_md(self._h, _c_double(float(temperature)), _c_int(1 if freeze_reference else 0)))
+
+    @staticmethod
+    def _local_num_samples(n_steps, store_x_interval):
+        # sizes only; the C-ABI call validates (and raises the binding's messages) before anything is written
+        if n_steps <= 0 or store_x_interval < 0:
+            return 0
+        return n_steps // (n_steps if store_x_interval == 0 else store_x_interval)
+
+    def multiple_steps_local(self, n_steps, local_idxs, store_x_interval=0, radius=1.2, k=10000.0, seed=2022):
+        """Steps in which only atoms selected around a random member of ``local_idxs`` move (probability
+        exp(-U_flat_bottom(r) / kT)); the chosen atom itself is frozen unless setup_local_md said otherwise.  Movers do not
+        run.  -> (xs[F,N,3], boxes[F,3,3])."""
+        n_steps, store_x_interval, seed = int(n_steps), int(store_x_interval), int(seed)
+        idxs = _i32(local_idxs, "local_idxs").reshape(-1)
+        n_samples = self._local_num_samples(n_steps, store_x_interval)
+        xs = np.empty((n_samples, self._N, 3), dtype=np.float64)
+        boxes = np.empty((n_samples, 3, 3), dtype=np.float64)
+        _check(_lib.tm_context_multiple_steps_local(
+            self._h, _c_int(n_steps), _ptr(idxs), _c_int(idxs.size), _c_int(store_x_interval), _c_double(float(radius)),
+            _c_double(float(k)), _c_int(seed), _ptr(xs), _ptr(boxes)))
+        return xs, boxes
+
+    def multiple_steps_local_selection(self, n_steps, reference_idx, selection_idxs, store_x_interval=0, radius=1.2, k=10000.0):
+        """Local MD with the free atoms chosen by the caller (restrained to ``reference_idx``, which stays frozen unless
+        setup_local_md said otherwise).  -> (xs[F,N,3], boxes[F,3,3])."""
+        n_steps, store_x_interval = int(n_steps), int(store_x_interval)
+        idxs = _i32(selection_idxs, "selection_idxs").reshape(-1)
+        n_samples = self._local_num_samples(n_steps, store_x_interval)
+        xs = np.empty((n_samples, self._N, 3), dtype=np.float64)
+        boxes = np.empty((n_samples, 3, 3), dtype=np.float64)
+        _check(_lib.tm_context_multiple_steps_local_selection(
+            self._h, _c_int(n_steps), _c_int(int(reference_idx)), _ptr(idxs), _c_int(idxs.size), _c_int(store_x_interval),
+            _c_double(float(radius)), _c_double(float(k)), _ptr(xs), _ptr(boxes)))
+        return xs, boxes
+
+    def local_md_last_selection(self):
+        """diagnostic (not in the reference surface): (reference atom, indices of the atoms that moved) of the last
+        local-MD call; (-1, empty) before the first."""
+        ref = _c_int(-1)
+        free = np.full(self._N, self._N, dtype=np.uint32)
+        _check(_lib.tm_context_local_md_last_selection(self._h, ctypes.byref(ref), _ptr(free)))
+        return ref.value, np.flatnonzero(free < self._N).astype(np.int32) if ref.value >= 0 else np.zeros(0, np.int32)
+
     def set_x_t(self, coords):
         c = _f64(coords, "coords")
         if c.shape[0] != self._N:
@@ -994,15 +1043,3 @@ for _name in (
     "translations_inside_and_outside_sphere_host_f32", "translations_inside_and_outside_sphere_host_f64",
 ):
     globals()[_name] = _not_on_hot_path(_name)
-
-
-def _local_md_not_built(name):
-    def method(self, *a, **k):
-        raise NotImplementedError(f"Context.{name}: local MD is outside the MI355X hot path of timemachine_amd (see DESIGN.md, 'out of scope')")
-
-    method.__name__ = name
-    return method
-
-
-for _name in ("multiple_steps_local", "multiple_steps_local_selection", "setup_local_md"):
-    setattr(Context, _name, _local_md_not_built(_name))
