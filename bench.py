@@ -430,12 +430,19 @@ def run_md(args, rank, local_rank, world, backend):
     else:
         N, system = 23559, None
 
-    def run(prec, steps, warmup, profile_steps):
+    def run(prec, steps, warmup, profile_steps, barostat_interval=0):
         if args.stub:
             bps, ctxt = None, StubContext(N)
         else:
             bps = make_bps(prec)
-            ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps)
+            movers = []
+            if barostat_interval > 0:
+                # the reference's second DHFR line: "dhfr-apo-barostat-interval-25" (tests/test_benchmark.py:517-518, 222-232)
+                from timemachine_amd.lib import MonteCarloBarostat
+
+                groups = [list(range(3 * i, 3 * i + 3)) for i in range(N // 3)]
+                movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, groups, barostat_interval, seed).impl(bps)]
+            ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps, movers=movers)
         device_sync(co)  # the first call initialises torch's HIP context (seconds): do it here, not in front of the clock
         ctxt.multiple_steps(SETTLE_STEPS, 0)  # untimed, whatever --warmup says (see the module docstring)
         if warmup > 0:
@@ -578,6 +585,15 @@ def run_md(args, rank, local_rank, world, backend):
             out["ns_day_" + ("f32" if other == np.float32 else "f64")] = (max(args.steps // 2, 1) / d2) * 86400.0 * DT * 1e-3
         except Exception as exc:  # pragma: no cover
             out["other_precision_error"] = str(exc)
+        # NPT: the same box with the Monte Carlo barostat every 25 steps (the reference benchmarks both ensembles)
+        try:
+            n_npt = max(args.steps // 2, 25)
+            d3, _, _, _, _ = run(precision, n_npt, max(args.warmup // 2, 25), 0, barostat_interval=25)
+            out["npt"] = {"barostat_interval": 25, "pressure_bar": 1.0, "ns_day": n_npt / d3 * 86400.0 * DT * 1e-3,
+                          "ms_per_step": 1e3 * d3 / n_npt, "dtype": args.precision,
+                          "note": "reference: tests/test_benchmark.py:517-518 (dhfr-apo-barostat-interval-25); two energy-only evaluations per attempt"}
+        except Exception as exc:  # pragma: no cover
+            out["npt_error"] = str(exc)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, xf, args.cutoff)
             out["cpu_baseline_configs"] = cpu_baseline_configs()

@@ -22,8 +22,17 @@ static const double AVOGADRO = 6.0221367e23;   // cpp/src/constants.hpp:6
 template <typename Real>
 __global__ void k_barostat_propose(
     const int adaptive, const unsigned long long seed, const unsigned long long attempt, const double *__restrict__ box,
-    double *__restrict__ volume_scale, Real *__restrict__ mv, double *__restrict__ box_proposed) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) {
+    double *__restrict__ volume_scale, Real *__restrict__ mv, double *__restrict__ box_proposed,
+    // the rest of the grid prepares the attempt's buffers in the same launch: x_proposed = x, molecule centroid sums = 0
+    const int n_x, const double *__restrict__ x, double *__restrict__ x_proposed, const int n_centroids, u64 *__restrict__ centroids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_x) {
+        x_proposed[i] = x[i];
+    }
+    if (i < n_centroids) {
+        centroids[i] = 0;
+    }
+    if (i != 0) {
         return;
     }
     unsigned int r[4];
@@ -255,12 +264,13 @@ template <typename Real> void MonteCarloBarostat<Real>::move(const int N, double
         return;
     }
     const int tpb = DEFAULT_TPB;
-    k_barostat_propose<Real><<<1, 64, 0, stream>>>(adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data);
+    const int n_prep = std::max(N_, num_mols_) * 3;
+    k_barostat_propose<Real><<<ceil_divide(std::max(n_prep, 1), tpb), tpb, 0, stream>>>(
+        adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data, N_ * 3, d_x,
+        d_x_proposed_.data, num_mols_ * 3, d_centroids_.data);
     HIP_CHECK(hipGetLastError());
     attempt_++;
-    HIP_CHECK(hipMemcpyAsync(d_x_proposed_.data, d_x, static_cast<size_t>(N_) * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (num_grouped_atoms_ > 0) {
-        d_centroids_.zero_async(stream, static_cast<size_t>(num_mols_) * 3);
         const int blocks = ceil_divide(num_grouped_atoms_, tpb);
         k_barostat_centroids<Real><<<blocks, tpb, 0, stream>>>(num_grouped_atoms_, d_x_proposed_.data, d_atom_idxs_.data, d_mol_idxs_.data, d_centroids_.data);
         k_barostat_rescale<Real><<<blocks, tpb, 0, stream>>>(
@@ -269,12 +279,14 @@ template <typename Real> void MonteCarloBarostat<Real>::move(const int N, double
         HIP_CHECK(hipGetLastError());
     }
     const int n_bps = static_cast<int>(bps_.size());
+    // every bound potential describes itself to one plan (as for the integrator's force evaluation): all short terms in
+    // one energy launch, the nonbonded tile kernel's partial sums left where they are, one reduction for the total
     auto total_energy = [&](const double *x, const double *box, i128 *out) {
-        d_u_buffer_.zero_async(stream, std::max(n_bps, 1));
+        plan_.clear();
         for (int i = 0; i < n_bps; i++) {
-            bps_[i]->execute_device(N_, x, box, nullptr, nullptr, d_u_buffer_.data + i, stream);
+            bps_[i]->potential->plan_forces(N_, bps_[i]->size, bps_[i]->size > 0 ? bps_[i]->d_p.data : nullptr, plan_);
         }
-        reduce_i128_device(d_u_buffer_.data, std::max(n_bps, 1), out, stream);
+        plan_.run_energy(N_, x, box, out, stream);
     };
     total_energy(d_x, d_box, d_u_init_.data);
     total_energy(d_x_proposed_.data, d_box_proposed_.data, d_u_final_.data);

@@ -108,6 +108,11 @@ public:
     bool run(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream,
              std::vector<DeferredForces> *deferred = nullptr, const int max_deferred = 0, u64 *d_du_dx_cm = nullptr,
              const int cm_stride = 0);
+    // Energy only: the total of everything planned, as one signed 128-bit fixed-point sum in d_u[0].  The table's terms
+    // run in one launch that leaves per-wave partial sums; potentials that launch their own kernels leave theirs in their own
+    // buffers (Potential::execute_energy_partials) or, failing that, reduce into a slot; ONE final reduction adds it all up.
+    // Integer sums: the same bits as summing child by child (SummedPotential / FanoutSummedPotential / the barostat).
+    void run_energy(const int N, const double *d_x, const double *d_box, i128 *d_u, hipStream_t stream);
     // after run(): did anything go to d_du_dx_cm?  (false when every table rode on a potential that took it into its own
     // accumulator: the consumer can skip reading and re-zeroing the array)
     bool cm_written() const { return cm_written_; }
@@ -119,6 +124,9 @@ private:
     DeviceBuffer<FusedTable> d_table_[2];
     std::vector<Rest> rest_;
     bool cm_written_ = true;
+    DeviceBuffer<i128> d_e_partials_[2]; // run_energy: per-wave sums of the table launches
+    DeviceBuffer<i128> d_e_slots_;       // run_energy: totals of potentials that reduce for themselves
+    void upload_tables(bool pending[2], hipStream_t stream);
 };
 
 class Potential {
@@ -143,6 +151,14 @@ public:
     virtual bool execute_forces_deferred(
         const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
         DeferredForces &out) {
+        return false;
+    }
+
+    // Energy-only evaluation that leaves per-wave partial sums (to be added up by the caller) in a buffer of the potential's
+    // own instead of reducing them into a d_u -- saves a launch per evaluation.  false = not supported (nothing was run).
+    virtual bool execute_energy_partials(
+        const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials,
+        int &count) {
         return false;
     }
 
@@ -455,6 +471,7 @@ public:
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool piggyback_lands_in_own_accumulator() const override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
+    bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
     double get_cutoff() const override { return cutoff_; }
@@ -504,6 +521,8 @@ protected:
     const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
+    bool defer_u_reduce_ = false; // run_pipeline leaves the tile kernel's energy partials un-reduced (execute_energy_partials)
+    int u_partials_count_ = 0;
     u64 *piggyback_acc_ = nullptr; // where the piggy-backed table's forces go, and its layout
     int piggyback_atom_stride_ = 3, piggyback_comp_stride_ = 1;
     bool piggyback_redirect_ = false; // the pending table accumulates into g_du_dx through slot_of_atom
@@ -684,6 +703,7 @@ private:
     DeviceBuffer<i128> d_u_buffer_, d_u_init_, d_u_final_;
     DeviceBuffer<u64> d_centroids_;
     DeviceBuffer<int> d_atom_idxs_, d_mol_idxs_, d_mol_offsets_, d_counters_;
+    ForcePlan plan_; // the two energy evaluations of an attempt
     void reset_counters();
 };
 

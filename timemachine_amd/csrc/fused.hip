@@ -16,6 +16,82 @@ __global__ __launch_bounds__(256) void k_fused_forces(
     fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl);
 }
 
+// The energy-only twin of fused_dispatch: same table, same per-term device functions with no force outputs asked for;
+// returns the term's fixed-point energy (0 for threads past a segment's end).
+template <typename Real>
+__device__ __forceinline__ i128 fused_dispatch_energy(
+    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
+    const double *__restrict__ box) {
+    const int n = table->n;
+    int s = 0, first = 0;
+    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
+        const int end = table->block_end[k];
+        if (block >= end) {
+            s = k + 1;
+            first = end;
+        }
+    }
+    const FusedSegment seg = table->seg[s];
+    const int idx = (block - first) * 256 + thread;
+    if (idx >= seg.count) {
+        return 0;
+    }
+    switch (seg.kind) {
+    case FUSED_BOND: return harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_ANGLE: return harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_TORSION: return periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST:
+        return nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST_NEGATED:
+        return nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST_PRECOMPUTED:
+        return nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, nullptr, nullptr, true);
+    case FUSED_CHIRAL_ATOM: return chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_CHIRAL_BOND: return chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, nullptr, nullptr, true);
+    case FUSED_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
+    case FUSED_LOG_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
+    default: return 0;
+    }
+}
+
+// every wave of every block writes its partial sum (zero included): the buffer needs no clearing
+template <typename Real>
+__global__ __launch_bounds__(256) void k_fused_energy(
+    const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, i128 *__restrict__ partials,
+    i128 *__restrict__ zero_slots, const int n_zero_slots) {
+    if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < n_zero_slots) {
+        zero_slots[threadIdx.x] = 0; // slots of potentials that run after this launch and may leave theirs untouched
+    }
+    const i128 e = fused_dispatch_energy<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box);
+    store_wave_energy<Real>(e, partials);
+}
+
+// final reduction over up to ENERGY_MAX_SOURCES arrays of partial sums (one workgroup: a few thousand values at most)
+static const int ENERGY_MAX_SOURCES = 12;
+struct EnergySources {
+    int n;
+    const i128 *p[ENERGY_MAX_SOURCES];
+    int count[ENERGY_MAX_SOURCES];
+};
+__global__ __launch_bounds__(256) void k_reduce_i128_sources(const EnergySources src, i128 *__restrict__ out) {
+    __shared__ i128 s_part[4];
+    i128 acc = 0;
+    for (int k = 0; k < src.n; k++) {
+        const i128 *__restrict__ in = src.p[k];
+        for (int i = threadIdx.x; i < src.count[k]; i += 256) {
+            acc += in[i];
+        }
+    }
+    acc = wave_sum_i128(acc);
+    if ((threadIdx.x & 63) == 0) {
+        s_part[threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
+}
+
 void ForcePlan::clear() {
     host_[0].n = 0;
     host_[1].n = 0;
@@ -34,19 +110,10 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
     t.n++;
 }
 
-bool ForcePlan::run(
-    const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
-    const int max_deferred, u64 *d_du_dx_cm, const int cm_stride) {
-    bool wrote_du_dx = false; // did anything add to the [N, 3] array?
-    // the table's terms go to the caller's component-major accumulator when there is one (lanes working on neighbouring
-    // atoms then share cache lines: fewer line requests for the memory-side atomics), to the [N, 3] array otherwise
-    u64 *table_acc = d_du_dx_cm ? d_du_dx_cm : d_du_dx;
-    const ForceLayout table_fl = d_du_dx_cm ? ForceLayout{1, cm_stride} : ForceLayout{3, 1};
-    // 1. tables to the device (only when they changed since the last step)
-    bool pending[2] = {false, false};
-    bool table_went_to_acc = false; // a table's forces were (or will be) added to table_acc
+void ForcePlan::upload_tables(bool pending[2], hipStream_t stream) {
     for (int prec = 0; prec < 2; prec++) {
         FusedTable &t = host_[prec];
+        pending[prec] = false;
         if (t.n == 0) {
             continue;
         }
@@ -67,6 +134,83 @@ bool ForcePlan::run(
             uploaded_valid_[prec] = true;
         }
     }
+}
+
+void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, i128 *d_u, hipStream_t stream) {
+    bool pending[2];
+    this->upload_tables(pending, stream);
+    EnergySources src;
+    src.n = 0;
+    // potentials that reduce for themselves get a slot each; every slot is one value of one source
+    const int n_rest = static_cast<int>(rest_.size());
+    d_e_slots_.reserve(std::max(n_rest, 1));
+    int n_slots = 0;
+    bool slots_zeroed = false;
+    // 1. the tables: one launch per precision, per-wave partial sums
+    for (int prec = 0; prec < 2; prec++) {
+        if (!pending[prec]) {
+            continue;
+        }
+        const int blocks = host_[prec].block_end[host_[prec].n - 1];
+        d_e_partials_[prec].reserve(static_cast<size_t>(blocks) * 4);
+        const int zero_now = slots_zeroed ? 0 : std::min(n_rest, 256);
+        if (prec == 1) {
+            k_fused_energy<double><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_e_partials_[prec].data, d_e_slots_.data, zero_now);
+        } else {
+            k_fused_energy<float><<<blocks, 256, 0, stream>>>(d_table_[prec].data, d_x, d_box, d_e_partials_[prec].data, d_e_slots_.data, zero_now);
+        }
+        HIP_CHECK(hipGetLastError());
+        slots_zeroed = slots_zeroed || n_rest <= 256;
+        src.p[src.n] = d_e_partials_[prec].data;
+        src.count[src.n] = blocks * 4;
+        src.n++;
+    }
+    // 2. the potentials that launch their own kernels
+    for (int i = 0; i < n_rest; i++) {
+        const Rest &r = rest_[i];
+        bool shared = false; // bound more than once: its partial buffer would be overwritten before the final reduction
+        for (int j = 0; j < n_rest; j++) {
+            shared = shared || (j != i && rest_[j].pot == r.pot);
+        }
+        const i128 *partials = nullptr;
+        int count = 0;
+        if (!shared && src.n < ENERGY_MAX_SOURCES - 1 && r.pot->execute_energy_partials(N, r.P, d_x, r.d_p, d_box, stream, partials, count)) {
+            if (count > 0) {
+                src.p[src.n] = partials;
+                src.count[src.n] = count;
+                src.n++;
+            }
+            continue;
+        }
+        if (!slots_zeroed) { // (a potential may leave its d_u as the caller set it: interaction groups without interactions)
+            d_e_slots_.zero_async(stream, std::max(n_rest, 1));
+            slots_zeroed = true;
+        }
+        r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, nullptr, nullptr, d_e_slots_.data + n_slots, stream);
+        n_slots++;
+    }
+    if (n_slots > 0) {
+        src.p[src.n] = d_e_slots_.data;
+        src.count[src.n] = n_slots;
+        src.n++;
+    }
+    // 3. one reduction over everything
+    k_reduce_i128_sources<<<1, 256, 0, stream>>>(src, d_u);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool ForcePlan::run(
+    const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
+    const int max_deferred, u64 *d_du_dx_cm, const int cm_stride) {
+    bool wrote_du_dx = false; // did anything add to the [N, 3] array?
+    // the table's terms go to the caller's component-major accumulator when there is one (lanes working on neighbouring
+    // atoms then share cache lines: fewer line requests for the memory-side atomics), to the [N, 3] array otherwise
+    u64 *table_acc = d_du_dx_cm ? d_du_dx_cm : d_du_dx;
+    const ForceLayout table_fl = d_du_dx_cm ? ForceLayout{1, cm_stride} : ForceLayout{3, 1};
+    // 1. tables to the device (only when they changed since the last step)
+    bool pending[2] = {false, false};
+    this->upload_tables(pending, stream);
+    bool table_went_to_acc = false; // a table's forces were (or will be) added to table_acc
     // 2. a long-running force kernel of the same precision may take a table along (its early-finishing waves run it)
     for (const Rest &r : rest_) {
         for (int prec = 0; prec < 2; prec++) {

@@ -659,7 +659,38 @@ void NonbondedAllPairs<Real>::execute_device(
     if (empty_) {
         return; // reference: nonbonded_interaction_group.cu:171-174 (outputs untouched, d_u left as the caller set it)
     }
-    this->run_pipeline(d_x, d_p, d_box, d_du_dx, d_du_dp, d_u, true, stream);
+    // An energy-only call on exactly the inputs the last MD step left pre-gathered (the barostat's "before" energy,
+    // a frame's energy right after multiple_steps) reads the sorted records as they are: no gather, no bounds kernel, and
+    // above all no forced list rebuild -- the update kernel has already made the displacement test for these coordinates.
+    // (Accumulators are not touched by an energy-only launch; the hand-over is consumed: the next call gathers itself.)
+    const bool pregathered = d_du_dx == nullptr && d_du_dp == nullptr && d_u != nullptr && pre_valid_ && d_x == pre_x_ &&
+                             d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ && calls_since_sort_ % steps_per_sort_ != 0;
+    this->run_pipeline(d_x, d_p, d_box, d_du_dx, d_du_dp, d_u, true, stream, pregathered);
+}
+
+template <typename Real>
+bool NonbondedAllPairs<Real>::execute_energy_partials(
+    const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials,
+    int &count) {
+    this->check_sizes(N, P);
+    if (empty_) {
+        partials = d_u_partials_.data; // an interaction group without interactions: nothing to add
+        count = 0;
+        return true;
+    }
+    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
+                             calls_since_sort_ % steps_per_sort_ != 0;
+    defer_u_reduce_ = true;
+    try {
+        this->run_pipeline(d_x, d_p, d_box, nullptr, nullptr, d_u_partials_.data, true, stream, pregathered);
+    } catch (...) {
+        defer_u_reduce_ = false;
+        throw;
+    }
+    defer_u_reduce_ = false;
+    partials = d_u_partials_.data;
+    count = u_partials_count_;
+    return true;
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, const int P) const {
@@ -782,7 +813,9 @@ void NonbondedAllPairs<Real>::run_pipeline(
         k_scatter_accum<4><<<ceil_divide(K_ * 4, tpb), tpb, 0, stream>>>(K_, d_perm_.data, d_g_du_dp_.data, acc_stride_, d_du_dp);
         HIP_CHECK(hipGetLastError());
     }
-    if (d_u) {
+    if (d_u && defer_u_reduce_) {
+        u_partials_count_ = launched_waves; // the caller adds them up together with everything else it evaluates
+    } else if (d_u) {
         reduce_i128_device(d_u_partials_.data, launched_waves, d_u, stream);
     }
     TM_DEBUG_SYNC("scatter / reduce", stream);

@@ -278,6 +278,14 @@ void SummedPotential::execute_device(
         plan_.run(N, d_x, d_box, d_du_dx, stream);
         return;
     }
+    if (d_u && !d_du_dx && !d_du_dp) {
+        // energy only (barostat attempts, HREX energy matrices, frame energies): the same plan, evaluated for energies --
+        // one launch for all short terms, one reduction for everything (ForcePlan::run_energy)
+        plan_.clear();
+        this->plan_forces(N, P, d_p, plan_);
+        plan_.run_energy(N, d_x, d_box, d_u, stream);
+        return;
+    }
     if (d_u) {
         d_u_buffer_.zero_async(stream, n);
     }
@@ -327,6 +335,12 @@ void FanoutSummedPotential::execute_device(
         plan_.clear();
         this->plan_forces(N, P, d_p, plan_);
         plan_.run(N, d_x, d_box, d_du_dx, stream);
+        return;
+    }
+    if (d_u && !d_du_dx && !d_du_dp) {
+        plan_.clear();
+        this->plan_forces(N, P, d_p, plan_);
+        plan_.run_energy(N, d_x, d_box, d_u, stream);
         return;
     }
     if (d_u) {
