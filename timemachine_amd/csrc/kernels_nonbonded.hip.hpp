@@ -271,7 +271,12 @@ template <typename Real> struct TileRegs {
 // INSIDE_SWITCH (f64 forces-only launches): the host vouches for cutoff <= TM_ES_SWITCH_D -- every caller the reference has --
 // so no pair inside the cutoff lies beyond the end of the electrostatic switch.  A template parameter and not a branch in
 // the kernel: a second copy of the batch body inside the item loop cost 2 % of the launch, executed or not.
-template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP, bool INSIDE_SWITCH = false>
+// SPLIT (1, 2 or 4; forces-only launches of SMALL systems): a work item is dealt as SPLIT tickets, each covering 32 / SPLIT of
+// the item's 32 filter rounds (and the pairs they find).  With fewer items than waves, one item is one wave's whole life --
+// 16 us of a lone wave's exposed latencies for a full 32 x 64 tile -- and the launch lasts as long as its heaviest item;
+// split, the same work is SPLIT independent chains on different SIMDs.  (Large systems keep SPLIT = 1: several items per
+// wave, and every ticket repeats the item's fetch, its LDS staging and its flush.)
+template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP, bool INSIDE_SWITCH = false, int SPLIT = 1>
 __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (TileShape<Real, COMPUTE_DU_DP>::min_waves)) void k_nonbonded_tiles(
     const int K,                               // atoms in `gathered` (record K is an all-zero sentinel)
     const int NR,                              // number of row atoms
@@ -402,7 +407,24 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         const unsigned int w = (r & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
         return r * gridDim.x + w;
     };
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT");
+    constexpr int ROUNDS = TILE / SPLIT; // filter rounds per ticket
+    [[maybe_unused]] int sub_drawn = 0;  // which part of its item the ticket last passed to position_to_slot covers
     auto position_to_slot = [&](unsigned int g) -> unsigned int {
+        if constexpr (SPLIT > 1) {
+            // positions [k * n, (k + 1) * n) are part k of the cost-sorted items: heaviest first within every pass
+            int part = 0;
+#pragma unroll
+            for (int k = 1; k < SPLIT; k++) {
+                if (g >= n_items_total) {
+                    g -= n_items_total;
+                    part = k;
+                }
+            }
+            // (uniform in fact -- g and the item count are the same in every lane -- but not as far as the compiler can tell:
+            // the count comes out of a shuffle)
+            sub_drawn = __builtin_amdgcn_readfirstlane(part);
+        }
         if (g >= n_items_total) {
             return NO_ITEM;
         }
@@ -449,6 +471,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 
     // prologue: first item fetched the slow way (ticket = wave index)
     unsigned int item = position_to_slot(position_of_ticket(static_cast<unsigned int>(wave)));
+    [[maybe_unused]] int sub_cur = sub_drawn, sub_next = 0;
     TileRegs<Real> cur;
     if (item != NO_ITEM) {
         load_indices(items[item], cur);
@@ -575,11 +598,14 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #endif
         int cnt = 0; // wave-uniform number of queued pairs
         // both halves of the wave start with row (lane & 31) in hand (the upper half gets its copy from the lower)
+        // (a ticket that starts at round r_begin starts with row (lane + r_begin) & 31 in hand)
+        const int r_begin = SPLIT > 1 ? sub_cur * ROUNDS : 0;
+        const int r_end = r_begin + ROUNDS;
         float4 rot;
-        rot.x = __shfl(s_rowf_mine.x, lane & (TILE - 1), 64);
-        rot.y = __shfl(s_rowf_mine.y, lane & (TILE - 1), 64);
-        rot.z = __shfl(s_rowf_mine.z, lane & (TILE - 1), 64);
-        rot.w = __shfl(s_rowf_mine.w, lane & (TILE - 1), 64);
+        rot.x = __shfl(s_rowf_mine.x, (lane + r_begin) & (TILE - 1), 64);
+        rot.y = __shfl(s_rowf_mine.y, (lane + r_begin) & (TILE - 1), 64);
+        rot.z = __shfl(s_rowf_mine.z, (lane + r_begin) & (TILE - 1), 64);
+        rot.w = __shfl(s_rowf_mine.w, (lane + r_begin) & (TILE - 1), 64);
         // measured (ns/day, f64 / f32): drawn at round 0: 2145 / 2900; 16: 2175 / 2905; 24: 2190 / 2897; 28: 2207 / 2925;
         // after the last round (descriptor load exposed): 2190 / 2965
 #ifdef TM_TICKET_ROUND
@@ -587,9 +613,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #else
         constexpr int TICKET_ROUND = sizeof(Real) == 8 ? TILE - 4 : TILE;
 #endif
-        for (int round0 = 0; round0 < TILE; round0 += 4) {
-            if (round0 == TICKET_ROUND) { // ---- stage A: draw the next item, request its descriptor
+        for (int round0 = r_begin; round0 < r_end; round0 += 4) {
+            if (round0 == (SPLIT > 1 ? r_begin + (TICKET_ROUND - (TILE - ROUNDS)) : TICKET_ROUND)) { // ---- stage A: draw the next item, request its descriptor
                 item_next = position_to_slot(next_position());
+                sub_next = sub_drawn;
                 have_next = item_next != NO_ITEM;
                 if (have_next) {
                     it_next = items[item_next];
@@ -665,7 +692,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             cnt = 0; // ablation: no phase 2 at all
 #endif
             // ---- phase 2: drain full batches (and everything after the last rounds)
-            const bool last = round0 == TILE - 4;
+            const bool last = round0 == r_end - 4;
             // one batch: lane `lane` (if active) takes the pair queued at `slot`.
             // (Measured and dropped: queueing the pairs without a Lennard-Jones term -- 8 of 9 in water -- apart from the
             // others, so that their batches neither read sigma / epsilon nor run the LJ code: one more partial batch per item
@@ -776,6 +803,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         }
         if (TICKET_ROUND >= TILE) { // f32: draw only now (the descriptor load is exposed, the balance pays for it)
             item_next = position_to_slot(next_position());
+            sub_next = sub_drawn;
             have_next = item_next != NO_ITEM;
             if (have_next) {
                 it_next = items[item_next];
@@ -852,6 +880,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #endif
         cur = nxt;
         item = item_next;
+        sub_cur = sub_next;
     }
 #ifdef TM_TIMING
     if (lane == 0 && timing) {
