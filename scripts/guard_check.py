@@ -39,5 +39,29 @@ bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(small)]
 ctxt = co.Context(small.coords, np.zeros_like(small.coords), small.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, small.masses, 3).impl(), bps)
 ctxt.multiple_steps(600, 0)
 total += check("small system md")
+# NPT (fused energy launches, pre-gathered before-energy), local MD (narrowed all-pairs + interaction group + restraints),
+# and the SPLIT = 2 / 4 kernels of small systems in both precisions
+mid = ts.config4_solvated_ligand()
+for prec in (np.float32, np.float64):
+    N = mid.num_atoms
+    bps = [bp.to_gpu(prec).bound_impl for bp in ts.bound_potentials(mid)]
+    groups = [list(range(3 * i, 3 * i + 3)) for i in range((N - 30) // 3)] + [list(range(N - 30, N))]
+    baro = MonteCarloBarostat(N, 1.0, 300.0, groups, 5, 11).impl(bps)
+    ctxt = co.Context(mid.coords, np.zeros_like(mid.coords), mid.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, mid.masses, 2).impl(), bps, movers=[baro])
+    ctxt.multiple_steps(300, 0)
+    total += check(f"npt {prec.__name__}")
+    for fr in (True, False):
+        ctxt = co.Context(mid.coords, np.zeros_like(mid.coords), mid.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, mid.masses, 2).impl(), bps)
+        ctxt.setup_local_md(300.0, fr)
+        ctxt.multiple_steps_local(100, np.arange(N - 30, N - 25, dtype=np.int32), radius=0.8, seed=3)
+        ctxt.multiple_steps(50, 0)
+        ref_atom, free = ctxt.local_md_last_selection()
+        ctxt.multiple_steps_local_selection(50, ref_atom, free[free != ref_atom].astype(np.int32), radius=0.8)
+    total += check(f"local md {prec.__name__}")
+    for sysm in (ts.config1_water_cluster(3.0), ts.small_solvated_ligand()):
+        b2 = [bp.to_gpu(prec).bound_impl for bp in ts.bound_potentials(sysm)]
+        c2 = co.Context(sysm.coords, np.zeros_like(sysm.coords), sysm.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, sysm.masses, 2).impl(), b2)
+        c2.multiple_steps(300, 0)
+    total += check(f"split kernels {prec.__name__}")
 print("TOTAL", total)
 sys.exit(1 if total else 0)
