@@ -451,3 +451,75 @@ def test_local_md_restraint_holds_the_free_atoms(co, solvated, precision):
     # water O-H bonds are still bonds
     oh = np.linalg.norm(x_prev[1 : N - 30 : 3] - x_prev[0 : N - 30 : 3], axis=1)
     assert 0.08 < oh.min() and oh.max() < 0.115
+
+
+@pytest.mark.parametrize("freeze_reference", [True, False])
+def test_local_md_nonbonded_all_pairs_subset(co, freeze_reference):
+    """tests/test_md.py:838-892: a Nonbonded over five random atoms of thirty (exclusions filtered with it); the reference
+    atom need not be one of them.  Local MD runs, and the potential answers afterwards exactly as before."""
+    from timemachine_amd.lib import LangevinIntegrator
+
+    coords, params, pot, masses = tiny_nb_system(2022, N=30)
+    rng = np.random.default_rng(2022)
+    N = len(coords)
+    box = np.eye(3) * 3.0
+    pot.atom_idxs = np.sort(rng.choice(np.arange(N, dtype=np.int32), size=5, replace=False)).astype(np.int32)
+    bps = [pot.bind(params).to_gpu(np.float32).bound_impl]
+    ref_vals = [bp.execute(coords, box) for bp in bps]
+    ctxt = co.Context(coords, np.zeros_like(coords), box, LangevinIntegrator(TEMP, 1.5e-3, 0.0, masses, 2022).impl(), bps)
+    ctxt.setup_local_md(TEMP, freeze_reference)
+    xs, boxes = ctxt.multiple_steps_local(100, np.array([N - 1], dtype=np.int32), radius=1.2)
+    assert np.all(np.isfinite(xs))
+    for (ref_du_dx, ref_u), bp in zip(ref_vals, bps):
+        du_dx, u = bp.execute(coords, box)
+        np.testing.assert_array_equal(ref_du_dx, du_dx)
+        np.testing.assert_equal(ref_u, u)
+        du_dx_end, _ = bp.execute(xs[-1], boxes[-1])
+        assert np.all(np.isfinite(du_dx_end))
+        # atoms outside the potential's subset feel nothing from it, before and after
+        outside = np.setdiff1d(np.arange(N), pot.atom_idxs)
+        assert not np.any(du_dx[outside]) and not np.any(du_dx_end[outside])
+
+
+def test_setup_context_with_references(co, solvated):
+    """tests/test_md.py:769-835: a Context keeps its integrator, bound potentials and movers alive on its own, and lets go of
+    them when it goes"""
+    import gc
+    import weakref
+
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s, coords = solvated
+    N = s.num_atoms
+
+    def build_context(barostat_interval):
+        refs, bps = [], []
+        for bp in ts.bound_potentials(s):
+            impl = bp.to_gpu(np.float32).bound_impl
+            bps.append(impl)
+            refs.append(weakref.ref(impl))
+        movers = []
+        if barostat_interval > 0:
+            groups = [list(range(3 * i, 3 * i + 3)) for i in range((N - 30) // 3)] + [list(range(N - 30, N))]
+            baro = MonteCarloBarostat(N, 1.0, TEMP, groups, barostat_interval, 2022).impl(bps)
+            movers.append(baro)
+            refs.append(weakref.ref(baro))
+        intg = LangevinIntegrator(TEMP, 1.5e-3, 0.0, s.masses, 2022).impl()
+        refs.append(weakref.ref(intg))
+        return co.Context(coords, np.zeros_like(coords), s.box, intg, bps, movers=movers), refs
+
+    for interval in (0, 10):
+        ctxt, refs = build_context(interval)
+        gc.collect()
+        assert all(r() is not None for r in refs)  # only the Context holds them now
+        xs, boxes = ctxt.multiple_steps(100)
+        assert np.all(np.isfinite(xs)) and np.all(np.isfinite(boxes))
+        assert np.all(xs[-1] != coords)
+        if interval == 0:
+            np.testing.assert_array_equal(boxes[-1], s.box)
+        else:
+            assert np.all(np.diagonal(boxes[-1]) != np.diagonal(s.box))  # the barostat changed the box
+        del ctxt
+        gc.collect()
+        assert all(r() is None for r in refs)
