@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--padding", type=float, default=0.18, help="nblist_padding of the nonbonded potential: a speed knob of the potential's constructor, "
                     "results do not depend on it bit for bit (reference default 0.1; 0.18 measured fastest here, DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-npt", action="store_true", help="skip the barostat-interval-25 leg (profiling runs: keeps the trace's tail the timed NVT steps)")
     ap.add_argument("--profile-steps", type=int, default=400)
     ap.add_argument("--windows", type=int, default=None, help="lambda windows (md: rows of the end-of-run u_kl gather, default 8; hrex: states, default 24)")
     ap.add_argument("--steps-per-frame", type=int, default=400, help="hrex: MD steps between exchanges (fe/free_energy.py default)")
@@ -587,11 +588,15 @@ def run_md(args, rank, local_rank, world, backend):
             out["other_precision_error"] = str(exc)
         # NPT: the same box with the Monte Carlo barostat every 25 steps (the reference benchmarks both ensembles)
         try:
+            if args.no_npt:
+                raise KeyboardInterrupt
             n_npt = max(args.steps // 2, 25)
             d3, _, _, _, _ = run(precision, n_npt, max(args.warmup // 2, 25), 0, barostat_interval=25)
             out["npt"] = {"barostat_interval": 25, "pressure_bar": 1.0, "ns_day": n_npt / d3 * 86400.0 * DT * 1e-3,
                           "ms_per_step": 1e3 * d3 / n_npt, "dtype": args.precision,
                           "note": "reference: tests/test_benchmark.py:517-518 (dhfr-apo-barostat-interval-25); two energy-only evaluations per attempt"}
+        except KeyboardInterrupt:
+            pass
         except Exception as exc:  # pragma: no cover
             out["npt_error"] = str(exc)
         if not args.no_cpu_baseline:

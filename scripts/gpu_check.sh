@@ -10,7 +10,7 @@ if [ "${RUN_BENCH:-1}" = "1" ]; then
   echo "== bench"; timeout 600 python bench.py --steps ${BENCH_STEPS:-1000} --warmup 200 > gpurun_out/bench.log 2>&1; echo "bench exit $?"; tail -5 gpurun_out/bench.log
 fi
 if [ "${RUN_PROF:-1}" = "1" ]; then
-  echo "== rocprofv3"; cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; echo "rocprof exit $?"; cd $GRAFT_REPO_ROOT
+  echo "== rocprofv3"; cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-npt --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; echo "rocprof exit $?"; cd $GRAFT_REPO_ROOT
   find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
 fi
 find gpurun_out/prof -name "*.db" -delete 2>/dev/null; du -sh gpurun_out

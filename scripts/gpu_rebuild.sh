@@ -6,7 +6,7 @@ for lib in "$@"; do
   if [ "$lib" = "default" ]; then unset TM_AMD_LIB; else export TM_AMD_LIB=$GRAFT_REPO_ROOT/timemachine_amd/csrc/$lib; fi
   tag=rb_$(echo $lib | tr -c 'a-zA-Z0-9' '_')
   mkdir -p gpurun_out/$tag
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/$tag/bench.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-npt --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/$tag/bench.log 2>&1)
   echo "== $lib: $(tail -1 gpurun_out/$tag/bench.log | cut -c1-120)"
   python - "$tag" <<'PY'
 import csv, sys
