@@ -262,6 +262,10 @@ int tm_hilbert_lut(uint32_t *out);
 int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
+/* debugging / A-B aid: potentials a barostat works on follow small box changes without rebuilding their neighbor list
+ * (DESIGN.md section 9, item 6).  0 turns that off process-wide (every box change rebuilds, as in the reference);
+ * results are bit-identical either way -- the test suite checks exactly that. */
+int tm_debug_set_box_scaling_reuse(int enabled);
 /* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.hip.hpp):
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
  * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */

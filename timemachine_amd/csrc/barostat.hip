@@ -185,6 +185,9 @@ MonteCarloBarostat<Real>::MonteCarloBarostat(
       temperature_(static_cast<Real>(temperature)), seed_(static_cast<unsigned long long>(static_cast<long long>(seed))),
       num_mols_(static_cast<int>(group_idxs.size())), num_grouped_atoms_(0), attempt_(0) {
     this->set_interval(interval); // validates
+    for (auto &bp : bps_) {
+        bp->potential->expect_box_scaling();
+    }
     if (temperature < 100.0) {
         std::cout << "warning temperature less than 100K" << std::endl;
     }

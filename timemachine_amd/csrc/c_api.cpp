@@ -834,6 +834,11 @@ int tm_hilbert_lut(uint32_t *out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+int tm_debug_set_box_scaling_reuse(int enabled) {
+    TM_TRY
+    g_box_scaling_reuse = enabled != 0;
+    TM_CATCH
+}
 int tm_profile_set_enabled(int enabled) {
     TM_TRY
     Profiler::get().set_enabled(enabled != 0);

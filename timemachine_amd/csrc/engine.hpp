@@ -168,6 +168,9 @@ public:
     // Anything a potential remembers about its inputs between calls (pre-gathered positions) is dropped.  Called when
     // coordinates, box or parameters change behind an unchanged pointer (set_params, Context::set_x_t, movers).
     virtual void invalidate_cached_inputs() {}
+    // A barostat is going to evaluate and move this potential's system: the box changes by fractions of a percent between
+    // calls.  Potentials with a neighbor list then follow small box changes without rebuilding it (k_check_gather_scaled).
+    virtual void expect_box_scaling() {}
 
     // Accumulates into d_du_dx / d_du_dp (caller zeroes them), overwrites d_u.  Any output may be nullptr.
     virtual void execute_device(
@@ -243,6 +246,11 @@ public:
             pot->invalidate_cached_inputs();
         }
     }
+    void expect_box_scaling() override {
+        for (auto &pot : potentials_) {
+            pot->expect_box_scaling();
+        }
+    }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
 
@@ -265,6 +273,11 @@ public:
     void invalidate_cached_inputs() override {
         for (auto &pot : potentials_) {
             pot->invalidate_cached_inputs();
+        }
+    }
+    void expect_box_scaling() override {
+        for (auto &pot : potentials_) {
+            pot->expect_box_scaling();
         }
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
@@ -443,6 +456,8 @@ private:
 
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
+extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
+
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
 class NonbondedAllPairsBase : public Potential {
 public:
@@ -474,6 +489,7 @@ public:
     bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
+    void expect_box_scaling() override { box_scales_ = true; }
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
@@ -521,6 +537,15 @@ protected:
     const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
+    bool box_scales_ = false; // a barostat works on this potential (expect_box_scaling)
+    // scale-aware rebuild test (kernels_nonbonded.hip.hpp: k_check_gather_scaled): on when a mover is at work and the padding
+    // leaves room for the scale allowance
+    bool scale_aware() const { return box_scales_ && g_box_scaling_reuse && 0.5 * nblist_padding_ - 0.5 * 0.004 * (cutoff_ + nblist_padding_) > 0.25 * nblist_padding_; }
+    // squared displacement (against the list build's snapshot) beyond which the list is rebuilt
+    double rebuild_threshold2() const {
+        const double d = scale_aware() ? 0.5 * nblist_padding_ - 0.5 * 0.004 * (cutoff_ + nblist_padding_) : 0.5 * nblist_padding_;
+        return d * d;
+    }
     bool defer_u_reduce_ = false; // run_pipeline leaves the tile kernel's energy partials un-reduced (execute_energy_partials)
     int u_partials_count_ = 0;
     u64 *piggyback_acc_ = nullptr; // where the piggy-backed table's forces go, and its layout

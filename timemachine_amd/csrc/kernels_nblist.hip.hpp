@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void k_block_bounds(
         if (tid < 9) {
             snap_box[tid] = box[tid];
         }
+        if (tid < 3) {
+            snap_box[9 + tid] = 1.0; // the snapshot is in this box's own scale again (k_check_gather_scaled)
+        }
     }
     const int total_blocks = n_col_blocks + (rows_equal_cols ? 0 : n_row_blocks);
     const int lane = threadIdx.x & 63;
@@ -168,6 +171,9 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         }
         if (blockIdx.x == 0 && threadIdx.x < 9) {
             snap_box[threadIdx.x] = box[threadIdx.x];
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 3) {
+            snap_box[9 + threadIdx.x] = 1.0;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             counters[3] += 1;

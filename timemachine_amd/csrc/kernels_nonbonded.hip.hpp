@@ -227,6 +227,125 @@ __global__ void k_check_gather(
     }
 }
 
+// The same check + gather for a potential whose box may change by small factors between list builds (a barostat in the
+// Context): a changed box is not by itself a reason to rebuild.
+//
+// The list was built from a snapshot x_s in a box B_s and holds every pair closer than cutoff + padding there.  For ANY
+// later coordinates x in a box B = rho * B_s (rho per dimension, diagonal boxes): let e_i = minimum image in B of
+// x_i - rho * x_s,i.  A pair with image vector v in (x, B), |v| < cutoff, has the snapshot image vector w with
+// rho * w = v - e_i + e_j, so |w| <= (cutoff + 2 max|e|) / rho_min: the list is complete as long as
+//     max|e| < (rho_min (cutoff + padding) - cutoff) / 2.
+// With |rho - 1| <= NB_SCALE_MAX that holds whenever max|e| < padding / 2 - NB_SCALE_MAX (cutoff + padding) / 2 =: D, the one
+// threshold scale-aware potentials use everywhere (this kernel and the integrator's pre-gather test, engine.hpp).
+// When the box has changed but no atom is beyond D, the snapshot is re-expressed in the new box (x_s,i <- x_i - e_i: the same
+// displacement, next to the atom again) so that later tests compare like with like; snap_box[9..11] carries the accumulated
+// rho since the last build (reset to 1 by the build kernels), snap_box[0..8] follows in k_rebase_snapshot_box.
+#define NB_SCALE_MAX 0.004
+template <typename Real>
+__global__ void k_check_gather_scaled(
+    const int K, const unsigned int *__restrict__ perm, const double *__restrict__ x, const double *__restrict__ p,
+    const double *__restrict__ box, double *__restrict__ snap_x, const double *__restrict__ snap_box,
+    const double threshold2, // D^2
+    int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
+    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        *flag_clear = 0;
+    }
+    if (idx < 8) {
+        gathered[static_cast<size_t>(K) * 8 + idx] = 0;
+    }
+    // wave-uniform: what happened to the box since the snapshot was last expressed in it
+    bool same = true, scalable = true;
+    double rho[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double now = box[d * 3 + c], then = snap_box[d * 3 + c];
+            same = same && now == then;
+            if (c != d) {
+                scalable = scalable && now == then; // off-diagonal entries (zeros) must not have changed
+            }
+        }
+        b[d] = box[d * 4];
+        rho[d] = b[d] / snap_box[d * 4];
+        const double total = rho[d] * snap_box[9 + d];
+        scalable = scalable && fabs(total - 1.0) <= NB_SCALE_MAX; // (false for NaN / inf: an uninitialised snapshot)
+    }
+    if (!same && !scalable && idx == 0) {
+        *flag_set = 1;
+    }
+    if (idx >= K) {
+        return;
+    }
+    const unsigned int a = perm[idx];
+    slot_of_atom[a] = idx;
+    const double xd = x[a * 3 + 0], yd = x[a * 3 + 1], zd = x[a * 3 + 2];
+    double ex = xd - snap_x[a * 3 + 0], ey = yd - snap_x[a * 3 + 1], ez = zd - snap_x[a * 3 + 2];
+    if (!same && scalable) {
+        ex = xd - rho[0] * snap_x[a * 3 + 0];
+        ey = yd - rho[1] * snap_x[a * 3 + 1];
+        ez = zd - rho[2] * snap_x[a * 3 + 2];
+        ex -= b[0] * rint(ex / b[0]);
+        ey -= b[1] * rint(ey / b[1]);
+        ez -= b[2] * rint(ez / b[2]);
+        snap_x[a * 3 + 0] = xd - ex;
+        snap_x[a * 3 + 1] = yd - ey;
+        snap_x[a * 3 + 2] = zd - ez;
+    }
+    if (ex * ex + ey * ey + ez * ez > threshold2) {
+        *flag_set = 1;
+    }
+    Real *g = gathered + static_cast<size_t>(idx) * 8;
+    g[0] = static_cast<Real>(xd);
+    g[1] = static_cast<Real>(yd);
+    g[2] = static_cast<Real>(zd);
+    g[3] = static_cast<Real>(p[a * 4 + 3]); // w
+    g[4] = static_cast<Real>(p[a * 4 + 0]); // q
+    g[5] = static_cast<Real>(p[a * 4 + 1]); // sig
+    g[6] = static_cast<Real>(p[a * 4 + 2]); // eps
+    g[7] = 0;
+    if (g_du_dx) {
+        g_du_dx[0 * acc_stride + idx] = 0;
+        g_du_dx[1 * acc_stride + idx] = 0;
+        g_du_dx[2 * acc_stride + idx] = 0;
+    }
+    if (g_du_dp) {
+        g_du_dp[0 * acc_stride + idx] = 0;
+        g_du_dp[1 * acc_stride + idx] = 0;
+        g_du_dp[2 * acc_stride + idx] = 0;
+        g_du_dp[3 * acc_stride + idx] = 0;
+    }
+}
+
+// after k_check_gather_scaled (its threads still read the old values): the snapshot's box becomes the current one, the
+// accumulated scale takes the step.  A build that follows in the same call overwrites both.
+static __global__ void k_rebase_snapshot_box(const double *__restrict__ box, double *__restrict__ snap_box) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) {
+        return;
+    }
+    bool same = true, scalable = true;
+    double total[3];
+    for (int d = 0; d < 3; d++) {
+        for (int c = 0; c < 3; c++) {
+            same = same && box[d * 3 + c] == snap_box[d * 3 + c];
+            if (c != d) {
+                scalable = scalable && box[d * 3 + c] == snap_box[d * 3 + c];
+            }
+        }
+        total[d] = box[d * 4] / snap_box[d * 4] * snap_box[9 + d];
+        scalable = scalable && fabs(total[d] - 1.0) <= NB_SCALE_MAX;
+    }
+    if (same || !scalable) {
+        return;
+    }
+    for (int d = 0; d < 3; d++) {
+        snap_box[d * 4] = box[d * 4];
+        snap_box[9 + d] = total[d];
+    }
+}
+
 // ---- K5: un-permute (reference: k_scatter_accum, k_nonbonded.cuh:86-104) ------------------------------------
 template <int D>
 __global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ perm, const u64 *__restrict__ g, const int acc_stride, u64 *__restrict__ out) {

@@ -473,6 +473,8 @@ template class Neighborlist<double>;
 // =============================================================================================================
 // NonbondedAllPairs
 // =============================================================================================================
+bool g_box_scaling_reuse = true;
+
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty) {
     // reference: cpp/src/nonbonded_common.cpp:39-60 (messages are part of the contract)
     if (atom_idxs.size() == 0) {
@@ -542,7 +544,7 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     d_g_du_dx_.realloc(static_cast<size_t>(acc_stride_) * 3);
     d_g_du_dp_.realloc(static_cast<size_t>(acc_stride_) * 4);
     d_snap_x_.realloc(static_cast<size_t>(N_) * 3);
-    d_snap_box_.realloc(9);
+    d_snap_box_.realloc(12); // [0..8] the box the snapshot is expressed in; [9..11] accumulated scale since the last build
     HIP_CHECK(hipMemset(d_snap_x_.data, 0, d_snap_x_.size()));
     HIP_CHECK(hipMemset(d_snap_box_.data, 0, d_snap_box_.size()));
     d_flags_.realloc(2);
@@ -627,7 +629,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     out.next.gathered = d_gathered_.data;
     out.next.real_bytes = static_cast<int>(sizeof(Real));
     out.next.snap_x = d_snap_x_.data;
-    out.next.pad2_quarter = 0.25 * nblist_padding_ * nblist_padding_;
+    out.next.pad2_quarter = rebuild_threshold2();
     out.next.flag_set = d_flags_.data + parity_; // run_pipeline has already advanced parity_: the NEXT call's pair
     out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
     out.next.g_du_dx = d_g_du_dx_.data;
@@ -739,9 +741,16 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // `gathered`, made the displacement test and zeroed the accumulator it consumed (PregatherTarget).
     int *flag_now = d_flags_.data + parity_;
     int *flag_next = d_flags_.data + (parity_ ^ 1);
-    if (!pregathered) {
+    if (!pregathered && scale_aware()) {
+        // a mover (barostat) changes the box by fractions of a percent between list builds: see k_check_gather_scaled
+        k_check_gather_scaled<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
+            K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now, flag_next,
+            d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
+        k_rebase_snapshot_box<<<1, 1, 0, stream>>>(d_box, d_snap_box_.data);
+        HIP_CHECK(hipGetLastError());
+    } else if (!pregathered) {
         k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
-            K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, 0.25 * nblist_padding_ * nblist_padding_, flag_now,
+            K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now,
             flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
         HIP_CHECK(hipGetLastError());
         TM_DEBUG_SYNC("k_check_gather", stream);

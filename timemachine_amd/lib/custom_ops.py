@@ -1008,6 +1008,11 @@ def debug_float_to_fixed_energy(values, precision):
     return [(int(r["hi"]) << 64) | int(r["lo"]) for r in out]
 
 
+def debug_set_box_scaling_reuse(enabled):
+    """A/B aid: 0 = every box change rebuilds the neighbor lists (as the reference does); results are bit-identical."""
+    _check(_lib.tm_debug_set_box_scaling_reuse(_c_int(1 if enabled else 0)))
+
+
 def profile_set_enabled(enabled):
     _check(_lib.tm_profile_set_enabled(_c_int(1 if enabled else 0)))
 
