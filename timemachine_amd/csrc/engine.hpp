@@ -422,7 +422,10 @@ public:
         const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream,
         // bounds_done: the column-block bounds are current and the counters have been reset with the flag by somebody else
         // (PregatherTarget's sorted hand-over): no bounds kernel is launched, the list kernel takes the snapshot itself
-        const bool bounds_done = false);
+        const bool bounds_done = false,
+        // rebase_box: the caller's rebuild test was the scale-aware one (k_check_gather_scaled): when no rebuild follows, the
+        // bounds kernel re-expresses the snapshot's box in the current one on its way out
+        const bool rebase_box = false);
 
     int get_num_row_idxs() const { return NR_; }
     int num_row_blocks() const { return ceil_divide(NR_, TILE); }

@@ -35,8 +35,12 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     Real *__restrict__ col_ctr, Real *__restrict__ col_ext, Real *__restrict__ row_ctr, Real *__restrict__ row_ext,
     unsigned int *__restrict__ counters, // [0]=unused [1]=n_items [2]=tile count [3]=builds so far [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
     const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
-    const int *__restrict__ flag, const int force) {
+    const int *__restrict__ flag, const int force,
+    double *__restrict__ rebase_snap_box) { // != nullptr: scale-aware potentials (k_check_gather_scaled ran in front of this launch)
     if (!force && *flag == 0) {
+        if (rebase_snap_box != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+            rebase_snapshot_box(box, rebase_snap_box);
+        }
         return;
     }
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;

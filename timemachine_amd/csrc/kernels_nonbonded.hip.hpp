@@ -239,7 +239,7 @@ __global__ void k_check_gather(
 // threshold scale-aware potentials use everywhere (this kernel and the integrator's pre-gather test, engine.hpp).
 // When the box has changed but no atom is beyond D, the snapshot is re-expressed in the new box (x_s,i <- x_i - e_i: the same
 // displacement, next to the atom again) so that later tests compare like with like; snap_box[9..11] carries the accumulated
-// rho since the last build (reset to 1 by the build kernels), snap_box[0..8] follows in k_rebase_snapshot_box.
+// rho since the last build (reset to 1 by the build kernels), snap_box[0..8] follows in rebase_snapshot_box().
 #define NB_SCALE_MAX 0.004
 template <typename Real>
 __global__ void k_check_gather_scaled(
@@ -319,12 +319,10 @@ __global__ void k_check_gather_scaled(
     }
 }
 
-// after k_check_gather_scaled (its threads still read the old values): the snapshot's box becomes the current one, the
-// accumulated scale takes the step.  A build that follows in the same call overwrites both.
-static __global__ void k_rebase_snapshot_box(const double *__restrict__ box, double *__restrict__ snap_box) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) {
-        return;
-    }
+// after k_check_gather_scaled (a later launch: the check's threads read the old values): the snapshot's box becomes the current
+// one, the accumulated scale takes the step.  One thread; called from the bounds kernel that follows every check on the
+// non-pre-gathered path, in its "no rebuild" exit (a build resets both instead).
+__device__ __forceinline__ void rebase_snapshot_box(const double *__restrict__ box, double *__restrict__ snap_box) {
     bool same = true, scalable = true;
     double total[3];
     for (int d = 0; d < 3; d++) {

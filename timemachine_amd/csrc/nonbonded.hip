@@ -367,7 +367,7 @@ template <typename Real>
 void Neighborlist<Real>::build_device(
     const Real *d_gathered, const double *d_box, const double cutoff, const double cost_cutoff, const int *d_flag,
     const int force, const int n_snap, const double *d_x, double *d_snap_x, double *d_snap_box, hipStream_t stream,
-    const bool bounds_done) {
+    const bool bounds_done, const bool rebase_box) {
     const bool ut = this->upper_triangular();
     const int ncb = this->num_column_blocks();
     const int nrb = this->num_row_blocks();
@@ -383,7 +383,7 @@ void Neighborlist<Real>::build_device(
         k_block_bounds<Real, false><<<grid, tpb, 0, stream>>>(
             ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
             d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
-            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force);
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, rebase_box ? d_snap_box : nullptr);
         HIP_CHECK(hipGetLastError());
         TM_DEBUG_SYNC("k_block_bounds", stream);
     }
@@ -455,7 +455,7 @@ void Neighborlist<Real>::compute_block_bounds_host(
     k_block_bounds<Real, true><<<std::max(ceil_divide(total_blocks, DEFAULT_TPB / 64), 1), DEFAULT_TPB, 0, 0>>>(
         ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_scratch_gathered_.data,
         d_box.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, 0, nullptr, nullptr, nullptr,
-        reinterpret_cast<const int *>(d_counters_.data), 1);
+        reinterpret_cast<const int *>(d_counters_.data), 1, nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(0));
     std::vector<Real> ctr(ncb * 3), ext(ncb * 3);
@@ -746,7 +746,6 @@ void NonbondedAllPairs<Real>::run_pipeline(
         k_check_gather_scaled<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now, flag_next,
             d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
-        k_rebase_snapshot_box<<<1, 1, 0, stream>>>(d_box, d_snap_box_.data);
         HIP_CHECK(hipGetLastError());
     } else if (!pregathered) {
         k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
@@ -759,7 +758,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     nblist_.build_device(
         d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream,
-        pregathered && sorted_pending);
+        pregathered && sorted_pending, !pregathered && scale_aware());
 
     TM_DEBUG_SYNC("list build", stream);
     // (d) K4: tile kernel
