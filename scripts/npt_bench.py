@@ -1,5 +1,5 @@
 """ns/day of the DHFR-sized box with and without the Monte Carlo barostat (the reference benchmarks both:
-tests/test_benchmark.py:517-518, barostat_interval in [0, 25]).  python scripts/npt_bench.py [f32|f64] [interval] [steps]"""
+tests/test_benchmark.py:517-518, barostat_interval in [0, 25]).  python scripts/npt_bench.py [f32|f64] [interval] [steps] [dhfr|config4|config2]"""
 import sys
 import time
 
@@ -13,7 +13,8 @@ prec = np.float64 if (len(sys.argv) > 1 and sys.argv[1] == "f64") else np.float3
 interval = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 co.set_device(0)
-s = ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=1.2)
+which = sys.argv[4] if len(sys.argv) > 4 else "dhfr"
+s = {"dhfr": lambda: ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=1.2), "config4": ts.config4_solvated_ligand, "config2": ts.small_solvated_ligand}[which]()
 N = s.num_atoms
 DT = 2.5e-3
 
@@ -27,7 +28,8 @@ def make_bps(p):
 eq = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, s.masses, 1).impl(), make_bps(np.float32))
 eq.multiple_steps(3000, 0)
 x, v = eq.get_x_t(), eq.get_v_t()
-groups = [list(range(3 * i, 3 * i + 3)) for i in range(N // 3)]
+nw = s.num_water_atoms if s.num_water_atoms else N
+groups = [list(range(3 * i, 3 * i + 3)) for i in range(nw // 3)] + ([list(range(nw, N))] if nw < N else [])
 for label, iv in (("nvt", 0), ("npt", interval)):
     bps = make_bps(prec)
     movers = [MonteCarloBarostat(N, 1.0, 300.0, groups, iv, 7).impl(bps)] if iv > 0 else []

@@ -787,29 +787,29 @@ void NonbondedAllPairs<Real>::run_pipeline(
     piggyback_table_ = nullptr;
     piggyback_blocks_ = 0;
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
+    // Small systems have fewer work items (about K / 2) than the launch has waves: their items are dealt in halves or
+    // quarters (SPLIT) so that a launch does not last as long as one lone wave needs for a whole tile.
+    // Measured on water boxes at liquid density, us per MD step, SPLIT 1 / 2 / 4 (scripts/size_sweep.py):
+    //   K = 256: 29.8 / 22.2 / 18.1 (f32), 28.9 / 22.5 / 19.0 (f64);  900: 29.9 / 22.9 / 19.9, 29.8 / 23.8 / 21.7;
+    //   2243: 33.9 / 27.1 / 29.7, 33.7 / 29.1 / 31.7;  3600: 35.7 / 32.0 / 35.1, 36.1 / 31.2 / 37.0;
+    //   6318: 38.7 / 35.8 / 45.7, 40.1 / 42.0 / 48.4;  9000: 40.8 / 42.5 / 56.1, 44.4 / 49.5 / 61.5
+#ifndef TM_SPLIT4_MAX_K
+#define TM_SPLIT4_MAX_K 1536
+#define TM_SPLIT2_MAX_K_F32 7168
+#define TM_SPLIT2_MAX_K_F64 4608
+#endif
+    int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
+#ifdef TM_SPLIT_ENV
+    if (const char *e = getenv("TM_AMD_SPLIT")) {
+        split = atoi(e);
+    }
+#endif
     switch (sel) {
     case 0: TM_LAUNCH_TILES(false, false, false); break;
     case 1: TM_LAUNCH_TILES(false, false, true); break;
     case 2: {
         // MD: the f64 kernel has a form for cutoffs that do not reach beyond the end of the electrostatic switch (all of the
         // reference's callers: cutoff == 1.2 nm); see INSIDE_SWITCH.
-        // Small systems have fewer work items (about K / 2) than the launch has waves: their items are dealt in halves or
-        // quarters (SPLIT) so that the launch does not last as long as one lone wave needs for a whole tile.
-        // Measured on water boxes at liquid density, us per MD step, SPLIT 1 / 2 / 4 (scripts/size_sweep.py):
-        //   K = 256: 29.8 / 22.2 / 18.1 (f32), 28.9 / 22.5 / 19.0 (f64);  900: 29.9 / 22.9 / 19.9, 29.8 / 23.8 / 21.7;
-        //   2243: 33.9 / 27.1 / 29.7, 33.7 / 29.1 / 31.7;  3600: 35.7 / 32.0 / 35.1, 36.1 / 31.2 / 37.0;
-        //   6318: 38.7 / 35.8 / 45.7, 40.1 / 42.0 / 48.4;  9000: 40.8 / 42.5 / 56.1, 44.4 / 49.5 / 61.5
-#ifndef TM_SPLIT4_MAX_K
-#define TM_SPLIT4_MAX_K 1536
-#define TM_SPLIT2_MAX_K_F32 7168
-#define TM_SPLIT2_MAX_K_F64 4608
-#endif
-        int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
-#ifdef TM_SPLIT_ENV
-        if (const char *e = getenv("TM_AMD_SPLIT")) {
-            split = atoi(e);
-        }
-#endif
         const bool inside = sizeof(Real) == 8 && cutoff_ <= TM_ES_SWITCH_D;
         if (inside) {
             if constexpr (sizeof(Real) == 8) {
@@ -831,7 +831,15 @@ void NonbondedAllPairs<Real>::run_pipeline(
         break;
     }
     case 3: TM_LAUNCH_TILES(false, true, true); break;
-    case 4: TM_LAUNCH_TILES(true, false, false); break;
+    case 4: // energy only (barostat attempts, HREX energy rows): the same deal for small systems
+        if (split == 4) {
+            TM_LAUNCH_TILES(true, false, false, false, 4);
+        } else if (split == 2) {
+            TM_LAUNCH_TILES(true, false, false, false, 2);
+        } else {
+            TM_LAUNCH_TILES(true, false, false);
+        }
+        break;
     case 5: TM_LAUNCH_TILES(true, false, true); break;
     case 6: TM_LAUNCH_TILES(true, true, false); break;
     case 7: TM_LAUNCH_TILES(true, true, true); break;
