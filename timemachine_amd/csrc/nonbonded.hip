@@ -115,7 +115,10 @@ const double *es_force_table_device(const double beta) {
     return d;
 }
 
-static const int STEPS_PER_SORT = 100;       // reference: cpp/src/nonbonded_all_pairs.cu:16
+#ifndef TM_STEPS_PER_SORT
+#define TM_STEPS_PER_SORT 100
+#endif
+static const int STEPS_PER_SORT = TM_STEPS_PER_SORT; // reference: cpp/src/nonbonded_all_pairs.cu:16 (100).  Re-measured here (f64 ns/day at 50 / 100 / 200 / 400): 2907 / 2932 / 2927 / 2875
 static const int STEPS_PER_SORT_GROUP = 200; // reference: cpp/src/nonbonded_interaction_group.cu:17
 
 // =============================================================================================================
