@@ -728,7 +728,12 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #ifdef TM_TICKET_ROUND
         constexpr int TICKET_ROUND = TM_TICKET_ROUND;
 #else
-        constexpr int TICKET_ROUND = sizeof(Real) == 8 ? TILE - 4 : TILE;
+        // (f32 re-measured at the end of round 2 with the compaction kernel: drawn at round 16 / 24 / 28: 3203 / 3205 / 3206
+        // ns/day, after the last round: 3173 -- the in-loop draw now wins for f32 as well)
+#ifndef TM_TICKET_ROUND_F32
+#define TM_TICKET_ROUND_F32 (TILE - 4)
+#endif
+        constexpr int TICKET_ROUND = sizeof(Real) == 8 ? TILE - 4 : TM_TICKET_ROUND_F32;
 #endif
         for (int round0 = r_begin; round0 < r_end; round0 += 4) {
             if (round0 == (SPLIT > 1 ? r_begin + (TICKET_ROUND - (TILE - ROUNDS)) : TICKET_ROUND)) { // ---- stage A: draw the next item, request its descriptor
