@@ -463,7 +463,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
     // |prefactor * 2^36| below this: every force component of a pair inside the cutoff converts on the fast path
-    [[maybe_unused]] const double ps_limit = TM_FIXED_FAST_LIMIT / cutoff_d * 0.999999;
+    [[maybe_unused]] const double ps_limit = TM_FIXED_FAST_LIMIT / cutoff_d * 0.999999; // (/ 2^36: the same bound on the prefactor itself)
     const Real beta = static_cast<Real>(beta_d);
     i128 energy = 0;
     // phase-1 filter in f32: box, and a cutoff^2 padded far beyond the rounding error of the filter arithmetic
@@ -878,7 +878,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
                     if constexpr (COMPUTE_DU_DX) {
                         u64 fx, fy, fz;
-                        pair_force_fixed(o.prefactor, ddx, ddy, ddz, fx, fy, fz);
+                        // (f32: one range test on the prefactor instead of three on the products: 3204 -> 3241 ns/day; same bits)
+                        pair_force_fixed_bounded(o.prefactor, ddx, ddy, ddz, static_cast<Real>(ps_limit * (1.0 / 68719476736.0)), fx, fy, fz);
                         lds_add(&s_fi[0][pi], fx);
                         lds_add(&s_fi[1][pi], fy);
                         lds_add(&s_fi[2][pi], fz);

@@ -375,5 +375,26 @@ __device__ __forceinline__ void pair_force_fixed(float prefactor, float dx, floa
         }
     }
 }
+// the same with ONE range test: |prefactor * d| <= |prefactor| * cutoff for every component of a pair inside the cutoff, so
+// |prefactor| below `limit` = 2^51 / 2^36 / cutoff (less a hair) keeps all three products in the fast conversion's range
+__device__ __forceinline__ void pair_force_fixed_bounded(float prefactor, float dx, float dy, float dz, const float limit, u64 &fx, u64 &fy, u64 &fz) {
+    const double a = static_cast<double>(prefactor * dx) * static_cast<double>(TM_FIXED_EXPONENT);
+    const double b = static_cast<double>(prefactor * dy) * static_cast<double>(TM_FIXED_EXPONENT);
+    const double c = static_cast<double>(prefactor * dz) * static_cast<double>(TM_FIXED_EXPONENT);
+    fx = static_cast<u64>(real_to_int64_fast(a));
+    fy = static_cast<u64>(real_to_int64_fast(b));
+    fz = static_cast<u64>(real_to_int64_fast(c));
+    const bool big = !(__builtin_fabsf(prefactor) < limit); // (true for NaN)
+    if (__ballot(big) != 0ull) {
+        if (big) {
+            fx = static_cast<u64>(llrint(a));
+            fy = static_cast<u64>(llrint(b));
+            fz = static_cast<u64>(llrint(c));
+        }
+    }
+}
+__device__ __forceinline__ void pair_force_fixed_bounded(double prefactor, double dx, double dy, double dz, const double, u64 &fx, u64 &fy, u64 &fz) {
+    pair_force_fixed(prefactor, dx, dy, dz, fx, fy, fz);
+}
 
 } // namespace tmamd
