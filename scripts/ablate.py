@@ -32,10 +32,8 @@ def worker():
         co.profile_set_enabled(False)
         out.append(f"{name} {1e3 * ms / n:7.1f} us")
         import ctypes
-        buf = np.zeros(8 * 8192, dtype=np.int64)
-        cnt = ctypes.c_int(0)
-        co._check(co._lib.tm_nonbonded_all_pairs_debug_timing(nb._h, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(buf.size), ctypes.byref(cnt)))
-        t = buf[: cnt.value].reshape(-1, 8)
+        buf, cnt = nb.debug_timing(8192)
+        t = buf.reshape(-1)[:cnt].reshape(-1, 8)
         if t[:, 6].sum() > 0:
             tot = t[:, 6].astype(float)
             bc = (t[:, 4] >> 20).astype(float); sa = (t[:, 5] >> 20).astype(float)

@@ -14,10 +14,9 @@ from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat, custom_o
 
 
 def check(tag):
-    n = ctypes.c_int(0)
-    co._check(co._lib.tm_debug_check_guards(ctypes.byref(n)))
-    print(f"{tag}: guard violations = {n.value}", flush=True)
-    return n.value
+    n = co.debug_check_guards()
+    print(f"{tag}: guard violations = {n}", flush=True)
+    return n
 
 
 s = ts.dhfr_sized_water_box()

@@ -18,10 +18,8 @@ for prec, name, waves in ((np.float64, "f64", int(os.environ.get("WG_WAVES_F64",
     nb = P.NonbondedAllPairs(s.num_atoms, s.beta, s.cutoff).to_gpu(prec).unbound_impl
     for _ in range(int(os.environ.get('WARM', 3))):
         nb.execute(x, s.nb_params, s.box, True, False, False)
-    buf = np.zeros(8 * 8192, dtype=np.int64)
-    cnt = ctypes.c_int(0)
-    co._check(co._lib.tm_nonbonded_all_pairs_debug_timing(nb._h, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(buf.size), ctypes.byref(cnt)))
-    t = buf[: cnt.value].reshape(-1, 8)
+    buf, cnt = nb.debug_timing(8192)
+    t = buf.reshape(-1)[:cnt].reshape(-1, 8)
     items = (t[:, 4] & ((1 << 20) - 1)).astype(float)
     batches = (t[:, 5] & ((1 << 20) - 1)).astype(float)
     st = (t[:, 7] & 0xffffffff).astype(float)

@@ -19,10 +19,8 @@ waves = 12 if prec == np.float64 else 10
 nb = P.NonbondedAllPairs(s.num_atoms, s.beta, s.cutoff).to_gpu(prec).unbound_impl
 for _ in range(4):
     nb.execute(s.coords, s.nb_params, s.box, True, False, False)
-buf = np.zeros(8 * 8192, dtype=np.int64)
-cnt = ctypes.c_int(0)
-co._check(co._lib.tm_nonbonded_all_pairs_debug_timing(nb._h, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(buf.size), ctypes.byref(cnt)))
-t = buf[: cnt.value].reshape(-1, 8)
+buf, cnt = nb.debug_timing(8192)
+t = buf.reshape(-1)[:cnt].reshape(-1, 8)
 items = t[:, 4] & ((1 << 20) - 1)
 st = (t[:, 7] & 0xFFFFFFFF).astype(float)
 en = ((t[:, 7] >> 32) & 0xFFFFFFFF).astype(float)

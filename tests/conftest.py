@@ -15,6 +15,33 @@ def pytest_configure(config):
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def load_binding(name):
+    """The custom_ops module of one binding, whatever TM_AMD_BINDING selected as `timemachine_amd.lib.custom_ops`:
+    "pybind11" = the compiled module (csrc/wrap_custom_ops.cpp), "ctypes" = its ctypes twin.  Both sit on the same C ABI."""
+    import importlib
+    import importlib.util
+    import sysconfig
+
+    import timemachine_amd.lib as lib
+
+    if name == "ctypes":
+        return importlib.import_module("timemachine_amd.lib.custom_ops_ctypes")
+    assert name == "pybind11", name
+    if getattr(lib.custom_ops, "BINDING", None) == "pybind11":
+        return lib.custom_ops
+    path = os.path.join(os.path.dirname(lib.__file__), "custom_ops" + sysconfig.get_config_var("EXT_SUFFIX"))
+    spec = importlib.util.spec_from_file_location("timemachine_amd.lib.custom_ops", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session", params=["pybind11", "ctypes"])
+def any_binding(request):
+    """CPU tests of the boundary run against both bindings"""
+    return load_binding(request.param)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
@@ -25,12 +52,9 @@ def pytest_sessionfinish(session, exitstatus):
     as an out-of-bounds-write detector: report what the guard zones caught once every test has run."""
     if "guard" not in os.path.basename(os.environ.get("TM_AMD_LIB", "")):
         return
-    import ctypes
-
     from timemachine_amd.lib import custom_ops
 
-    n = ctypes.c_int(0)
-    custom_ops._check(custom_ops._lib.tm_debug_check_guards(ctypes.byref(n)))
-    print(f"\n[guard build] device-buffer guard violations over the session: {n.value}")
-    if n.value:
+    n = custom_ops.debug_check_guards()
+    print(f"\n[guard build] device-buffer guard violations over the session: {n}")
+    if n:
         session.exitstatus = 1

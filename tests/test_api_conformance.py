@@ -31,14 +31,41 @@ def api():
 
 
 @pytest.fixture(scope="module")
-def co():
-    from timemachine_amd.lib import custom_ops
+def co(any_binding):
+    """both bindings of the C ABI: the compiled pybind11 module (the product) and its ctypes twin"""
+    return any_binding
 
-    return custom_ops
+
+def _split_top_level(text):
+    """'a: X[int, int], b: bool = True' -> ['a: X[int, int]', 'b: bool = True'] (commas inside brackets do not split)"""
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "[(":
+            depth += 1
+        elif ch in "])":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur.strip())
+    return parts
 
 
 def _params(fn):
-    sig = inspect.signature(fn)
+    """(argument names, has-default flags): inspect.signature for Python callables, the signature line pybind11 writes into
+    __doc__ for compiled ones ("name(self: T, coords: ..., compute_u: bool = True) -> tuple")."""
+    try:
+        sig = inspect.signature(fn)
+    except (ValueError, TypeError):
+        line = fn.__doc__.strip().splitlines()[0]
+        inner = line[line.index("(") + 1 : line.rindex(")")]
+        parts = _split_top_level(inner)
+        names = [p.split(":")[0].strip() for p in parts]
+        defaults = [" = " in p.split(":", 1)[1] if ":" in p else False for p in parts]
+        return names, defaults
     ps = [p for p in sig.parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
     return [p.name for p in ps], [p.default is not inspect.Parameter.empty for p in ps]
 
@@ -101,18 +128,29 @@ def test_array_arguments_convert_like_the_binding_layer(co):
     TypeError, `[0]` and `[(0, 0)]` are accepted index arrays."""
     import numpy as np
 
-    assert co._i32([0]).dtype == np.int32
-    assert co._i32([(0, 0)]).shape == (1, 2)
-    assert co._u32([1, 2]).dtype == np.uint32
-    assert co._f64([1, 2]).dtype == np.float64
-    assert co._f64(np.arange(3, dtype=np.float32)).dtype == np.float64
-    assert co._i32(np.arange(3, dtype=np.int16)).dtype == np.int32
+    # exercised through real constructors whose own validation comes AFTER the conversion and fails before any device
+    # work ("src == dst"): a RuntimeError proves the argument converted, a TypeError that it was refused
+    def bond(idxs):
+        with pytest.raises(RuntimeError, match="src == dst"):
+            co.HarmonicBond_f32(idxs)
+
+    bond([(0, 0)])  # Python sequences convert element by element
+    bond([[3, 3]])
+    bond(np.array([[1, 1]], dtype=np.int16))  # safe casts convert
+    bond(np.array([[1, 1]], dtype=np.uint8))
     for bad in (
-        lambda: co._i32([0.5]),
-        lambda: co._i32(np.array([1], dtype=np.int64)),
-        lambda: co._u32([-1]),
-        lambda: co._i32([2**40]),
-        lambda: co._f64(np.array([1j])),
+        lambda: co.HarmonicBond_f32(np.array([[1, 1]], dtype=np.int64)),  # unsafe ndarray casts are refused
+        lambda: co.HarmonicBond_f32(np.array([[0.5, 1.5]])),
+        lambda: co.HarmonicBond_f32([[0, 2**40]]),  # out of range
+        lambda: co.NonbondedExclusions_f32(np.array([[0, 1]], dtype=np.int32), np.array([[1j, 1j]]), 2.0, 1.2),
     ):
         with pytest.raises(TypeError):
             bad()
+    with pytest.raises(RuntimeError, match="expected same number of pairs and scale tuples"):  # f32 -> f64 is safe
+        co.NonbondedPairList_f64(np.array([[0, 1]], dtype=np.int32), np.ones((2, 2), dtype=np.float32), 2.0, 1.2)
+    if co.BINDING == "ctypes":  # the twin's own conversion helper, element by element
+        assert co._i32([0]).dtype == np.int32 and co._i32([(0, 0)]).shape == (1, 2)
+        assert co._u32([1, 2]).dtype == np.uint32 and co._f64([1, 2]).dtype == np.float64
+        for bad in (lambda: co._u32([-1]), lambda: co._i32([2**40]), lambda: co._i32([0.5]), lambda: co._f64(np.array([1j]))):
+            with pytest.raises(TypeError):
+                bad()

@@ -32,10 +32,16 @@ def test_header_cites_reference_interfaces():
     assert text.count("wrap_kernels.cpp") >= 20  # every entry point names the binding it replaces
 
 
-def test_host_only_entry_points():
-    from timemachine_amd.lib import custom_ops
+def test_host_only_entry_points(any_binding):
+    assert any_binding.FIXED_EXPONENT == 0x1000000000
 
-    assert custom_ops.FIXED_EXPONENT == 0x1000000000
+    class custom_ops:  # the C ABI itself, through ctypes
+        _lib = ctypes.CDLL(LIB)
+        _I128 = np.dtype([("lo", np.uint64), ("hi", np.int64)])
+
+    custom_ops._lib.tm_fixed_to_float.restype = ctypes.c_double
+    custom_ops._lib.tm_fixed_to_float.argtypes = [ctypes.c_uint64]
+    custom_ops._lib.tm_energy_to_float.restype = ctypes.c_double
     assert custom_ops._lib.tm_fixed_to_float(ctypes.c_uint64(1 << 36)) == 1.0
     assert custom_ops._lib.tm_fixed_to_float(ctypes.c_uint64((1 << 64) - (1 << 35))) == -0.5
     rec = np.zeros(1, dtype=custom_ops._I128)
@@ -49,16 +55,17 @@ def test_host_only_entry_points():
     assert custom_ops._lib.tm_energy_to_float(rec.ctypes.data_as(ctypes.c_void_p)) == -1.0
 
 
-def test_hilbert_lut_of_the_library_is_bit_exact():
+def test_hilbert_lut_of_the_library_is_bit_exact(any_binding):
     from oracle import hilbert as ohilbert
-    from timemachine_amd.lib import custom_ops
+
+    custom_ops = any_binding
 
     np.testing.assert_array_equal(custom_ops.hilbert_lut(), ohilbert.lut())
 
 
-def test_constructor_validation_messages_match_reference():
+def test_constructor_validation_messages_match_reference(any_binding):
     """Messages are part of the contract (reference tests regex-match them); all raised before any GPU work."""
-    from timemachine_amd.lib import custom_ops
+    custom_ops = any_binding
 
     with pytest.raises(RuntimeError, match="Neighborlist N must be at least 1"):  # tests/test_nblist.py:22-25
         custom_ops.Neighborlist_f32(0)
@@ -167,6 +174,7 @@ def test_es_force_table_matches_the_analytic_function():
 
     from timemachine_amd.lib import custom_ops
 
+    assert custom_ops.BINDING == os.environ.get("TM_AMD_BINDING", "pybind11").lower()  # the product binding is the compiled module
     for beta in (2.0, 2.6):
         tab = custom_ops.es_force_table(beta)
         assert tab.shape == (256, 6) and np.all(np.isfinite(tab))

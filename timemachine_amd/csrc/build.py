@@ -4,6 +4,8 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so travels to the GPU box
 with the repo snapshot.  One object per translation unit, compiled in parallel, linked into one shared library.
+Then the compiled Python module timemachine_amd/lib/custom_ops.<abi>.so (pybind11, wrap_custom_ops.cpp, g++) is
+built against it.
 -ffp-contract=off: the per-pair math must compile to the same instruction sequence at every call site (exclusions are
 subtracted in fixed point and have to cancel bit-for-bit); every fused multiply-add we want is written explicitly.
 """
@@ -12,9 +14,14 @@ import hashlib
 import os
 import subprocess
 import sys
+import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libtimemachine_amd.so")
+# the compiled Python module (pybind11, host-only C++): timemachine_amd/lib/custom_ops.<abi>.so, linked against LIB
+BINDING_SRC = "wrap_custom_ops.cpp"
+BINDING = os.path.join(os.path.dirname(HERE), "lib", "custom_ops" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+CXX = os.environ.get("CXX", "g++")
 SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "local_md.hip", "potential.hip", "c_api.cpp"]
 HEADERS = [
     "common.hpp", "engine.hpp", "fixed_point.hip.hpp", "nb_pair.hip.hpp", "kernels_nonbonded.hip.hpp", "kernels_nblist.hip.hpp", "kernels_bonded.hip.hpp", "philox.hip.hpp", "nb_math.hip.hpp", "nb_math_coeffs.h", "nb_es_table.hip.hpp",
@@ -29,7 +36,7 @@ FLAGS = [
 
 def _stamp():
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS + ["build.py"]:
+    for f in SOURCES + HEADERS + [BINDING_SRC, "build.py"]:
         with open(os.path.join(HERE, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -69,10 +76,27 @@ def build_variant(tag, defines, only=None):
     return out
 
 
+def build_binding(verbose=True):
+    """custom_ops.<abi>.so: g++ only (no device code in it); RUNPATH $ORIGIN/../csrc finds the library it binds."""
+    import pybind11
+
+    cmd = [
+        CXX, "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+        "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], os.path.join(HERE, BINDING_SRC), "-o", BINDING,
+        "-L" + HERE, "-ltimemachine_amd", "-Wl,--enable-new-dtags,-rpath,$ORIGIN/../csrc",
+    ]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose and (r.stdout + r.stderr).strip():
+        print(f"--- {BINDING_SRC} ---\n{r.stdout + r.stderr}", file=sys.stderr)
+    if r.returncode != 0:
+        raise RuntimeError(f"{CXX} failed on {BINDING_SRC}")
+    return BINDING
+
+
 def build(force=False, verbose=True):
     stamp_file = os.path.join(HERE, ".build_stamp")
     stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    if not force and os.path.exists(LIB) and os.path.exists(BINDING) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
     objs = []
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -87,6 +111,7 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         print(r.stdout + r.stderr, file=sys.stderr)
         raise RuntimeError("link failed")
+    build_binding(verbose)
     with open(stamp_file, "w") as fh:
         fh.write(stamp)
     return LIB

@@ -5,13 +5,30 @@ by keyword: class names, field names, field order, defaults, and ``impl()`` / ``
 ``custom_ops`` constructor argument each field feeds is stated once, in ``_CTOR_ARGS``, next to the wrap_kernels.cpp lines
 that define that constructor.
 """
+import os
+import sys
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
 import numpy as np
 from numpy.typing import NDArray
 
-from . import custom_ops
+# `custom_ops` is the compiled pybind11 module (csrc/wrap_custom_ops.cpp -> lib/custom_ops.<abi>.so), like the reference's.
+# TM_AMD_BINDING=ctypes swaps in the ctypes mirror of the same surface (custom_ops_ctypes.py) -- both sit on the same C ABI and
+# the test suite runs against both; TM_AMD_LIB (a variant build of the library, A/B measurements) implies it, because the
+# compiled module is linked against the product library.
+if os.environ.get("TM_AMD_BINDING", "").lower() == "ctypes" or os.environ.get("TM_AMD_LIB"):
+    from . import custom_ops_ctypes as custom_ops
+
+    sys.modules[__name__ + ".custom_ops"] = custom_ops
+else:
+    try:
+        from . import custom_ops
+    except ImportError as e:  # no CPU fallback, no silent second choice: say what is missing
+        raise ImportError(
+            f"timemachine_amd.lib.custom_ops (the compiled pybind11 module) could not be imported: {e}. Build it first: "
+            "python -c 'import __graft_entry__ as g; g.build()' or python -m timemachine_amd.csrc.build"
+        ) from e
 
 # custom_ops constructor argument order, by class (field names of the dataclass; "*" = the objects handed to impl())
 _CTOR_ARGS = {

@@ -1,4 +1,5 @@
-"""``timemachine_amd.lib.custom_ops`` -- the reference's ``timemachine.lib.custom_ops`` surface for the force-evaluation +
+"""``timemachine_amd.lib.custom_ops_ctypes`` -- the ctypes twin of the compiled ``custom_ops`` module (selected with
+TM_AMD_BINDING=ctypes, or implied by TM_AMD_LIB): the reference's ``timemachine.lib.custom_ops`` surface for the force-evaluation +
 Langevin-step hot path, served by ``libtimemachine_amd.so`` (hand-written HIP for gfx950) through its C ABI
 (``include/timemachine_amd.h``).
 
@@ -26,6 +27,7 @@ if not os.path.exists(_LIB_PATH):
 _lib = ctypes.CDLL(_LIB_PATH)
 
 FIXED_EXPONENT = 0x1000000000  # wrap_kernels.cpp:2144
+BINDING = "ctypes"
 
 TM_OK, TM_ERR_RUNTIME, TM_ERR_INVALID_HARDWARE = 0, 1, 2
 _F32, _F64 = 0, 1
@@ -70,10 +72,11 @@ def _as(a, dtype, what):
         probe = np.asarray(a)
         target = np.dtype(dtype)
         if probe.dtype.kind in "iub" and target.kind in "iu":
-            try:
-                return np.ascontiguousarray(np.array(a, dtype=target))
-            except OverflowError as e:
-                raise TypeError(f"{what}: value out of range for {target}") from e
+            # explicit range check: numpy 1.x wraps out-of-range Python ints silently ([-1] -> 4294967295 for uint32)
+            info = np.iinfo(target)
+            if probe.dtype == object or (probe.size and (int(probe.min()) < info.min or int(probe.max()) > info.max)):
+                raise TypeError(f"{what}: value out of range for {target}")
+            return np.ascontiguousarray(probe.astype(target))
         arr = probe
     else:
         arr = a
@@ -478,6 +481,14 @@ def _all_pairs_get_tile_count(self):
     return n.value
 
 
+def _all_pairs_debug_timing(self, max_waves=8192):
+    """per-wave cycle counters of the last tile launch (-DTM_TIMING builds): (int64[max_waves, 8], waves)"""
+    buf = np.zeros((max_waves, 8), dtype=np.int64)
+    cnt = _c_int(0)
+    _check(_lib.tm_nonbonded_all_pairs_debug_timing(self._h, _ptr(buf), _c_int(buf.size), ctypes.byref(cnt)))
+    return buf, cnt.value
+
+
 def _all_pairs_get_build_count(self):
     n = ctypes.c_uint(0)
     _check(_lib.tm_nonbonded_all_pairs_get_build_count(self._h, ctypes.byref(n)))
@@ -486,6 +497,7 @@ def _all_pairs_get_build_count(self):
 
 for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
     _k.get_build_count = _all_pairs_get_build_count  # diagnostic (not in the reference surface)
+    _k.debug_timing = _all_pairs_debug_timing
     _k.set_atom_idxs = _all_pairs_set_atom_idxs
     _k.get_atom_idxs = _all_pairs_get_atom_idxs
     _k.get_num_atom_idxs = _all_pairs_get_num_atom_idxs
@@ -1011,6 +1023,17 @@ def debug_float_to_fixed_energy(values, precision):
 def debug_set_box_scaling_reuse(enabled):
     """A/B aid: 0 = every box change rebuilds the neighbor lists (as the reference does); results are bit-identical."""
     _check(_lib.tm_debug_set_box_scaling_reuse(_c_int(1 if enabled else 0)))
+
+
+def debug_check_guards():
+    """-DTM_GUARD builds: violated guard zones so far; -1 in product builds"""
+    n = _c_int(0)
+    _check(_lib.tm_debug_check_guards(ctypes.byref(n)))
+    return n.value
+
+
+def version():
+    return _lib.tm_version().decode()
 
 
 def profile_set_enabled(enabled):
