@@ -5,8 +5,11 @@
 
 Protocol = the reference's own (tests/test_benchmark.py:243-282): build the system, equilibrate untimed, then time
 ctxt.multiple_steps(K) and report ns/day = K / t * 86400 * dt[ps] * 1e-3.  A "step" is one pass of the hot path: force
-evaluation (NonbondedAllPairs + NonbondedExclusions + HarmonicBond + HarmonicAngle) + the BAOAB Langevin update, all
-resident in HBM.
+evaluation (NonbondedAllPairs + NonbondedExclusions + HarmonicBond + HarmonicAngle + PeriodicTorsion) + the BAOAB Langevin update, all
+resident in HBM.  The default workload carries every term the north star names: 7 023 waters + a 2 490-atom solute with
+bonds, angles, proper + improper-form PeriodicTorsion terms and 1-4 exclusions at partial scales (DHFR's shape,
+testsystems/dhfr.py:9-23); `--workload water` is the pure-water box of rounds 1 and 2.  The record also carries the same box
+at the reference's own protocol (cutoff 1.0 nm, f32: `rc1.0_f32`; and `rc1.0_f64`).
 
 Timing.  The timed Context is settled with SETTLE_STEPS untimed steps (part of the equilibration: first list builds,
 allocator and clock ramp), then W warm-up steps, then EXACTLY K steps between barrier + device synchronisation on both
@@ -37,6 +40,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  configs 1 (500 BAOAB steps in each box) and 2 (u + du_dx + du_dp, 10 repetitions) the same way
 """
 import argparse
+import dataclasses
 import json
 import os
 import socket
@@ -53,6 +57,7 @@ DT = 2.5e-3  # ps
 TEMPERATURE = 300.0
 FRICTION = 1.0
 SETTLE_STEPS = 500  # untimed, on the timed Context, whatever --warmup says
+SECONDARY_STEPS = 500  # timed steps of the legs that are not `value` (other precision, cutoff 1.0, NPT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6  # = 1/2 of the 157.3 TFLOP/s FP32 vector peak (MI355X_MICROARCH.md chip table)
 FP32_VALU_PEAK_TFLOPS = 157.3
@@ -69,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["md", "hrex"], default="md")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cutoff", type=float, default=1.2)
+    ap.add_argument("--workload", choices=["dhfr", "water"], default="dhfr", help="dhfr: 7023 waters + a 2490-atom solute with every bonded term kind and "
+                    "scaled 1-4 exclusions (the shape of the reference's DHFR benchmark); water: 7853 waters only (rounds 1-2)")
+    ap.add_argument("--no-rc10", action="store_true", help="skip the cutoff-1.0 legs (the reference's own setup_dhfr protocol: rc 1.0, f32)")
     ap.add_argument("--padding", type=float, default=0.18, help="nblist_padding of the nonbonded potential: a speed knob of the potential's constructor, "
                     "results do not depend on it bit for bit (reference default 0.1; 0.18 measured fastest here, DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,6 +172,42 @@ def device_sync(co):
         pass
 
 
+WORKLOAD_TEXT = {
+    "dhfr": "DHFR-shaped: 7023 flexible TIP3P-like waters + a 2490-atom solute (30 C27H56 chains, amber99-like alkane parameters) = 23559 atoms; "
+            "{bonds} bonds, {angles} angles, {torsions} PeriodicTorsion terms (proper n=3/2/1 + improper-form), {exclusions} exclusions of which "
+            "{exclusions_14} are 1-4 pairs scaled by (1/1.2, 1/2)",
+    "water": "7853 flexible TIP3P-like waters = 23559 atoms; {bonds} bonds, {angles} angles, {torsions} torsions, {exclusions} full exclusions",
+}
+
+
+def term_counts(system):
+    partial = int(np.sum(np.any(system.scale_factors != 1.0, axis=1)))
+    return {"bonds": len(system.bond_idxs), "angles": len(system.angle_idxs), "torsions": len(system.torsion_idxs),
+            "exclusions": len(system.exclusion_idxs), "exclusions_14": partial}
+
+
+def pci_bus_id(local_rank, stub):
+    """PCI bus id of this rank's GPU (None without one): two ranks reporting the same id would share a device"""
+    if stub:
+        return None
+    try:
+        import torch
+
+        props = torch.cuda.get_device_properties(local_rank)
+        return f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+    except Exception:  # pragma: no cover
+        return None
+
+
+def collective_ranks(backend):
+    """ranks of the process group the collectives ran in when it is an RCCL ("nccl") group, else None"""
+    if backend != "nccl":
+        return None
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_initialized() else None
+
+
 class StubContext:
     """Stand-in for custom_ops.Context (--stub): sleeps 20 us per step.  Exercises everything around the hot path."""
 
@@ -257,9 +301,11 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(system, x, cutoff, reps=3, rows_per_rep=1024):
-    """config 3: du/dx of NonbondedAllPairs on `reps` disjoint row slabs of the i<j pair matrix (row-blocked dense
-    evaluation == the reference's JAX formulation), each scaled to the full matrix by its pair count."""
+def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
+    """config 3: du/dx of NonbondedAllPairs on `reps` samples of the i<j pair matrix (row-blocked dense evaluation == the
+    reference's JAX formulation).  A sample is `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see
+    ~N columns, rows near N almost none: one slab says little about the whole, eight evenly spaced ones see its average),
+    scaled to the full matrix by pair count; successive samples are shifted by a fraction of the slab spacing."""
     import torch
 
     from oracle import ref_potentials as rp
@@ -269,25 +315,28 @@ def cpu_baseline(system, x, cutoff, reps=3, rows_per_rep=1024):
     pt = torch.tensor(system.nb_params)
     bt = torch.tensor(system.box)
     pairs_full = N * (N - 1) // 2
+    spacing = (N - 1) // slabs_per_rep
     estimates, seconds, slabs = [], [], []
-    for rep in range(reps):
-        start = (rep * (N // max(reps, 1))) // 512 * 512
-        rows = range(start, min(start + rows_per_rep, N - 1))
+    for rep in range(-1, reps):  # rep -1: one untimed slab (thread pool start-up, allocator)
         xt = torch.tensor(x, requires_grad=True)
-        t0 = time.time()
-        for r0 in range(rows.start, rows.stop, 512):
-            r1 = min(r0 + 512, rows.stop)
+        starts = [k * spacing + (rep * spacing) // (reps + 1) for k in range(slabs_per_rep)] if rep >= 0 else [N // 2]
+        el, pairs_sample = 0.0, 0
+        for start in starts:
+            r0, r1 = start, min(start + rows_per_slab, N - 1)
+            t0 = time.time()
             d3 = rp.delta_r(xt[r0:r1][:, None, :], xt[r0:][None, :, :], torch.diagonal(bt))
             d2 = (d3 * d3).sum(-1)
             upper = torch.arange(r0, r1)[:, None] < torch.arange(r0, N)[None, :]
             d2 = torch.where(upper, d2, torch.full_like(d2, 1e6))
             lj, es = rp._pair_energies(torch.sqrt(d2), pt[r0:r1, 0][:, None] * pt[None, r0:, 0], pt[r0:r1, 1][:, None] + pt[None, r0:, 1], pt[r0:r1, 2][:, None] * pt[None, r0:, 2], system.beta, cutoff)
             (lj.sum() + es.sum()).backward()
-        el = time.time() - t0
-        pairs_sample = sum(N - 1 - i for i in rows)
+            el += time.time() - t0
+            pairs_sample += sum(N - 1 - i for i in range(r0, r1))
+        if rep < 0:
+            continue
         estimates.append(el * pairs_full / pairs_sample)
         seconds.append(el)
-        slabs.append(f"{rows.start}..{rows.stop - 1}")
+        slabs.append("+".join(str(st) for st in starts))
     t_step = float(np.mean(estimates))
     return {
         "value": 86400.0 * DT * 1e-3 / t_step,
@@ -295,8 +344,9 @@ def cpu_baseline(system, x, cutoff, reps=3, rows_per_rep=1024):
         "cores": cores,
         "cpu": _cpu_model(),
         "kind": "port",
-        "sample": f"config 3: du/dx of NonbondedAllPairs on {reps} row slabs of the i<j pair matrix (rows {', '.join(slabs)}; {sum(seconds):.1f} s of CPU work), "
-        f"each scaled to the full matrix by pair count; torch f64 on {cores} threads; oracle restatement of the reference's dense JAX path, not JAX itself",
+        "sample": f"config 3: du/dx of NonbondedAllPairs on {reps} samples of the i<j pair matrix, each {slabs_per_rep} slabs of {rows_per_slab} rows spread evenly "
+        f"over the triangle (first rows {'; '.join(slabs)}; {sum(seconds):.1f} s of CPU work), scaled to the full matrix by pair count; torch f64 on {cores} "
+        "threads; oracle restatement of the reference's dense JAX path, not JAX itself",
         "seconds_per_force_eval_extrapolated": t_step,
         "repetitions": reps,
         "spread_rel": float((max(estimates) - min(estimates)) / t_step),
@@ -416,13 +466,15 @@ def run_md(args, rank, local_rank, world, backend):
             raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
         co.set_device(local_rank)
         precision = np.float64 if args.precision == "f64" else np.float32
-        system = ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=args.cutoff)
+        build = ts.dhfr_shaped_box if args.workload == "dhfr" else ts.dhfr_sized_water_box
+        system = build(seed=2025, hmr=True, cutoff=args.cutoff)
         N = system.num_atoms
 
-        def make_bps(prec):
+        def make_bps(prec, cutoff=None):
             # one SummedPotential for the whole state -- how the reference packs a state
             # (fe/free_energy.py:614-657: make_summed_potential(...).to_gpu(np.float32) -> one BoundPotential)
-            bps = ts.bound_potentials(system, prec, nblist_padding=args.padding)
+            sys_c = system if cutoff is None else dataclasses.replace(system, cutoff=cutoff)
+            bps = ts.bound_potentials(sys_c, prec, nblist_padding=args.padding)
             summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps])
             return [summed.bind_params_list([bp.params for bp in bps]).to_gpu(prec).bound_impl]
 
@@ -431,18 +483,19 @@ def run_md(args, rank, local_rank, world, backend):
     else:
         N, system = 23559, None
 
-    def run(prec, steps, warmup, profile_steps, barostat_interval=0):
+    rank_ms_per_step = []  # one entry per run() call; [0] is the headline run
+
+    def run(prec, steps, warmup, profile_steps, barostat_interval=0, cutoff=None):
         if args.stub:
             bps, ctxt = None, StubContext(N)
         else:
-            bps = make_bps(prec)
+            bps = make_bps(prec, cutoff)
             movers = []
             if barostat_interval > 0:
                 # the reference's second DHFR line: "dhfr-apo-barostat-interval-25" (tests/test_benchmark.py:517-518, 222-232)
                 from timemachine_amd.lib import MonteCarloBarostat
 
-                groups = [list(range(3 * i, 3 * i + 3)) for i in range(N // 3)]
-                movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, groups, barostat_interval, seed).impl(bps)]
+                movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, ts.molecule_groups(system), barostat_interval, seed).impl(bps)]
             ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps, movers=movers)
         device_sync(co)  # the first call initialises torch's HIP context (seconds): do it here, not in front of the clock
         ctxt.multiple_steps(SETTLE_STEPS, 0)  # untimed, whatever --warmup says (see the module docstring)
@@ -456,6 +509,7 @@ def run_md(args, rank, local_rank, world, backend):
         device_sync(co)
         parallel.barrier()
         host_s = time.perf_counter() - t0
+        rank_ms_per_step.append(1e3 * dev_s / steps)  # this rank's own clock, before the max over ranks
         dev_s, host_s = parallel.max_over_ranks(dev_s), parallel.max_over_ranks(host_s)
         xf = ctxt.get_x_t()
         assert np.all(np.isfinite(xf)), "trajectory diverged"
@@ -498,6 +552,11 @@ def run_md(args, rank, local_rank, world, backend):
     u_kl = parallel.gather_rows(my_windows, u_row, world, row_length=n_windows)
     gather_ms = 1e3 * parallel.max_over_ranks(time.perf_counter() - t0)
     gather_ok = bool(np.all(np.isfinite(u_kl))) and u_kl.shape == (world, n_windows)
+    # who ran what, so that an N > 1 record explains itself: every rank's own ms per step, device and bus id
+    per_rank = parallel.gather_objects({
+        "rank": rank, "local_rank": local_rank, "ms_per_step": rank_ms_per_step[0], "windows": my_windows,
+        "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
+    })
 
     if rank != 0:
         return
@@ -516,11 +575,14 @@ def run_md(args, rank, local_rank, world, backend):
         "dtype": args.precision,
         "data": "synthetic",
         "config": {
-            "workload": "configs[2] (zero-based; BASELINE's third): DHFR-sized explicit-water box, 7853 flexible TIP3P-like waters = 23559 atoms, box 6.223 nm, "
-            f"direct-space erfc*switch electrostatics + LJ, cutoff {args.cutoff} nm, beta 2.0, HMR, dt 2.5 fs, Langevin 300 K friction 1/ps; "
+            "workload": "configs[2] (zero-based; BASELINE's third): DHFR-sized explicit-solvent box, "
+            + (WORKLOAD_TEXT[args.workload] if args.stub else WORKLOAD_TEXT[args.workload].format(**term_counts(system))) +
+            f", box 6.223 nm, direct-space erfc*switch electrostatics + LJ, cutoff {args.cutoff} nm, beta 2.0, HMR, dt 2.5 fs, Langevin 300 K friction 1/ps; "
             "one independent replica per GPU",
             "atoms": N,
-            "potentials": f"HarmonicBond/HarmonicAngle/Nonbonded(AllPairs+Exclusions) *_{args.precision}, LangevinIntegrator<float>",
+            "terms": None if args.stub else term_counts(system),
+            "potentials": ("HarmonicBond/HarmonicAngle/" + ("PeriodicTorsion/" if args.stub or len(system.torsion_idxs) else "")
+                           + f"Nonbonded(AllPairs+Exclusions) *_{args.precision} packed into one SummedPotential, LangevinIntegrator<float>"),
             "replicas": world,
             "nblist_padding": args.padding,
         },
@@ -529,6 +591,11 @@ def run_md(args, rank, local_rank, world, backend):
         "host_ns_day": args.steps / host_s * 86400.0 * DT * 1e-3 * world,
         "world_size": world,
         "backend": backend,
+        # `value` is the AGGREGATE over the n_gpus replicas (the contract's whole-job throughput); the metric's "per GPU" figure:
+        "value_per_gpu": ns_day / world,
+        "rccl_ranks": collective_ranks(backend),
+        "per_rank": per_rank,
+        "binding": "stub" if args.stub else co.BINDING,
         "device": "stub" if args.stub else co.device_name(),
         "mbar_gather_ok": gather_ok,
         "mbar_gather_ms": gather_ms,
@@ -580,18 +647,35 @@ def run_md(args, rank, local_rank, world, backend):
 
     if world == 1 and not args.stub:
         # the other precision, for the record (the reference ships f32 kernels; BASELINE asks for f64 forces)
+        # (secondary legs are not `value`: they run SECONDARY_STEPS timed steps each -- 20 steps hold 1 to 3 list rebuilds)
         other = np.float32 if precision == np.float64 else np.float64
+        n_sec = max(args.steps, SECONDARY_STEPS)
+        w_sec = max(args.warmup, 50)
+        tag = {np.float32: "f32", np.float64: "f64"}
         try:
-            d2, _, _, _, _ = run(other, max(args.steps // 2, 1), max(args.warmup // 2, 1), 0)
-            out["ns_day_" + ("f32" if other == np.float32 else "f64")] = (max(args.steps // 2, 1) / d2) * 86400.0 * DT * 1e-3
+            d2, _, _, _, _ = run(other, n_sec, w_sec, 0)
+            out["ns_day_" + tag[other]] = n_sec / d2 * 86400.0 * DT * 1e-3
         except Exception as exc:  # pragma: no cover
             out["other_precision_error"] = str(exc)
+        # the reference's own protocol line: setup_dhfr uses cutoff 1.0 nm (testsystems/dhfr.py:21) and its benchmark f32
+        # potentials (tests/test_benchmark.py:219,504-518); same coordinates, same padding, both precisions
+        if not args.no_rc10 and args.cutoff != 1.0:
+            try:
+                rc10 = {}
+                for prec in (np.float32, np.float64):
+                    d4, _, _, _, _ = run(prec, n_sec, w_sec, 0, cutoff=1.0)
+                    rc10[tag[prec]] = n_sec / d4 * 86400.0 * DT * 1e-3
+                out["rc1.0_f32"], out["rc1.0_f64"] = rc10["f32"], rc10["f64"]
+                out["rc1.0_note"] = (f"ns/day of the same box at cutoff 1.0 nm, {n_sec} timed steps each; rc1.0_f32 is the configuration the reference's "
+                                     "dhfr-apo benchmark runs (testsystems/dhfr.py:21, tests/test_benchmark.py:219)")
+            except Exception as exc:  # pragma: no cover
+                out["rc10_error"] = str(exc)
         # NPT: the same box with the Monte Carlo barostat every 25 steps (the reference benchmarks both ensembles)
         try:
             if args.no_npt:
                 raise KeyboardInterrupt
-            n_npt = max(args.steps // 2, 25)
-            d3, _, _, _, _ = run(precision, n_npt, max(args.warmup // 2, 25), 0, barostat_interval=25)
+            n_npt = n_sec
+            d3, _, _, _, _ = run(precision, n_npt, w_sec, 0, barostat_interval=25)
             out["npt"] = {"barostat_interval": 25, "pressure_bar": 1.0, "ns_day": n_npt / d3 * 86400.0 * DT * 1e-3,
                           "ms_per_step": 1e3 * d3 / n_npt, "dtype": args.precision,
                           "note": "reference: tests/test_benchmark.py:517-518 (dhfr-apo-barostat-interval-25); two energy-only evaluations per attempt"}

@@ -59,6 +59,12 @@ def gather_rows(local_windows: Sequence[int], local_rows: np.ndarray, n_windows:
     world = dist.get_world_size()
     dev = _device(dist)
     cap = -(-n_windows // world)
+    # row_length must be passed on EVERY rank or on none (the two branches issue different collectives: a mix hangs the job),
+    # and with it the placement must fit the round-robin capacity
+    if row_length is not None and len(local_windows) > cap:
+        raise ValueError(
+            f"gather_rows(row_length=...): this rank holds {len(local_windows)} windows but the single-collective path assumes at most "
+            f"ceil({n_windows} / {world}) = {cap} per rank (windows_for_rank placement); omit row_length for other placements")
     if row_length is None:
         # agree on L and on the per-rank capacity (a rank without rows does not know L; placement may not be round-robin)
         meta = torch.tensor([L, len(local_windows)], dtype=torch.int64, device=dev)
@@ -77,6 +83,16 @@ def gather_rows(local_windows: Sequence[int], local_rows: np.ndarray, n_windows:
     filled = np.isfinite(everyone[:, 0])
     out = np.full((n_windows, L), np.nan)
     out[everyone[filled, 0].astype(np.int64)] = everyone[filled, 1:]
+    return out
+
+
+def gather_objects(obj) -> list:
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable records: who ran what); [obj] without a job"""
+    dist = _dist()
+    if dist is None:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
     return out
 
 

@@ -38,6 +38,7 @@ class System:
     beta: float = 2.0
     cutoff: float = 1.2
     num_water_atoms: int = 0
+    group_idxs: Optional[list] = None  # molecules (barostat groups); None: see molecule_groups()
 
     @property
     def num_atoms(self):
@@ -185,6 +186,183 @@ def add_chain_ligand(sys: System, n_atoms: int = 20, lamb: float = 0.0, seed: in
 def dhfr_sized_water_box(seed: int = 2025, hmr: bool = True, cutoff: float = 1.2) -> System:
     """Config 3: 7 853 waters = 23 559 atoms in the 6.223 nm DHFR box (testsystems/data/5dfr_solv_equil.pdb:2)."""
     return build_water_box(7853, 6.223, seed=seed, hmr=hmr, cutoff=cutoff)
+
+
+# ---- a DHFR-shaped solute: a paraffin bundle with protein-like term counts --------------------------------------------
+# amber99-like alkane parameters in the deserializer's conventions (HarmonicBond u = k/2 (r - r0)^2, so k = 2 K_amber)
+R_CC, R_CH = 0.1526, 0.109
+K_CC, K_CH = 259408.0, 284512.0  # 310 / 340 kcal/mol/A^2
+THETA_TET = 1.9106332362490186  # acos(-1/3): every angle of the ideal geometry below
+K_CCC, K_HCH, K_HCC = 334.72, 292.88, 418.4  # 40 / 35 / 50 kcal/mol/rad^2
+SIG_CT, EPS_CT, SIG_HC, EPS_HC = 0.339967, 0.45773, 0.264953, 0.065689
+K_TORSION_X = 0.650844  # X-CT-CT-X: 1.4 / 9 kcal/mol, n = 3, phase 0
+SCALE_14 = (1.0 - 1.0 / 1.2, 0.5)  # fraction REMOVED of a 1-4 pair: charges scaled by 1/1.2, LJ by 1/2 (amber)
+
+
+def _dihedral(p0, p1, p2, p3):
+    """signed dihedral i-j-k-l with PeriodicTorsion's sign convention (timemachine/potentials/bonded.py:141-175): the two
+    plane normals are (r_j - r_i) x (r_j - r_k) and (r_j - r_k) x (r_l - r_k), the sign is taken along r_j - r_k"""
+    rij, rkj, rkl = p1 - p0, p1 - p2, p3 - p2
+    n1, n2 = np.cross(rij, rkj), np.cross(rkj, rkl)
+    return np.arctan2(np.dot(np.cross(n1, n2), rkj) / np.linalg.norm(rkj), np.dot(n1, n2))
+
+
+def paraffin_chain(n_carbons: int):
+    """One all-trans C_n H_(2n+2) chain along x at its force-field minimum (every angle acos(-1/3)): coordinates,
+    carbon / hydrogen index lists and the bonded topology.  Atom order: C0, its H's, C1, its H's, ..."""
+    half = THETA_TET / 2
+    step, rise = R_CC * np.sin(half), R_CC * np.cos(half)
+    coords, carbons, h_of = [], [], []
+    for k in range(n_carbons):
+        s = 1.0 if k % 2 == 0 else -1.0
+        c = np.array([k * step, 0.5 * s * rise, 0.0])
+        carbons.append(len(coords))
+        coords.append(c)
+        hs = []
+        for sign in (1.0, -1.0):  # the two H's every carbon has: away from the chain axis, above and below the zigzag plane
+            hs.append(len(coords))
+            coords.append(c + R_CH * np.array([0.0, s * np.cos(half), sign * np.sin(half)]))
+        if k == 0 or k == n_carbons - 1:  # methyl ends: the third H sits where the next carbon would be
+            hs.append(len(coords))
+            coords.append(c + R_CH * np.array([(-1.0 if k == 0 else 1.0) * np.sin(half), -s * np.cos(half), 0.0]))
+        h_of.append(hs)
+    coords = np.array(coords)
+    n = len(coords)
+    nbrs = [[] for _ in range(n)]
+    bonds = []
+    for k in range(n_carbons):
+        for h in h_of[k]:
+            bonds.append((carbons[k], h))
+        if k + 1 < n_carbons:
+            bonds.append((carbons[k], carbons[k + 1]))
+    for i, j in bonds:
+        nbrs[i].append(j)
+        nbrs[j].append(i)
+    angles = [(a, c, b) for c in range(n) for ia, a in enumerate(nbrs[c]) for b in nbrs[c][ia + 1 :]]
+    torsions = [(a, i, j, b) for (i, j) in bonds if len(nbrs[i]) > 1 and len(nbrs[j]) > 1 for a in nbrs[i] if a != j for b in nbrs[j] if b != i]
+    return coords, carbons, h_of, bonds, angles, torsions
+
+
+def dhfr_shaped_box(seed: int = 2025, hmr: bool = True, cutoff: float = 1.2, beta: float = 2.0) -> System:
+    """Config 3 with DHFR's SHAPE (testsystems/dhfr.py:9-23: 2 489 protein atoms + 21 069 water atoms in a 6.223 nm box, every
+    bonded term kind, 1-4 exclusions with partial scales): 7 023 flexible TIP3P-like waters + a 2 490-atom solute = 23 559
+    atoms.  The solute is a bundle of 30 all-trans C27H56 chains (a paraffin crystallite, 6 x 5 chains) with amber99-like
+    alkane parameters: 2 460 bonds, 4 860 angles, 8 610 PeriodicTorsion terms (7 020 X-C-C-X n=3 terms, 1 440 C-C-C-C n=2 / n=1
+    terms, 150 improper-form terms around carbons), 2 460 + 4 860 fully excluded 1-2 / 1-3 pairs and 7 020 1-4 pairs scaled
+    by (1/1.2, 1/2) -- DHFR itself has 2 523 / 4 547 / ~6 700 + 418.  Waters first, solute last (num_water_atoms)."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(seed)
+    L = 6.223
+    n_waters, ny, nz, nc = 7023, 6, 5, 27
+    dy, dz = 0.48, 0.44
+    c_xyz, carbons, h_of, bonds, angles, torsions = paraffin_chain(nc)
+    per_chain = len(c_xyz)
+    assert ny * nz * per_chain == 2490
+    length = c_xyz[:, 0].max() - c_xyz[:, 0].min()
+    origin = np.array([0.5 * (L - length), 0.5 * (L - (ny - 1) * dy), 0.5 * (L - (nz - 1) * dz)])
+    sol_xyz, sol_bonds, sol_angles, sol_tors, sol_tparams, sol_is_c, sol_q = [], [], [], [], [], [], []
+    c_set = set(carbons)
+    for iy in range(ny):
+        for iz in range(nz):
+            off = len(sol_xyz) * per_chain
+            shift = origin + np.array([0.0, iy * dy, iz * dz])
+            sol_xyz.append(c_xyz + shift)
+            sol_bonds += [(i + off, j + off) for i, j in bonds]
+            sol_angles += [(a + off, c + off, b + off) for a, c, b in angles]
+            for a, i, j, b in torsions:
+                sol_tors.append((a + off, i + off, j + off, b + off))
+                sol_tparams.append((K_TORSION_X, 0.0, 3.0))
+                if a in c_set and b in c_set:  # C-C-C-C: amber's extra n = 2 and n = 1 terms (0.25 / 0.2 kcal/mol, phase pi)
+                    sol_tors += [(a + off, i + off, j + off, b + off)] * 2
+                    sol_tparams += [(1.046, np.pi, 2.0), (0.8368, np.pi, 1.0)]
+            for k in range(5, nc - 1, 5):  # improper-form terms (central atom third), minimum at the built geometry
+                quad = (carbons[k - 1], carbons[k + 1], carbons[k], h_of[k][0])
+                phi0 = _dihedral(*[c_xyz[q] for q in quad])
+                sol_tors.append(tuple(q + off for q in quad))
+                sol_tparams.append((4.6024, 2.0 * phi0 - np.pi, 2.0))  # 1.1 kcal/mol, n = 2: k (1 + cos(2 phi - phase)) minimal at phi0
+            is_c = np.zeros(per_chain, dtype=bool)
+            is_c[carbons] = True
+            q = np.where(is_c, -0.12, 0.06)
+            q[[carbons[0], carbons[-1]]] = -0.18  # methyl carbons: neutral CH3 / CH2 groups (OPLS-like)
+            sol_is_c.append(is_c)
+            sol_q.append(q)
+    sol_xyz = np.concatenate(sol_xyz)
+    sol_is_c, sol_q = np.concatenate(sol_is_c), np.concatenate(sol_q)
+    n_sol = len(sol_xyz)
+
+    # water: a jittered 21^3 lattice, sites closer than 0.30 nm to any solute atom dropped, 7 023 of the rest kept
+    m = 21
+    spacing = L / m
+    grid = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    centers = (grid + 0.5) * spacing
+    free = np.array([len(hit) == 0 for hit in cKDTree(sol_xyz).query_ball_point(centers, 0.30)])
+    centers = centers[free]
+    assert len(centers) >= n_waters, (len(centers), n_waters)
+    centers = centers[rng.permutation(len(centers))[:n_waters]] + rng.uniform(-0.02, 0.02, (n_waters, 3))
+    rots = _random_rotations(rng, n_waters)
+    wat_xyz = (centers[:, None, :] + np.einsum("nij,aj->nai", rots, water_geometry())).reshape(-1, 3)
+    Nw = 3 * n_waters
+    o = np.arange(n_waters) * 3
+    nb_w = np.zeros((Nw, 4))
+    nb_w[o, 0], nb_w[o + 1, 0], nb_w[o + 2, 0] = Q_O * np.sqrt(ONE_4PI_EPS0), Q_H * np.sqrt(ONE_4PI_EPS0), Q_H * np.sqrt(ONE_4PI_EPS0)
+    nb_w[o, 1], nb_w[o + 1, 1], nb_w[o + 2, 1] = SIG_O / 2, 0.05, 0.05
+    nb_w[o, 2] = np.sqrt(EPS_O)
+    excl_w = np.stack([np.stack([o, o + 1], 1), np.stack([o, o + 2], 1), np.stack([o + 1, o + 2], 1)], 1).reshape(-1, 2)
+    bonds_w = np.stack([np.stack([o, o + 1], 1), np.stack([o, o + 2], 1)], 1).reshape(-1, 2)
+    angles_w = np.stack([o + 1, o, o + 2], 1)
+
+    sol_bonds, sol_angles, sol_tors = np.array(sol_bonds) + Nw, np.array(sol_angles) + Nw, np.array(sol_tors) + Nw
+    sol_tparams = np.array(sol_tparams)
+    nb_s = np.stack([sol_q * np.sqrt(ONE_4PI_EPS0), np.where(sol_is_c, SIG_CT, SIG_HC) / 2, np.sqrt(np.where(sol_is_c, EPS_CT, EPS_HC)), np.zeros(n_sol)], 1)
+    cc = sol_is_c[sol_bonds[:, 0] - Nw] & sol_is_c[sol_bonds[:, 1] - Nw]
+    bond_p = np.stack([np.where(cc, K_CC, K_CH), np.where(cc, R_CC, R_CH)], 1)
+    n_c_ends = sol_is_c[sol_angles[:, 0] - Nw].astype(int) + sol_is_c[sol_angles[:, 2] - Nw].astype(int)
+    angle_p = np.stack([np.choose(n_c_ends, [K_HCH, K_HCC, K_CCC]), np.full(len(sol_angles), THETA_TET), np.zeros(len(sol_angles))], 1)
+    e13 = sol_angles[:, [0, 2]]
+    proper = sol_tparams[:, 2] == 3.0  # one 1-4 pair per X-C-C-X quadruple (the extra C-C-C-C and improper terms add none)
+    e14 = sol_tors[proper][:, [0, 3]]
+    excl_s = np.concatenate([sol_bonds, e13, e14])
+    scales_s = np.concatenate([np.ones((len(sol_bonds) + len(e13), 2)), np.tile(SCALE_14, (len(e14), 1))])
+    assert len(np.unique(np.sort(excl_s, axis=1), axis=0)) == len(excl_s)
+
+    m_w = [M_O - 2 * M_H, 2 * M_H, 2 * M_H] if hmr else [M_O, M_H, M_H]
+    masses_s = np.where(sol_is_c, 12.011, 1.008)
+    if hmr:  # every hydrogen twice as heavy, its carbon lighter by as much (as for the waters; tests/test_benchmark.py:207-214)
+        n_h = np.zeros(n_sol)
+        np.add.at(n_h, sol_bonds[~cc][:, 0] - Nw, 1.0)  # (C, H) bonds list the carbon first
+        masses_s = np.where(sol_is_c, 12.011 - 1.008 * n_h, 2 * 1.008)
+    return System(
+        coords=np.concatenate([wat_xyz, sol_xyz]),
+        box=np.eye(3) * L,
+        masses=np.concatenate([np.tile(m_w, n_waters), masses_s]).astype(np.float64),
+        nb_params=np.concatenate([nb_w, nb_s]),
+        exclusion_idxs=np.concatenate([excl_w, excl_s]).astype(np.int32),
+        scale_factors=np.concatenate([np.ones((len(excl_w), 2)), scales_s]),
+        bond_idxs=np.concatenate([bonds_w, sol_bonds]).astype(np.int32),
+        bond_params=np.concatenate([np.tile([K_OH, R_OH], (len(bonds_w), 1)), bond_p]),
+        angle_idxs=np.concatenate([angles_w, sol_angles]).astype(np.int32),
+        angle_params=np.concatenate([np.tile([K_HOH, THETA_HOH, 0.0], (len(angles_w), 1)), angle_p]),
+        torsion_idxs=sol_tors.astype(np.int32),
+        torsion_params=sol_tparams,
+        beta=beta,
+        cutoff=cutoff,
+        num_water_atoms=Nw,
+        group_idxs=[list(range(3 * i, 3 * i + 3)) for i in range(n_waters)]
+        + [list(range(Nw + c * per_chain, Nw + (c + 1) * per_chain)) for c in range(ny * nz)],
+    )
+
+
+def molecule_groups(sys: System):
+    """atom index lists of the molecules (what a MonteCarloBarostat rescales as rigid units): waters, then whatever the
+    builder recorded for the solute (one group for everything else otherwise)"""
+    if sys.group_idxs is not None:
+        return sys.group_idxs
+    nw = sys.num_water_atoms // 3
+    groups = [list(range(3 * i, 3 * i + 3)) for i in range(nw)]
+    if sys.num_atoms > sys.num_water_atoms:
+        groups.append(list(range(sys.num_water_atoms, sys.num_atoms)))
+    return groups
 
 
 def small_solvated_ligand(lamb: float = 0.0, seed: int = 2025) -> System:
