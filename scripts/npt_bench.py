@@ -14,7 +14,7 @@ interval = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 co.set_device(0)
 which = sys.argv[4] if len(sys.argv) > 4 else "dhfr"
-s = {"dhfr": lambda: ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=1.2), "config4": ts.config4_solvated_ligand, "config2": ts.small_solvated_ligand}[which]()
+s = {"dhfr": lambda: ts.dhfr_shaped_box(seed=2025, hmr=True, cutoff=1.2), "water": lambda: ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=1.2), "config4": ts.config4_solvated_ligand, "config2": ts.small_solvated_ligand}[which]()
 N = s.num_atoms
 DT = 2.5e-3
 
@@ -28,8 +28,7 @@ def make_bps(p):
 eq = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, s.masses, 1).impl(), make_bps(np.float32))
 eq.multiple_steps(3000, 0)
 x, v = eq.get_x_t(), eq.get_v_t()
-nw = s.num_water_atoms if s.num_water_atoms else N
-groups = [list(range(3 * i, 3 * i + 3)) for i in range(nw // 3)] + ([list(range(nw, N))] if nw < N else [])
+groups = ts.molecule_groups(s)
 for label, iv in (("nvt", 0), ("npt", interval)):
     bps = make_bps(prec)
     movers = [MonteCarloBarostat(N, 1.0, 300.0, groups, iv, 7).impl(bps)] if iv > 0 else []

@@ -19,7 +19,8 @@ What comes from where
                                  arithmetic of k_hilbert.cu restated in oracle/hilbert.py.
   * water.npy                  : a data file of the reference's own test-suite (tests/data/water.npy), copied verbatim.
 
-Only data (inputs + expected outputs) is written; no reference source text.
+Only data (inputs + expected outputs) is written; no reference source text.  TM_GOLDEN_OUT=<dir> writes there instead of
+next to this script (tests/test_golden_regeneration.py regenerates every fixture into a temp dir and compares).
 """
 import ctypes
 import os
@@ -164,14 +165,71 @@ def gen_bonded(rng, out):
         check_fd(key + " du_dp", lambda pp: float(ref_fn(x, pp, box, idx)), prm, gp, rng, h=1e-6, tol=5e-6)
         d.update({f"u_{key}": u_ref, f"du_dx_{key}": gx, f"du_dp_{key}": gp})
         print(f"  {key}: u={u_ref:.6f}")
+    # the same system 50 nm away from the origin (exact in f64: the coordinates are f32 values below 2).  Bonded terms only see
+    # differences, which the reference's kernels form in double before casting (k_harmonic_bond.cuh:27,
+    # k_harmonic_angle.cuh:44-45, k_periodic_torsion.cuh:49-51): an f32 kernel that subtracted AFTER casting would lose
+    # 4e-6 nm here.  Reference energies at the shifted coordinates; gradients are translation invariant.
+    x_far = x + 50.0
+    assert np.array_equal(x_far - 50.0, x)
+    d["x_far"] = x_far
+    for key, ref_fn, idx, prm in (
+        ("bond", ref_bonded.harmonic_bond, bonds, bp), ("angle", ref_bonded.harmonic_angle, angles, ap), ("torsion", ref_bonded.periodic_torsion, tors, tp),
+    ):
+        u_far = float(ref_fn(x_far, prm, box, idx))
+        assert rel(u_far, d[f"u_{key}"]) < 1e-12, (key, u_far, d[f"u_{key}"])
+        d[f"u_{key}_far"] = u_far
     np.savez_compressed(os.path.join(out, "bonded.npz"), **d)
+
+
+def strained(s, seed0, inflate=0.05, open_angles=0.05, sigma=0.0003, floor=100.0, angle_floor=0.01):
+    """The system's coordinates with (i) every molecule inflated by 5 % about its centroid (every bond stretched), (ii) every
+    angle opened by ~0.05 rad (the atoms moved along the sum of d(theta)/dx over the angle terms -- uniform inflation alone
+    leaves angles where they are), (iii) N(0, 0.0003 nm) per component, rounded to f32 values.  Own generators: the shared
+    stream is not touched.  Terms at their rest geometry carry forces ~ 0, against which a tolerance relative to the force norm
+    (floor 1) says nothing: an f32 kernel's bond force has an absolute error of k * eps_f32 * r ~ 4.6e5 * 6e-8 * 0.1 = 3e-3
+    kJ/mol/nm and its angle an error of ~4e-7 rad (3e-3 kJ/mol/nm as well for water) whatever the arithmetic.  The first seed
+    for which EVERY bonded atom feels a bond force above `floor` kJ/mol/nm and every angle is off its rest value by more than
+    `angle_floor` rad is taken, so 1e-4 of the norm (the f32 bar of the tests) lies above those errors everywhere."""
+    import torch
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    n = s.num_atoms
+    b = np.asarray(s.bond_idxs)
+    _, mol = connected_components(coo_matrix((np.ones(len(b)), (b[:, 0], b[:, 1])), shape=(n, n)), directed=False)
+    cen = np.zeros((mol.max() + 1, 3))
+    np.add.at(cen, mol, s.coords)
+    cen /= np.bincount(mol)[:, None]
+    base = cen[mol] + (1.0 + inflate) * (s.coords - cen[mol])
+    a = torch.as_tensor(np.asarray(s.angle_idxs, dtype=np.int64))
+
+    def angles(xt):
+        rji, rjk = xt[a[:, 0]] - xt[a[:, 1]], xt[a[:, 2]] - xt[a[:, 1]]
+        return torch.acos((rji * rjk).sum(-1) / rji.norm(dim=-1) / rjk.norm(dim=-1))
+
+    xt = torch.tensor(base, requires_grad=True)
+    (grad,) = torch.autograd.grad(angles(xt).sum(), xt)
+    grad = grad.numpy()
+    # step length: the largest angle change a unit step produces is ~ |grad|^2 summed over an angle's three atoms
+    per_angle = (grad[s.angle_idxs] ** 2).sum(axis=(1, 2))
+    base = base + open_angles / np.median(per_angle) * grad
+    theta0 = np.asarray(s.angle_params)[:, 1]
+    bonded = np.unique(b)
+    for seed in range(seed0, seed0 + 64):
+        x = (base + np.random.default_rng(seed).normal(0.0, sigma, base.shape)).astype(np.float32).astype(np.float64)
+        _, g, _ = rp.harmonic_bond(x, s.bond_params, s.box, s.bond_idxs)
+        off = np.abs(angles(torch.tensor(x)).numpy() - theta0)
+        worst = (np.linalg.norm(g[bonded], axis=1).min(), off.min())
+        if worst[0] >= floor and worst[1] >= angle_floor:
+            return x
+    raise RuntimeError(f"no seed strains every bond and angle enough (last: min bond force {worst[0]:.1f}, min angle offset {worst[1]:.4f})")
 
 
 def gen_config2(rng, out):
     """~2 300-atom solvated ligand (BASELINE config 2), three lambda values."""
     for lamb in (0.0, 0.3, 1.0):
         s = ts.small_solvated_ligand(lamb=lamb)
-        x = s.coords.astype(np.float32).astype(np.float64)
+        x = strained(s, 2202)
         p = s.nb_params.astype(np.float32).astype(np.float64)
         u_ref = float(ref_nonbonded.nonbonded(x, p, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, runtime_validate=False))
         u, gx, gp = rp.nonbonded(x, p, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff)
@@ -253,7 +311,7 @@ def gen_hilbert(rng, out):
 
 if __name__ == "__main__":
     rng = np.random.default_rng(20260927)
-    out = HERE
+    out = os.environ.get("TM_GOLDEN_OUT", HERE)
     print("nonbonded"); gen_nonbonded(rng, out)
     print("bonded"); gen_bonded(rng, out)
     print("config 2"); gen_config2(rng, out)

@@ -178,7 +178,7 @@ def main():
         print(f"  centroid restraint b0={b0}: u={u_ref:.6f}")
     d.update(cr_a=ga, cr_b=gb)
 
-    np.savez_compressed(os.path.join(HERE, "groups.npz"), **d)
+    np.savez_compressed(os.path.join(os.environ.get("TM_GOLDEN_OUT", HERE), "groups.npz"), **d)
     shutil.rmtree(_tmp, ignore_errors=True)
     print("done")
 

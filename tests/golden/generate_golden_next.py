@@ -59,7 +59,7 @@ from oracle.fixed_point import float_to_fixed  # noqa: E402
 from timemachine_amd import hrex as threx  # noqa: E402
 from timemachine_amd import testsystems as ts  # noqa: E402
 
-from generate_golden import check_fd, rel  # noqa: E402  (same protocol as the hot-path goldens)
+from generate_golden import check_fd, rel, strained  # noqa: E402  (same protocol as the hot-path goldens)
 
 np.seterr(all="ignore")
 
@@ -102,7 +102,7 @@ def gen_vv(rng, out):
     x_m, v_m = ointegrator.velocity_verlet_device_model(x0, v0, lambda x: float_to_fixed(grad(x)), cbs, dt, n_steps + 1)
     ex, ev = np.abs(x_m - ref_xs[-1]).max(), np.abs(v_m - ref_vs[-1]).max()
     print(f"  vv: oracle device model vs reference after {n_steps + 1} steps: |dx| {ex:.2e}  |dv| {ev:.2e}")
-    assert ex < 5e-10 and ev < 5e-8, (ex, ev)  # fixed-point state quantisation: 2^-36 per update
+    assert ex < 1e-9 and ev < 1e-7, (ex, ev)  # fixed-point state quantisation (2^-36 per update) through 11 steps of stiff O-H dynamics
     np.savez_compressed(
         os.path.join(out, "vv.npz"), x0=x0, v0=v0, box=box, masses=s.masses, dt=dt, n_steps=n_steps, bond_idxs=s.bond_idxs,
         bond_params=s.bond_params, angle_idxs=s.angle_idxs, angle_params=s.angle_params, ref_xs=ref_xs, ref_vs=ref_vs,
@@ -152,6 +152,10 @@ def gen_hrex(rng, out):
             far = np.abs(np.arange(n_states)[:, None] - np.arange(n_states)[None, :]) > 4
             log_q = np.where(far, -np.inf, log_q)
         perm0 = rng.permutation(n_states)
+        if hole:  # a state assignment the evaluated band can belong to: every replica within two states of its own index
+            perm0 = np.arange(n_states)
+            for k in rng.permutation(n_states - 1)[: n_states // 3]:
+                perm0[[k, k + 1]] = perm0[[k + 1, k]]
         pair_idxs = rng.integers(0, len(pairs), n_attempts)
         uniforms = rng.random(n_attempts)
         import jax.numpy as jnp
@@ -162,6 +166,7 @@ def gen_hrex(rng, out):
         assert np.array_equal(perm, p2) and np.array_equal(proposed, pr2) and np.array_equal(accepted, ac2)
         p3, pr3, ac3 = ohrex.run_moves(list(perm0), [tuple(p) for p in pairs], log_q, pair_idxs, uniforms)
         assert np.array_equal(perm, p3) and np.array_equal(proposed, pr3) and np.array_equal(accepted, ac3)
+        assert int(accepted.sum()) > 0 and int(accepted.sum()) < int(proposed.sum())  # a chain that both accepts and rejects
         print(f"  hrex {tag}: {n_states} states, {n_attempts} attempts, {int(accepted.sum())} accepted; product + oracle == reference")
         cases.update({f"{tag}_perm0": perm0, f"{tag}_pairs": pairs, f"{tag}_log_q": log_q, f"{tag}_pair_idxs": pair_idxs, f"{tag}_uniforms": uniforms,
                       f"{tag}_perm": perm, f"{tag}_proposed": proposed, f"{tag}_accepted": accepted})
@@ -198,7 +203,7 @@ def gen_edges(rng, out):
     # BASELINE config 1: 85 waters + 1 neutral LJ atom = 256 atoms, vacuum (100 nm) and periodic (3.0 nm) boxes
     for tag, L in (("vacuum", 100.0), ("pbc", 3.0)):
         s = ts.config1_water_cluster(L)
-        xs = s.coords.astype(np.float32).astype(np.float64)
+        xs = strained(s, 1101)  # every bond stretched, every bonded atom pulled (generate_golden.strained)
         ps = s.nb_params.astype(np.float32).astype(np.float64)
         d = _nb_case(f"config1_{tag}", xs, ps, s.box, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, rng)
         for key, ref_fn, ora_fn, idx, prm in (
@@ -274,13 +279,20 @@ def gen_config4(rng, out):
     )
 
 
+GENERATORS = {"vv": gen_vv, "barostat": gen_barostat, "hrex": gen_hrex, "edges": gen_edges, "box_resize": gen_box_resize, "filter": gen_filter,
+              "config4": gen_config4}
+
 if __name__ == "__main__":
-    rng = np.random.default_rng(20260928)
-    out = HERE
-    which = sys.argv[1:] or ["vv", "barostat", "hrex", "edges", "box_resize", "filter", "config4"]
+    import time
+    import zlib
+
+    out = os.environ.get("TM_GOLDEN_OUT", HERE)
+    which = sys.argv[1:] or list(GENERATORS)
     for name in which:
-        print(name)
-        {"vv": gen_vv, "barostat": gen_barostat, "hrex": gen_hrex, "edges": gen_edges, "box_resize": gen_box_resize, "filter": gen_filter,
-         "config4": gen_config4}[name](rng, out)
+        # every generator draws from its OWN stream: any subset, in any order, reproduces the committed files
+        rng = np.random.default_rng([20260928, zlib.crc32(name.encode())])
+        t0 = time.time()
+        GENERATORS[name](rng, out)
+        print(f"{name}: {time.time() - t0:.1f} s")
     shutil.rmtree(_tmp, ignore_errors=True)
     print("done")

@@ -344,8 +344,11 @@ def test_config1_both_boxes(co, P, tag, precision):
     assert x.shape == (256, 3)
     nb = P.Nonbonded(256, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(precision).unbound_impl
     compare_forces(nb, x, p, box, float(g["u"]), g["du_dx"], g["du_dp"], precision)
-    brt = 1e-7 if precision == np.float64 else 2e-2
+    # f32: 1e-4 of the force norm.  The fixture's coordinates are strained (tests/golden/generate_golden.py: strained), so the
+    # stiff O-H bonds pull with ~1e3 kJ/mol/nm and their absolute f32 error (k * eps_f32 * r ~ 3e-3 kJ/mol/nm) is 1e-6 of it
+    brt = 1e-7 if precision == np.float64 else 1e-4
     for pot, prm, key in ((P.HarmonicBond(s.bond_idxs), s.bond_params, "bond"), (P.HarmonicAngle(s.angle_idxs), s.angle_params, "angle")):
+        assert np.linalg.norm(g[f"du_dx_{key}"], axis=1).max() > 100.0  # strained: the terms pull
         du_dx, du_dp, u = pot.to_gpu(precision).unbound_impl.execute(x, prm, box)
         np.testing.assert_allclose(u, float(g[f"u_{key}"]), rtol=brt, atol=brt * 10)
         assert_equal_vectors(g[f"du_dx_{key}"], du_dx, brt)

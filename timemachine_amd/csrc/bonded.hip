@@ -290,6 +290,9 @@ void FlatBottomBond<Real, Log>::execute_device(
         HIP_CHECK(hipGetLastError());
         if (d_u)
             reduce_i128_device(d_u_partials_.data, blocks * 4, d_u, stream);
+    } else if (d_u) {
+        // no bonds (local MD starts both of its restraints that way): the contract is that d_u is OVERWRITTEN
+        HIP_CHECK(hipMemsetAsync(d_u, 0, sizeof(i128), stream));
     }
 }
 

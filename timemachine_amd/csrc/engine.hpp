@@ -36,6 +36,14 @@ enum FusedKind : int {
     FUSED_LOG_FLAT_BOTTOM_BOND = 9
 };
 static const int FUSED_MAX_SEGMENTS = 16;
+// Neighbor-list counters (one array of NB_NUM_COUNTERS u32 per list): [0..2] list totals, [3] builds since construction,
+// [NB_COUNTER_CLASS0 + shard * NB_CLASSES + class] work items per (shard, cost class) bucket.  Written by the list build
+// (kernels_nblist.hip.hpp), read by the tile kernel (kernels_nonbonded.hip.hpp), reset by whoever raises the rebuild flag
+// (the bounds kernel, or the integrator's update kernel on the sorted hand-over path).
+static const int NB_SHARDS = 4;         // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
+static const int NB_CLASSES = 16;       // work items are bucketed by cost (estimated interacting pairs), heaviest first
+static const int NB_COUNTER_CLASS0 = 4;
+static const int NB_NUM_COUNTERS = NB_COUNTER_CLASS0 + NB_SHARDS * NB_CLASSES;
 struct FusedSegment {
     int kind;
     int count;            // terms

@@ -13,7 +13,8 @@ template <typename Real>
 __global__ __launch_bounds__(256) void k_fused_forces(
     const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx,
     const ForceLayout fl) {
-    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl);
+    __shared__ u64 s_window[4][3 * FORCE_WINDOW]; // one accumulation window per wave (kernels_bonded.hip.hpp: ForceLayout::win)
+    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl, (lds_u64_ptr)(&s_window[threadIdx.x >> 6][0]));
 }
 
 // The energy-only twin of fused_dispatch: same table, same per-term device functions with no force outputs asked for;

@@ -78,14 +78,16 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
     const GReal dz = static_cast<GReal>(t.snap_x[atom * 3 + 2]) - gz;
     const GReal d2 = dx * dx + dy * dy + dz * dz;
     if (static_cast<double>(d2) > t.pad2_quarter) {
-        *t.flag_set = 1; // benign race: every writer stores the same value
-        if (t.nbl_counters != nullptr) {
-            // sorted hand-over: whoever raises the flag also resets the list counters the coming build accumulates into
-            // (what the producer's bounds kernel does on the other paths; kernels_nblist.hip.hpp).  Few atoms get here per step.
+        if (t.nbl_counters == nullptr) {
+            *t.flag_set = 1; // benign race: every writer stores the same value
+        } else if (atomicExch(t.flag_set, 1) == 0) {
+            // sorted hand-over: the FIRST atom to raise the flag also resets the list counters the coming build accumulates into
+            // (what the producer's bounds kernel does on the other paths; kernels_nblist.hip.hpp) -- counters[3], the build
+            // count, stays.  On a rebuild step hundreds of atoms get here; one of them writes.
             t.nbl_counters[0] = 0;
             t.nbl_counters[1] = 0;
             t.nbl_counters[2] = 0;
-            for (int k = 4; k < 4 + 64; k++) {
+            for (int k = NB_COUNTER_CLASS0; k < NB_NUM_COUNTERS; k++) {
                 t.nbl_counters[k] = 0;
             }
         }

@@ -136,11 +136,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 static const int NB_CHUNK = 64;        // columns per work item == wave width
-static const int NB_SHARDS = 4;        // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
-static const int NB_CLASSES = 16;      // work items are bucketed by cost (estimated interacting pairs), heaviest first
+// (NB_SHARDS, NB_CLASSES, NB_COUNTER_CLASS0, NB_NUM_COUNTERS -- the layout of the neighbor-list counters -- live in engine.hpp:
+// the integrator's update kernel resets them too)
 static const int NB_CLASS_PAIRS = 128; // bucket width; class NB_CLASSES-1 holds items with < 128 pairs
-static const int NB_COUNTER_CLASS0 = 4; // neighbor-list counters[4 + shard * NB_CLASSES + class]: items per bucket
-static const int NB_NUM_COUNTERS = NB_COUNTER_CLASS0 + NB_SHARDS * NB_CLASSES;
 static_assert(NB_SHARDS * NB_CLASSES == 64, "one bucket per lane of the tile kernel's prefix sum");
 
 
@@ -166,8 +164,21 @@ __device__ __forceinline__ double pair_d2(double dx, double dy, double dz, doubl
 __device__ __forceinline__ float pair_d2(float dx, float dy, float dz, float dw) {
     return __builtin_fmaf(dw, dw, __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
 }
-__device__ __forceinline__ void lds_add(u64 *p, u64 v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_sub(u64 *p, u64 v) { __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#if defined(TM_ABLATE) && TM_ABLATE == 6 // ablation (timing only): phase 2 computes every pair but issues no LDS atomic
+#define TM_LDS_ACC_GATE(v) if ((v) != 0x123456789abcull) return
+#elif defined(TM_ABLATE) && TM_ABLATE == 7 // ablation (timing only): plain LDS stores instead of atomics (wrong sums, same traffic shape)
+#define TM_LDS_ACC_GATE(v) do { *p = (v); return; } while (0)
+#else
+#define TM_LDS_ACC_GATE(v) do { } while (0)
+#endif
+__device__ __forceinline__ void lds_add(u64 *p, u64 v) {
+    TM_LDS_ACC_GATE(v);
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_sub(u64 *p, u64 v) {
+    TM_LDS_ACC_GATE(v);
+    __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // ---- K1: rebuild check + gather (+ zero the Hilbert-order accumulators) -------------------------------------
 // reference: k_check_rebuild_coords_and_box_gather + k_gather_coords_and_params (k_nonbonded.cuh:12-84)
@@ -369,10 +380,12 @@ __device__ __forceinline__ i128 nonbonded_pair_list_term(
 // this header; called by k_fused_forces and by the tail of the tile kernel.
 // (a real call, not inlined: inside the tile kernel its registers would be allocated together with the item loop's, and the
 // f64 kernels sit at their 168-VGPR limit -- with the bonded terms inlined, any change to them moved spills into that loop)
+// `window`: FORCE_WINDOW * 3 u64 of LDS private to the calling wave (ForceLayout::win), or nullptr.  All 64 lanes of the wave
+// must make the call (the window is zeroed, filled and flushed by the whole wave).
 template <typename Real>
 __device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl);
+    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window);
 
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
 // Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
@@ -610,7 +623,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             // costs nothing, the others 8-10 us per launch).
             // slice t goes to workgroup t % G, wave (t / G) % WAVES: every CU takes the same share
             for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
-                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride, out_remap});
+                // (window: this wave's s_fi + s_fj, contiguous and not in use before the first item is staged)
+                static_assert(sizeof(lds.fi) + sizeof(lds.fj) >= sizeof(u64) * 3 * FORCE_WINDOW && offsetof(WaveLds, fj) == offsetof(WaveLds, fi) + sizeof(lds.fi), "window");
+                fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride, out_remap},
+                                     (lds_u64_ptr)(&s_fi[0][0]));
             }
         }
     }
@@ -1063,21 +1079,28 @@ __device__ __forceinline__ i128 nonbonded_pair_list_term(
         } else {
             nb_pair<false>(charge_scale, lj_scale, qi, qj, sig_i, sig_j, eps_i, eps_j, d2, static_cast<Real>(beta_d), o, tab);
         }
+#if defined(TM_ABLATE) && TM_ABLATE == 5
+#define TM_ACC_GATE(v) ((v) == 0x123456789abcull) // ablation (timing only): terms computed, atomics not issued
+#else
+#define TM_ACC_GATE(v) true
+#endif
 #define TM_ACC(ptr, val)                                                                                               \
 do {                                                                                                               \
     const u64 v_ = (val);                                                                                          \
-    atomicAdd((ptr), NEGATED ? (0ull - v_) : v_);                                                                  \
+    if (TM_ACC_GATE(v_)) {                                                                                         \
+        atomicAdd((ptr), NEGATED ? (0ull - v_) : v_);                                                              \
+    }                                                                                                              \
 } while (0)
         if (du_dx) {
             u64 fx, fy, fz;
             pair_force_fixed(o.prefactor, dx, dy, dz, fx, fy, fz);
-            const size_t ri = fl.row(ia), rj = fl.row(ja);
-            TM_ACC(du_dx + ri + 0 * static_cast<size_t>(fl.comp), fx);
-            TM_ACC(du_dx + ri + 1 * static_cast<size_t>(fl.comp), fy);
-            TM_ACC(du_dx + ri + 2 * static_cast<size_t>(fl.comp), fz);
-            TM_ACC(du_dx + rj + 0 * static_cast<size_t>(fl.comp), 0ull - fx);
-            TM_ACC(du_dx + rj + 1 * static_cast<size_t>(fl.comp), 0ull - fy);
-            TM_ACC(du_dx + rj + 2 * static_cast<size_t>(fl.comp), 0ull - fz);
+            // (through force_add: inside a fused slice the pair's atoms usually sit in the wave's LDS window)
+            force_add(du_dx, fl, ia, 0, NEGATED ? 0ull - fx : fx);
+            force_add(du_dx, fl, ia, 1, NEGATED ? 0ull - fy : fy);
+            force_add(du_dx, fl, ia, 2, NEGATED ? 0ull - fz : fz);
+            force_add(du_dx, fl, ja, 0, NEGATED ? fx : 0ull - fx);
+            force_add(du_dx, fl, ja, 1, NEGATED ? fy : 0ull - fy);
+            force_add(du_dx, fl, ja, 2, NEGATED ? fz : 0ull - fz);
         }
         if (du_dp) {
             TM_ACC(du_dp + ia * 4 + 0, (float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(charge_scale * qj * o.inv_dij * o.ebd)));
@@ -1212,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_nonbonded_precomputed(
 template <typename Real>
 __device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx, const ForceLayout fl) {
+    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window) {
     const int n = table->n;
     int s = 0, first = 0;
     for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
@@ -1224,9 +1247,25 @@ __device__ __attribute__((noinline)) void fused_dispatch(
     }
     const FusedSegment seg = table->seg[s];
     const int idx = (block - first) * 256 + thread;
-    if (idx >= seg.count) {
-        return;
+    const int lane = thread & 63;
+    const int idx0 = idx - lane; // the slice's first term (wave-uniform)
+    if (idx0 >= seg.count) {
+        return; // the whole wave: nothing left of this segment
     }
+    // The slice's LDS window starts a few atoms below the first atom of its first term: term lists come in atom order
+    // (molecule by molecule), so the atoms of 64 consecutive terms nearly always fall inside; whatever does not takes the
+    // global atomic as before.
+    if (window != nullptr) {
+        const int width = seg.kind == FUSED_ANGLE ? 3 : ((seg.kind == FUSED_TORSION || seg.kind == FUSED_CHIRAL_ATOM || seg.kind == FUSED_CHIRAL_BOND) ? 4 : 2);
+        const int a0 = __builtin_amdgcn_readfirstlane(seg.idxs[static_cast<size_t>(idx0) * width]);
+        fl.win = window;
+        fl.win_base = a0 > 8 ? a0 - 8 : 0;
+        for (int t = lane; t < 3 * FORCE_WINDOW; t += 64) {
+            window[t] = 0;
+        }
+        wave_lds_sync();
+    }
+    if (idx < seg.count) {
     switch (seg.kind) {
     case FUSED_BOND: harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
     case FUSED_ANGLE: harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, du_dx, nullptr, false, fl); break;
@@ -1245,6 +1284,19 @@ __device__ __attribute__((noinline)) void fused_dispatch(
     case FUSED_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false, fl); break;
     case FUSED_LOG_FLAT_BOTTOM_BOND: flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, du_dx, nullptr, false, fl); break;
     default: break;
+    }
+    }
+    if (window != nullptr) {
+        // flush: one global atomic per touched (atom, component) of the slice
+        wave_lds_sync();
+        for (int t = lane; t < 3 * FORCE_WINDOW; t += 64) {
+            const u64 v = window[t];
+            if (v != 0) {
+                const int d = t / FORCE_WINDOW, a = fl.win_base + (t - d * FORCE_WINDOW);
+                atomicAdd(du_dx + fl.row(a) + static_cast<size_t>(d) * fl.comp, v);
+            }
+        }
+        wave_lds_sync();
     }
 }
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <set>
 
@@ -97,11 +98,19 @@ void es_force_table_host(const double beta, double *out) {
 }
 
 const double *es_force_table_device(const double beta) {
-    // one table per (device, beta), kept for the life of the process: potentials of one state share it
-    static std::map<std::pair<int, double>, double *> cache;
+    // one table per (device, beta), kept for the life of the process: potentials of one state share it.  Constructors may run
+    // on several host threads at once (the bindings release the GIL around calls): the cache is guarded.
+    static std::map<std::pair<int, unsigned long long>, double *> cache;
+    static std::mutex cache_mutex;
+    if (!(beta == beta)) {
+        throw std::runtime_error("beta must not be NaN");
+    }
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    const auto key = std::make_pair(dev, beta);
+    unsigned long long beta_bits = 0;
+    std::memcpy(&beta_bits, &beta, sizeof(beta_bits)); // keyed on the bit pattern: -0.0 / 0.0 and the like stay apart
+    const auto key = std::make_pair(dev, beta_bits);
+    std::lock_guard<std::mutex> lock(cache_mutex);
     auto it = cache.find(key);
     if (it != cache.end()) {
         return it->second;

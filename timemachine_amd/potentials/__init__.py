@@ -4,8 +4,6 @@ from .potential import (  # noqa: F401
     BoundPotential,
     GpuImplWrapper,
     Potential,
-    get_bound_potential_by_type,
-    get_potential_by_type,
 )
 from .potentials import (  # noqa: F401
     CentroidRestraint,

@@ -9,7 +9,7 @@ the energy with the f64 HIP kernels.
 """
 from abc import ABC
 from dataclasses import astuple, dataclass
-from typing import Any, Generic, Optional, Sequence, TypeVar
+from typing import Any, Generic, TypeVar
 
 import numpy as np
 from numpy.typing import NDArray
@@ -87,19 +87,3 @@ class BoundGpuImplWrapper:
     def __call__(self, conf: NDArray, box: NDArray) -> float:
         _, u = self.bound_impl.execute(conf, box, False, True)
         return u
-
-
-def get_bound_potential_by_type(bps: Sequence[BoundPotential], pot_type):
-    # reference: potential.py:83-98
-    for bp in bps:
-        if isinstance(bp.potential, pot_type):
-            return bp
-    raise ValueError(f"Unable to find potential of type: {pot_type}")
-
-
-def get_potential_by_type(pots: Sequence[Potential], pot_type):
-    # reference: potential.py:101-116
-    for pot in pots:
-        if isinstance(pot, pot_type):
-            return pot
-    raise ValueError(f"Unable to find potential of type: {pot_type}")

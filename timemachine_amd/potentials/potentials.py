@@ -58,19 +58,18 @@ class Nonbonded(Potential):
     disable_hilbert_sort: bool = False
     nblist_padding: float = 0.1
 
-    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
-        all_pairs = NonbondedAllPairs(
-            self.num_atoms,
-            self.beta,
-            self.cutoff,
-            atom_idxs=self.atom_idxs,
-            disable_hilbert_sort=self.disable_hilbert_sort,
-            nblist_padding=self.nblist_padding,
+    def _members(self):
+        """(NonbondedAllPairs over the chosen atoms, NonbondedExclusions restricted to pairs inside that set)"""
+        members_of = np.arange(self.num_atoms, dtype=np.int32) if self.atom_idxs is None else self.atom_idxs
+        kept_idxs, kept_scales = filter_exclusions(members_of, self.exclusion_idxs, self.scale_factors)
+        return (
+            NonbondedAllPairs(self.num_atoms, self.beta, self.cutoff, self.atom_idxs, self.disable_hilbert_sort, self.nblist_padding),
+            NonbondedExclusions(kept_idxs, kept_scales, self.beta, self.cutoff),
         )
-        atom_idxs = self.atom_idxs if self.atom_idxs is not None else np.arange(self.num_atoms, dtype=np.int32)
-        exclusion_idxs, scale_factors = filter_exclusions(atom_idxs, self.exclusion_idxs, self.scale_factors)
-        exclusions = NonbondedExclusions(exclusion_idxs, scale_factors, self.beta, self.cutoff)
-        return FanoutSummedPotential([all_pairs, exclusions]).to_gpu(precision)
+
+    def to_gpu(self, precision: Precision) -> GpuImplWrapper:
+        # both members take the SAME parameter array (fan-out); the second subtracts in fixed point what the first added
+        return FanoutSummedPotential(list(self._members())).to_gpu(precision)
 
 
 @dataclass
