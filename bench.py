@@ -63,6 +63,13 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # = 1/2 of the 157.3 TFLOP/s FP32 vector peak (MI3
 FP32_VALU_PEAK_TFLOPS = 157.3
 C_PAIR_FLOPS = 280.0  # per interacting pair (rsqrt, erfc, exp, sincos, LJ, fixed-point conversions)
 C_SLOT_FLOPS = 20.0  # per evaluated slot (min-image distance + cutoff test)
+# The same two figures counted on THIS kernel's ISA (f64 forces-only batch body / compact filter round, DESIGN.md section 4.2;
+# an FMA = 2): displacement 4, d^2 7, table index + degree-5 Horner 11, charges 2, LJ 20, prefactor 1, fixed-point products +
+# magic adds 6 = 51 per interacting pair; filter: 4 subtractions + mul + 3 FMA = 11 per evaluated slot.  The table-driven
+# kernel simply executes fewer flops than the reference formula SURVEY priced.
+OWN_PAIR_FLOPS = {"f64": 51.0, "f32": 78.0}  # f32: analytic erfc / exp / switch instead of the table (rsq, rcp, exp, sin, cos count 1)
+OWN_SLOT_FLOPS = 11.0
+CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; used only to turn a kernel time into cycles for valu_busy
 METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
 
@@ -643,7 +650,26 @@ def run_md(args, rank, local_rank, world, backend):
             "tiles_32x32": tiles,
             "tile_occupancy": p_int / (1024.0 * tiles) if tiles else None,
             "kernel_share_of_step": prof["kernel_ms"] / (1e3 * dev_s / args.steps),
+            "flop_constants": {"per_pair": C_PAIR_FLOPS, "per_slot": C_SLOT_FLOPS, "source": "SURVEY.md section 8(d): the reference formula's operation count"},
         }
+        # the honest instruction picture: this kernel's own flop count, and what the SQ counters of the committed PMC passes say
+        own = OWN_PAIR_FLOPS[args.precision] * p_int + OWN_SLOT_FLOPS * 1024 * tiles
+        rv = out["roofline_valu"]
+        rv["own_isa"] = {"flops_per_pair": OWN_PAIR_FLOPS[args.precision], "flops_per_slot": OWN_SLOT_FLOPS, "flops_per_launch": own,
+                         "achieved": own / t_s / 1e12, "frac": own / t_s / 1e12 / peak_fl,
+                         "note": "flops this kernel's ISA executes per pair / per filter slot (FMA = 2); the fraction of peak a flop count can reach is "
+                                 "bounded by the share of FMA among the issued instructions -- the kernel is VALU-ISSUE bound, see valu_busy"}
+        sq = pmc.get("sq") or {}
+        if sq.get("SQ_INSTS_VALU"):
+            kernel_cycles = t_s * CLOCK_GHZ * 1e9
+            rv["insts_valu_per_launch"] = sq["SQ_INSTS_VALU"]
+            rv["lane_ops_per_pair"] = sq["SQ_INSTS_VALU"] * 64.0 / p_int
+            # SQ_ACTIVE_INST_VALU counts quad-cycles the VALUs spend executing; 1024 SIMDs x kernel cycles are available
+            rv["valu_busy"] = sq.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * kernel_cycles)
+            rv["insts_salu_per_launch"] = sq.get("SQ_INSTS_SALU")
+            rv["insts_lds_per_launch"] = sq.get("SQ_INSTS_LDS")
+            rv["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT")
+            rv["counters_source"] = f"{pmc.get('source')} (separate rocprofv3 --pmc passes of this command; valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel_ms * {CLOCK_GHZ} GHz))"
 
     if world == 1 and not args.stub:
         # the other precision, for the record (the reference ships f32 kernels; BASELINE asks for f64 forces)
@@ -782,9 +808,15 @@ def run_hrex(args, rank, local_rank, world, backend):
     for c in ctxts:
         assert np.all(np.isfinite(c.get_x_t())), "trajectory diverged"
     t_max = {k: parallel.max_over_ranks(v) for k, v in timers.items()}
+    md_steps = n_frames * steps_per_frame
+    # who holds what: every rank's resident replicas (windows), its own MD time per frame, device and bus id
+    per_rank = parallel.gather_objects({
+        "rank": rank, "local_rank": local_rank, "resident_replicas": [int(r) for r in mine], "md_ms_per_frame": 1e3 * timers["md"] / n_frames,
+        "ms_per_step": 1e3 * timers["md"] / max(n_frames * steps_per_frame * max(len(mine), 1), 1),
+        "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
+    })
     if rank != 0:
         return
-    md_steps = n_frames * steps_per_frame
     accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
     proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
     emit_json({
@@ -812,6 +844,10 @@ def run_hrex(args, rank, local_rank, world, backend):
         "swap_acceptance": accepted / max(proposed, 1),
         "world_size": world,
         "backend": backend,
+        "value_per_gpu": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3 / world,
+        "rccl_ranks": collective_ranks(backend),
+        "per_rank": per_rank,
+        "binding": "stub" if args.stub else co.BINDING,
         "device": "stub" if args.stub else co.device_name(),
     })
 

@@ -42,14 +42,17 @@ for f in sorted(glob.glob(sys.argv[1]+'/*/*counter_collection.csv')):
             if 'tiles' in k or 'find_ixns' in k or 'baoab' in k: print(line)
             # the MD-step variant of the tile kernel: forces only (<Real, false, true, false>)
             if k.startswith('k_nonbonded_tiles<%s, false, true, false' % {'f64': 'double', 'f32': 'float'}[sys.argv[2]]) and disp[k] > 50:
-                for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+                for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT',
+                          'SQ_ACTIVE_INST_LDS', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'):
                     if c in agg[k]: traffic[c] = agg[k][c] / disp[k]
 if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
     # KB per dispatch; the guide's gfx950 correction: FETCH_SIZE tallies 128-B read requests at 64 B -> double it
     b = (2.0 * traffic['FETCH_SIZE'] + traffic['WRITE_SIZE']) * 1024
-    json.dump({sys.argv[2]: {"bytes": b, "fetch_kb_raw": traffic['FETCH_SIZE'], "write_kb_raw": traffic['WRITE_SIZE'],
-               "correction": "2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)", "source": "profiles/r02_pmc_md_%s.txt" % sys.argv[2]}},
-              open(sys.argv[1] + '/pmc_traffic.json', 'w'))
+    rec = {"bytes": b, "fetch_kb_raw": traffic['FETCH_SIZE'], "write_kb_raw": traffic['WRITE_SIZE'],
+           "correction": "2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)", "source": "profiles/pmc_md_%s.txt" % sys.argv[2],
+           # per-dispatch averages of the SQ passes of the same command (instruction counts; cycle counters in quad-cycles)
+           "sq": {k: v for k, v in traffic.items() if k.startswith('SQ_') or k.startswith('GRBM')}}
+    json.dump({sys.argv[2]: rec}, open(sys.argv[1] + '/pmc_traffic.json', 'w'))
     print('traffic bytes per launch', b)
 PY
 find $PMC -name "*counter_collection.csv" -delete; find $PMC -name "*.db" -delete; du -sh gpurun_out

@@ -46,6 +46,14 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert out["mbar_gather_ok"] is True and out["mbar_gather_ms"] > 0
     single = _line(_run("--steps", "40", "--warmup", "10"))
     assert out["value"] > 1.2 * single["value"]  # aggregate over both ranks, not per rank
+    # the N > 1 record explains itself: the per-GPU figure, who ran what, and (on an "nccl" group only) the RCCL rank count
+    assert out["value_per_gpu"] == pytest.approx(out["value"] / 2)
+    assert out["rccl_ranks"] is None  # gloo here; dist.get_world_size() of the nccl group on the GPU box
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and [r["windows"] for r in out["per_rank"]] == [[0], [1]]
+    for r in out["per_rank"]:
+        assert r["ms_per_step"] > 0 and r["device"] == "stub" and "pci_bus_id" in r and r["host"]
+    assert max(r["ms_per_step"] for r in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-6)  # value = max over ranks
+    assert single["value_per_gpu"] == pytest.approx(single["value"]) and len(single["per_rank"]) == 1
 
 
 def test_bench_refuses_a_mismatched_launcher():
@@ -59,3 +67,6 @@ def test_bench_hrex_mode_two_ranks():
     assert out["scaling"] == "strong" and out["frames_per_s"] > 0 and out["exchange_latency_ms"] > 0
     assert 0.0 < out["swap_acceptance"] <= 1.0
     assert set(out["per_frame_ms"]) == {"md", "matrix", "exchange", "rebind"}
+    # resident replicas per rank: round-robin placement (parallel.windows_for_rank), every window exactly once
+    assert [r["resident_replicas"] for r in out["per_rank"]] == [[0, 2, 4], [1, 3, 5]]
+    assert out["value_per_gpu"] == pytest.approx(out["value"] / 2) and out["rccl_ranks"] is None
