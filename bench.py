@@ -309,10 +309,10 @@ def _cpu_model():
 
 
 def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
-    """config 3: du/dx of NonbondedAllPairs on `reps` samples of the i<j pair matrix (row-blocked dense evaluation == the
-    reference's JAX formulation).  A sample is `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see
-    ~N columns, rows near N almost none: one slab says little about the whole, eight evenly spaced ones see its average),
-    scaled to the full matrix by pair count; successive samples are shifted by a fraction of the slab spacing."""
+    """config 3: du/dx of NonbondedAllPairs on a sample of the i<j pair matrix (row-blocked dense evaluation == the reference's
+    JAX formulation): `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see ~N columns, rows near N almost
+    none: one slab says little about the whole, eight evenly spaced ones see its average), scaled to the full matrix by pair
+    count.  The same sample is timed `reps` times (after an untimed slab); the median is reported, the spread is timing noise."""
     import torch
 
     from oracle import ref_potentials as rp
@@ -323,12 +323,12 @@ def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
     bt = torch.tensor(system.box)
     pairs_full = N * (N - 1) // 2
     spacing = (N - 1) // slabs_per_rep
-    estimates, seconds, slabs = [], [], []
+    starts = [k * spacing + spacing // 2 for k in range(slabs_per_rep)]  # the SAME slabs every repetition: the spread is timing noise only
+    estimates, seconds = [], []
     for rep in range(-1, reps):  # rep -1: one untimed slab (thread pool start-up, allocator)
         xt = torch.tensor(x, requires_grad=True)
-        starts = [k * spacing + (rep * spacing) // (reps + 1) for k in range(slabs_per_rep)] if rep >= 0 else [N // 2]
         el, pairs_sample = 0.0, 0
-        for start in starts:
+        for start in (starts if rep >= 0 else [N // 2]):
             r0, r1 = start, min(start + rows_per_slab, N - 1)
             t0 = time.time()
             d3 = rp.delta_r(xt[r0:r1][:, None, :], xt[r0:][None, :, :], torch.diagonal(bt))
@@ -343,17 +343,18 @@ def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
             continue
         estimates.append(el * pairs_full / pairs_sample)
         seconds.append(el)
-        slabs.append("+".join(str(st) for st in starts))
-    t_step = float(np.mean(estimates))
+    slabs = ["+".join(str(st) for st in starts)]
+    t_step = float(np.median(estimates))
     return {
         "value": 86400.0 * DT * 1e-3 / t_step,
         "unit": "ns/day",
         "cores": cores,
         "cpu": _cpu_model(),
         "kind": "port",
-        "sample": f"config 3: du/dx of NonbondedAllPairs on {reps} samples of the i<j pair matrix, each {slabs_per_rep} slabs of {rows_per_slab} rows spread evenly "
-        f"over the triangle (first rows {'; '.join(slabs)}; {sum(seconds):.1f} s of CPU work), scaled to the full matrix by pair count; torch f64 on {cores} "
-        "threads; oracle restatement of the reference's dense JAX path, not JAX itself",
+        "sample": f"config 3: du/dx of NonbondedAllPairs on {slabs_per_rep} slabs of {rows_per_slab} rows spread evenly over the i<j pair matrix (first rows "
+        f"{'; '.join(slabs)}), scaled to the full matrix by pair count, {reps} repetitions of the same sample ({sum(seconds):.1f} s of CPU work, median taken); "
+        f"torch f64 on {cores} threads; oracle restatement of the reference's dense JAX path, not JAX itself",
+        "estimates_s": [float(e) for e in estimates],
         "seconds_per_force_eval_extrapolated": t_step,
         "repetitions": reps,
         "spread_rel": float((max(estimates) - min(estimates)) / t_step),

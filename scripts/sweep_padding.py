@@ -34,7 +34,7 @@ def main():
 
     co.set_device(0)
     prec = np.float64 if args.precision == "f64" else np.float32
-    system = ts.dhfr_sized_water_box(seed=2025, hmr=True, cutoff=args.cutoff)
+    system = ts.dhfr_shaped_box(seed=2025, hmr=True, cutoff=args.cutoff)  # the bench workload
 
     def make_bps(p, padding=0.1):
         bps = ts.bound_potentials(system, p, nblist_padding=padding)

@@ -53,9 +53,15 @@ struct FusedSegment {
     double beta, cutoff;  // pair lists
     const int *aux;       // chiral bond restraints: signs [count]
     const double *es_table = nullptr; // pair lists, f64 kernels: the electrostatic force-factor table of `beta` (nb_es_table.hip.hpp)
+    int window = 1; // accumulate through the per-wave LDS window (set by ForcePlan::add_segment from the owner's max_atom_incidence)
+    int reserved_ = 0; // (no padding bytes: tables are compared with memcmp to decide on re-uploads)
 };
+static const int FUSED_WINDOW_MIN_INCIDENCE = 8;
 struct FusedTable {
     int n;
+    int window; // != 0: slices accumulate in the calling wave's LDS window before they touch the global accumulator (ForceLayout::win)
+    int num_atoms; // atoms of the system (bounds the window's row prefetch)
+    int reserved_ = 0; // (no padding bytes: tables are compared with memcmp)
     int block_end[FUSED_MAX_SEGMENTS]; // exclusive prefix sum of 256-thread blocks per segment
     FusedSegment seg[FUSED_MAX_SEGMENTS];
 };
@@ -140,6 +146,30 @@ private:
 class Potential {
 public:
     virtual ~Potential() {}
+    // How many terms of this potential's list the busiest atom takes part in (set by the constructors of the term-list
+    // potentials; "unknown" = very many).  A ForcePlan uses it to decide whether the potential's slices accumulate through the
+    // per-wave LDS window (ForceLayout::win): it pays where many terms meet on the same atoms -- a protein's angles, torsions and
+    // exclusions -- and costs a lone wave 1-2 us where they do not (water: 2 bonds, 1 angle, 2 exclusions per atom).
+    int max_atom_incidence() const { return max_atom_incidence_; }
+    void note_term_atoms(const std::vector<int> &idxs) {
+        int hi = -1;
+        for (const int a : idxs) {
+            hi = a > hi ? a : hi;
+        }
+        std::vector<int> count(static_cast<size_t>(hi + 1), 0);
+        int most = 0;
+        for (const int a : idxs) {
+            if (a >= 0) {
+                most = ++count[a] > most ? count[a] : most;
+            }
+        }
+        max_atom_incidence_ = most;
+    }
+
+protected:
+    int max_atom_incidence_ = 1 << 20;
+
+public:
     static const int D = 3;
 
     // Forces-only planning hook (see ForcePlan).  Default: not fusable, executed through execute_device.

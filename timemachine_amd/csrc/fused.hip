@@ -1,6 +1,7 @@
 // ForcePlan: all bonded terms and pair lists of a step in one kernel launch per precision (see engine.hpp).
 // The per-term device functions are the ones the stand-alone kernels call (kernels_bonded.hip.hpp, kernels_nonbonded.hip.hpp),
 // so a fused launch produces the same bits as separate launches.
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels_bonded.hip.hpp"
@@ -14,7 +15,9 @@ __global__ __launch_bounds__(256) void k_fused_forces(
     const FusedTable *__restrict__ table, const double *__restrict__ coords, const double *__restrict__ box, u64 *__restrict__ du_dx,
     const ForceLayout fl) {
     __shared__ u64 s_window[4][3 * FORCE_WINDOW]; // one accumulation window per wave (kernels_bonded.hip.hpp: ForceLayout::win)
-    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl, (lds_u64_ptr)(&s_window[threadIdx.x >> 6][0]));
+    __shared__ int s_window_rows[4][FORCE_WINDOW];
+    fused_dispatch<Real>(table, static_cast<int>(blockIdx.x), static_cast<int>(threadIdx.x), coords, box, du_dx, fl, (lds_u64_ptr)(&s_window[threadIdx.x >> 6][0]),
+                         (lds_int_ptr)(&s_window_rows[threadIdx.x >> 6][0]));
 }
 
 // The energy-only twin of fused_dispatch: same table, same per-term device functions with no force outputs asked for;
@@ -94,8 +97,13 @@ __global__ __launch_bounds__(256) void k_reduce_i128_sources(const EnergySources
 }
 
 void ForcePlan::clear() {
+    static const int window = std::getenv("TM_AMD_NO_FUSED_WINDOW") == nullptr ? 1 : 0;
     host_[0].n = 0;
     host_[1].n = 0;
+    host_[0].window = window;
+    host_[1].window = window;
+    host_[0].num_atoms = 0; // set by run() / run_energy(), which know N
+    host_[1].num_atoms = 0;
     rest_.clear();
 }
 
@@ -108,6 +116,7 @@ void ForcePlan::add_segment(const int precision_bytes, const FusedSegment &seg, 
     const int blocks = ceil_divide(seg.count, 256);
     t.block_end[t.n] = (t.n ? t.block_end[t.n - 1] : 0) + blocks;
     t.seg[t.n] = seg;
+    t.seg[t.n].window = (owner != nullptr && owner->max_atom_incidence() < FUSED_WINDOW_MIN_INCIDENCE) ? 0 : 1;
     t.n++;
 }
 
@@ -123,6 +132,7 @@ void ForcePlan::upload_tables(bool pending[2], hipStream_t stream) {
         for (int k = t.n; k < FUSED_MAX_SEGMENTS; k++) {
             t.block_end[k] = 0;
             t.seg[k] = FusedSegment{0, 0, nullptr, nullptr, nullptr, 0.0, 0.0};
+            t.seg[k].window = 0;
         }
         if (!uploaded_valid_[prec] || std::memcmp(&uploaded_[prec], &t, sizeof(FusedTable)) != 0) {
             d_table_[prec].reserve(1);
@@ -138,6 +148,7 @@ void ForcePlan::upload_tables(bool pending[2], hipStream_t stream) {
 }
 
 void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, i128 *d_u, hipStream_t stream) {
+    host_[0].num_atoms = host_[1].num_atoms = N;
     bool pending[2];
     this->upload_tables(pending, stream);
     EnergySources src;
@@ -209,6 +220,7 @@ bool ForcePlan::run(
     u64 *table_acc = d_du_dx_cm ? d_du_dx_cm : d_du_dx;
     const ForceLayout table_fl = d_du_dx_cm ? ForceLayout{1, cm_stride} : ForceLayout{3, 1};
     // 1. tables to the device (only when they changed since the last step)
+    host_[0].num_atoms = host_[1].num_atoms = N;
     bool pending[2] = {false, false};
     this->upload_tables(pending, stream);
     bool table_went_to_acc = false; // a table's forces were (or will be) added to table_acc

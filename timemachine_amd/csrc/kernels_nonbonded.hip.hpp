@@ -380,12 +380,14 @@ __device__ __forceinline__ i128 nonbonded_pair_list_term(
 // this header; called by k_fused_forces and by the tail of the tile kernel.
 // (a real call, not inlined: inside the tile kernel its registers would be allocated together with the item loop's, and the
 // f64 kernels sit at their 168-VGPR limit -- with the bonded terms inlined, any change to them moved spills into that loop)
-// `window`: FORCE_WINDOW * 3 u64 of LDS private to the calling wave (ForceLayout::win), or nullptr.  All 64 lanes of the wave
-// must make the call (the window is zeroed, filled and flushed by the whole wave).
+// `window`: FORCE_WINDOW * 3 u64 of LDS private to the calling wave (ForceLayout::win), or nullptr; `window_rows`: FORCE_WINDOW
+// ints of LDS private to the wave (the accumulator rows of the window's atoms, fetched while the terms compute).  All 64 lanes
+// of the wave must make the call (the window is zeroed, filled and flushed by the whole wave).
+typedef __attribute__((address_space(3))) int *lds_int_ptr;
 template <typename Real>
 __device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window);
+    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window, lds_int_ptr window_rows);
 
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
 // Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
@@ -625,8 +627,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
                 // (window: this wave's s_fi + s_fj, contiguous and not in use before the first item is staged)
                 static_assert(sizeof(lds.fi) + sizeof(lds.fj) >= sizeof(u64) * 3 * FORCE_WINDOW && offsetof(WaveLds, fj) == offsetof(WaveLds, fi) + sizeof(lds.fi), "window");
+                static_assert(sizeof(lds.queue) >= sizeof(int) * FORCE_WINDOW, "window rows");
                 fused_dispatch<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box, out_du_dx, ForceLayout{out_atom_stride, out_comp_stride, out_remap},
-                                     (lds_u64_ptr)(&s_fi[0][0]));
+                                     (lds_u64_ptr)(&s_fi[0][0]), (lds_int_ptr)(&s_queue[0]));
             }
         }
     }
@@ -1235,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_nonbonded_precomputed(
 template <typename Real>
 __device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window) {
+    const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window, lds_int_ptr window_rows) {
     const int n = table->n;
     int s = 0, first = 0;
     for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
@@ -1255,6 +1258,9 @@ __device__ __attribute__((noinline)) void fused_dispatch(
     // The slice's LDS window starts a few atoms below the first atom of its first term: term lists come in atom order
     // (molecule by molecule), so the atoms of 64 consecutive terms nearly always fall inside; whatever does not takes the
     // global atomic as before.
+    if (table->window == 0 || seg.window == 0) {
+        window = nullptr; // sparse term lists (ForcePlan::add_segment), or the A/B switch TM_AMD_NO_FUSED_WINDOW: straight to the global accumulator
+    }
     if (window != nullptr) {
         const int width = seg.kind == FUSED_ANGLE ? 3 : ((seg.kind == FUSED_TORSION || seg.kind == FUSED_CHIRAL_ATOM || seg.kind == FUSED_CHIRAL_BOND) ? 4 : 2);
         const int a0 = __builtin_amdgcn_readfirstlane(seg.idxs[static_cast<size_t>(idx0) * width]);
@@ -1262,6 +1268,15 @@ __device__ __attribute__((noinline)) void fused_dispatch(
         fl.win_base = a0 > 8 ? a0 - 8 : 0;
         for (int t = lane; t < 3 * FORCE_WINDOW; t += 64) {
             window[t] = 0;
+        }
+        // the window atoms' accumulator rows (a dependent global load when the accumulator is remapped): requested now, needed
+        // only by the flush -- the terms compute underneath.  (Fetched in the flush itself, the window cost small systems 2 us
+        // per step: a lone wave's second dependent load stage.)  Atoms past the end of the system never receive a force.
+        if (fl.remap != nullptr) {
+            for (int t = lane; t < FORCE_WINDOW; t += 64) {
+                const int a = fl.win_base + t;
+                window_rows[t] = a < table->num_atoms ? fl.remap[a] : 0;
+            }
         }
         wave_lds_sync();
     }
@@ -1292,8 +1307,9 @@ __device__ __attribute__((noinline)) void fused_dispatch(
         for (int t = lane; t < 3 * FORCE_WINDOW; t += 64) {
             const u64 v = window[t];
             if (v != 0) {
-                const int d = t / FORCE_WINDOW, a = fl.win_base + (t - d * FORCE_WINDOW);
-                atomicAdd(du_dx + fl.row(a) + static_cast<size_t>(d) * fl.comp, v);
+                const int d = t / FORCE_WINDOW, off = t - d * FORCE_WINDOW;
+                const size_t row = fl.remap != nullptr ? static_cast<size_t>(window_rows[off]) * fl.atom : static_cast<size_t>(fl.win_base + off) * fl.atom;
+                atomicAdd(du_dx + row + static_cast<size_t>(d) * fl.comp, v);
             }
         }
         wave_lds_sync();

@@ -994,6 +994,7 @@ NonbondedPairList<Real, Negated>::NonbondedPairList(
     d_scales_.realloc(M_ * 2);
     if (M_ > 0) {
         d_pair_idxs_.copy_from(pair_idxs.data());
+        this->note_term_atoms(pair_idxs);
         d_scales_.copy_from(scales.data());
     }
     d_u_partials_.realloc(ceil_divide(M_, 256) * 4 + 1);
@@ -1053,6 +1054,7 @@ NonbondedPairListPrecomputed<Real>::NonbondedPairListPrecomputed(const std::vect
     d_pair_idxs_.realloc(B_ * 2);
     if (B_ > 0) {
         d_pair_idxs_.copy_from(pair_idxs.data());
+        this->note_term_atoms(pair_idxs);
     }
     d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
 }
