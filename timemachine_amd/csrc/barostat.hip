@@ -60,18 +60,45 @@ __global__ void k_barostat_propose(
     box_proposed[8] *= scale;
 }
 
+// Fixed-point sums of the molecules' coordinates.  A molecule's atoms are consecutive in the flattened group list, so the
+// lanes of a wave that belong to one molecule form a run: the run's sum is formed in registers (a segmented scan over the
+// lanes, six shuffle steps) and its LAST lane issues the atomics -- one per run and component instead of one per atom.
+// (One atomic per atom made the 83 atoms of a solute chain queue on a single cache line: 18.9 us for this kernel at 23.5k
+// atoms, memory-side atomics being served one after the other per line.)  Integer sums: the same bits in any order.
 template <typename Real>
 __global__ void k_barostat_centroids(
     const int n_grouped, const double *__restrict__ x, const int *__restrict__ atom_idxs, const int *__restrict__ mol_idxs,
     u64 *__restrict__ centroids) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_grouped) {
-        return;
-    }
-    const int a = atom_idxs[idx], m = mol_idxs[idx];
+    const int lane = threadIdx.x & 63;
+    const bool valid = idx < n_grouped;
+    const int m = valid ? mol_idxs[idx] : -1 - lane; // invalid lanes: runs of their own
+    u64 v[3] = {0, 0, 0};
+    if (valid) {
+        const int a = atom_idxs[idx];
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        atomicAdd(centroids + m * 3 + d, float_to_fixed<Real>(static_cast<Real>(x[a * 3 + d])));
+        for (int d = 0; d < 3; d++) {
+            v[d] = float_to_fixed<Real>(static_cast<Real>(x[a * 3 + d]));
+        }
+    }
+    // segmented inclusive scan: after step o a lane holds the sum of its run's members among the 2 o lanes ending at it
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int m_up = __shfl_up(m, o, 64);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const u64 up = __shfl_up(v[d], o, 64);
+            if (lane >= o && m_up == m) {
+                v[d] += up;
+            }
+        }
+    }
+    const int m_next = __shfl_down(m, 1, 64);
+    if (valid && (lane == 63 || m_next != m)) { // the last lane of a run carries its sum
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            atomicAdd(centroids + m * 3 + d, v[d]);
+        }
     }
 }
 
