@@ -312,7 +312,7 @@ def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
     """config 3: du/dx of NonbondedAllPairs on a sample of the i<j pair matrix (row-blocked dense evaluation == the reference's
     JAX formulation): `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see ~N columns, rows near N almost
     none: one slab says little about the whole, eight evenly spaced ones see its average), scaled to the full matrix by pair
-    count.  The same sample is timed `reps` times (after an untimed slab); the median is reported, the spread is timing noise."""
+    count.  The same sample is timed `reps` times (after an untimed pass over it); the median is reported, the spread is timing noise."""
     import torch
 
     from oracle import ref_potentials as rp
@@ -325,10 +325,11 @@ def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
     spacing = (N - 1) // slabs_per_rep
     starts = [k * spacing + spacing // 2 for k in range(slabs_per_rep)]  # the SAME slabs every repetition: the spread is timing noise only
     estimates, seconds = [], []
-    for rep in range(-1, reps):  # rep -1: one untimed slab (thread pool start-up, allocator)
+    for rep in range(-1, reps):  # rep -1: one untimed pass over the whole sample (thread pool, allocator, clocks: measured 61 / 51 / 40 s
+        # for three passes when only a single slab came first)
         xt = torch.tensor(x, requires_grad=True)
         el, pairs_sample = 0.0, 0
-        for start in (starts if rep >= 0 else [N // 2]):
+        for start in starts:
             r0, r1 = start, min(start + rows_per_slab, N - 1)
             t0 = time.time()
             d3 = rp.delta_r(xt[r0:r1][:, None, :], xt[r0:][None, :, :], torch.diagonal(bt))
