@@ -266,6 +266,11 @@ int tm_profile_reset(void);
  * (DESIGN.md section 9, item 6).  0 turns that off process-wide (every box change rebuilds, as in the reference);
  * results are bit-identical either way -- the test suite checks exactly that. */
 int tm_debug_set_box_scaling_reuse(int enabled);
+/* debugging / A-B aid: nonbonded potentials over at most `max_atoms` atoms keep a STATIC, complete interaction list (every column
+ * block listed for every row block: nothing can invalidate it, no list kernel runs on MD steps).
+ * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.
+ * Results are bit-identical either way. */
+int tm_debug_set_static_list_max_k(int max_atoms, int *previous);
 /* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.hip.hpp):
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
  * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */

@@ -228,6 +228,7 @@ def test_box_scaling_keeps_the_neighbor_list_valid(co, relaxed, precision, inter
 
     def run(reuse):
         co.debug_set_box_scaling_reuse(reuse)
+        static_before = co.debug_set_static_list_max_k(0)  # this test is about list REBUILDS: a static, complete list has none
         try:
             bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s, precision, nblist_padding=padding)]
             baro = MonteCarloBarostat(N, pressure, 300.0, groups, interval, 5).impl(bps)
@@ -237,6 +238,7 @@ def test_box_scaling_keeps_the_neighbor_list_valid(co, relaxed, precision, inter
             return xs, boxes, baro.get_counters(), nb.get_build_count()
         finally:
             co.debug_set_box_scaling_reuse(True)
+            co.debug_set_static_list_max_k(static_before)
 
     xs_a, boxes_a, counters_a, builds_a = run(True)
     xs_b, boxes_b, counters_b, builds_b = run(False)

@@ -839,6 +839,14 @@ int tm_debug_set_box_scaling_reuse(int enabled) {
     g_box_scaling_reuse = enabled != 0;
     TM_CATCH
 }
+int tm_debug_set_static_list_max_k(int max_atoms, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_static_list_max_k;
+    }
+    g_static_list_max_k = max_atoms;
+    TM_CATCH
+}
 int tm_profile_set_enabled(int enabled) {
     TM_TRY
     Profiler::get().set_enabled(enabled != 0);

@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "nb_es_table.hip.hpp"
 
+#include <limits>
 #include <memory>
 #include <optional>
 
@@ -498,6 +499,7 @@ private:
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
+extern int g_static_list_max_k;  // potentials over at most this many atoms keep a static, complete list (tm_debug_set_static_list_max_k)
 
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
 class NonbondedAllPairsBase : public Potential {
@@ -581,12 +583,26 @@ protected:
     bool box_scales_ = false; // a barostat works on this potential (expect_box_scaling)
     // scale-aware rebuild test (kernels_nonbonded.hip.hpp: k_check_gather_scaled): on when a mover is at work and the padding
     // leaves room for the scale allowance
-    bool scale_aware() const { return box_scales_ && g_box_scaling_reuse && 0.5 * nblist_padding_ - 0.5 * 0.004 * (cutoff_ + nblist_padding_) > 0.25 * nblist_padding_; }
+    bool scale_aware() const { return box_scales_ && g_box_scaling_reuse && 0.5 * list_padding() - 0.5 * 0.004 * (cutoff_ + list_padding()) > 0.25 * list_padding(); }
     // squared displacement (against the list build's snapshot) beyond which the list is rebuilt
     double rebuild_threshold2() const {
-        const double d = scale_aware() ? 0.5 * nblist_padding_ - 0.5 * 0.004 * (cutoff_ + nblist_padding_) : 0.5 * nblist_padding_;
+        if (static_list()) {
+            // never: no displacement invalidates a complete list (and whoever raised the flag would also reset list counters
+            // that no build refills -- an exploding system would lose its forces instead of being reported unstable)
+            return std::numeric_limits<double>::infinity();
+        }
+        const double d = scale_aware() ? 0.5 * list_padding() - 0.5 * 0.004 * (cutoff_ + list_padding()) : 0.5 * list_padding();
         return d * d;
     }
+    // SMALL systems keep a STATIC, complete list: with K <= static_list_max_k() interacting atoms every column block is listed for
+    // every row block (a padding far beyond any box), so no displacement can invalidate the list, the rebuild flag never goes
+    // up, and no list kernel is launched on MD steps at all -- at this size a step is three kernel launches' worth of latency,
+    // not work, and the launch that only reads the flag is one of them.  The phase-2 test `d2 < cutoff^2` decides alone, as
+    // always: same bits.  nblist_padding_ stays what the caller asked for (get_nblist_padding); this is what the list is built with.
+    bool static_list() const { return K_ <= static_list_max_k() && group_rows_ == 0; }
+    double list_padding() const { return static_list() ? 1.0e3 : nblist_padding_; }
+    static int static_list_max_k();
+    bool static_list_built_ = false; // the complete list of the current order exists
     bool defer_u_reduce_ = false; // run_pipeline leaves the tile kernel's energy partials un-reduced (execute_energy_partials)
     int u_partials_count_ = 0;
     u64 *piggyback_acc_ = nullptr; // where the piggy-backed table's forces go, and its layout

@@ -574,6 +574,15 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     }
 }
 
+// Measured on water boxes and solvated ligands (scripts/size_sweep.py, us per MD step, listed -> static; f64 / f32):
+//   256 atoms 19.3 -> 16.4 / 18.3 -> 15.6;  900: 22.0 -> 17.9 / 20.2 -> 16.9;  2 243: 29.8 -> 24.2 / 27.5 -> 22.7;
+//   3 600: 31.4 -> 26.1 / 33.8 -> 22.3;  6 318: 40.3 -> 38.7 / 34.6 -> 39.3;  9 000: 44.6 -> 58.9 / 40.9 -> 52.6
+#ifndef TM_STATIC_LIST_MAX_K
+#define TM_STATIC_LIST_MAX_K 4608
+#endif
+int g_static_list_max_k = std::getenv("TM_AMD_STATIC_LIST_MAX_K") ? std::atoi(std::getenv("TM_AMD_STATIC_LIST_MAX_K")) : TM_STATIC_LIST_MAX_K;
+template <typename Real> int NonbondedAllPairs<Real>::static_list_max_k() { return g_static_list_max_k; }
+
 template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::vector<int> &atom_idxs) {
     verify_atom_idxs(N_, atom_idxs);
     std::vector<unsigned int> u(atom_idxs.begin(), atom_idxs.end());
@@ -732,7 +741,8 @@ void NonbondedAllPairs<Real>::run_pipeline(
     pre_sorted_ = false;
 
     // (a) every STEPS_PER_SORT calls: re-sort along the Hilbert curve; a new order invalidates the list
-    int force = (force_rebuild_ || (sorted_pending && !pregathered)) ? 1 : 0;
+    // (a static list does not care that bounds / counters of an unconsumed hand-over are stale: only a new order invalidates it)
+    int force = (force_rebuild_ || (sorted_pending && !pregathered && !static_list())) ? 1 : 0;
     if (calls_since_sort_ % steps_per_sort_ == 0) {
         if (!disable_hilbert_ && group_rows_ > 0) { // interaction group: each side keeps its own contiguous, sorted range
             hilbert_->sort_device(group_rows_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
@@ -768,9 +778,15 @@ void NonbondedAllPairs<Real>::run_pipeline(
     }
 
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
-    nblist_.build_device(
-        d_gathered_.data, d_box, cutoff_ + nblist_padding_, cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream,
-        pregathered && sorted_pending, !pregathered && scale_aware());
+    if (static_list() && static_list_built_ && !force) {
+        // the complete list of this order exists and nothing can invalidate it: no list kernel on this call
+    } else {
+        const bool bounds_done = pregathered && sorted_pending && !force; // (a forced build computes its own bounds and counters)
+        nblist_.build_device(
+            d_gathered_.data, d_box, cutoff_ + list_padding(), cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream,
+            bounds_done, !pregathered && scale_aware());
+        static_list_built_ = static_list() && force != 0;
+    }
 
     TM_DEBUG_SYNC("list build", stream);
     // (d) K4: tile kernel

@@ -1111,6 +1111,14 @@ void declare_functions(py::module &m) {
         },
         py::arg("values"), py::arg("precision"));
     m.def("debug_set_box_scaling_reuse", [](const bool enabled) { check(tm_debug_set_box_scaling_reuse(enabled ? 1 : 0)); }, py::arg("enabled"));
+    m.def(
+        "debug_set_static_list_max_k",
+        [](const int max_atoms) { // A/B aid: static complete lists for potentials over <= max_atoms atoms (0: off); -> the old value
+            int previous = 0;
+            check(tm_debug_set_static_list_max_k(max_atoms, &previous));
+            return previous;
+        },
+        py::arg("max_atoms"));
     m.def("debug_check_guards", []() { // -DTM_GUARD builds: violated guard zones so far; -1 in product builds
         int n = 0;
         check(tm_debug_check_guards(&n));

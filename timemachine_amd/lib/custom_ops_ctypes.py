@@ -1036,6 +1036,14 @@ def version():
     return _lib.tm_version().decode()
 
 
+def debug_set_static_list_max_k(max_atoms):
+    """A/B aid: potentials over at most `max_atoms` atoms keep a static, complete interaction list (0: off); -> the old value.
+    Results are bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_static_list_max_k(_c_int(int(max_atoms)), ctypes.byref(prev)))
+    return prev.value
+
+
 def profile_set_enabled(enabled):
     _check(_lib.tm_profile_set_enabled(_c_int(1 if enabled else 0)))
 
