@@ -17,8 +17,9 @@ pass() { name=$1; shift
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS
 pass b SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE
 pass c SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_ATOMIC_RETURN SQ_ACTIVE_INST_MISC
-pass fetch FETCH_SIZE
-pass write WRITE_SIZE
+pass d SQ_INSTS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_IFETCH SQ_INSTS_VSKIPPED SQ_ACTIVE_INST_VALU2 SQ_INST_LEVEL_LDS SQ_BUSY_CU_CYCLES
+[ -n "${PMC_SKIP_TRAFFIC:-}" ] || pass fetch FETCH_SIZE
+[ -n "${PMC_SKIP_TRAFFIC:-}" ] || pass write WRITE_SIZE
 cd $ROOT
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys

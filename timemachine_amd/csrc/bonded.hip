@@ -16,9 +16,10 @@ template <typename Real> HarmonicBond<Real>::HarmonicBond(const std::vector<int>
         }
     }
     d_idxs_.realloc(B_ * 2);
-    if (B_ > 0)
+    if (B_ > 0) {
         d_idxs_.copy_from(bond_idxs.data());
-        this->note_term_atoms(bond_idxs);
+    }
+    this->note_term_atoms(bond_idxs);
     d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
 }
 
@@ -60,9 +61,10 @@ template <typename Real> HarmonicAngle<Real>::HarmonicAngle(const std::vector<in
         }
     }
     d_idxs_.realloc(A_ * 3);
-    if (A_ > 0)
+    if (A_ > 0) {
         d_idxs_.copy_from(angle_idxs.data());
-        this->note_term_atoms(angle_idxs);
+    }
+    this->note_term_atoms(angle_idxs);
     d_u_partials_.realloc(ceil_divide(A_, 256) * 4 + 1);
 }
 
@@ -104,9 +106,10 @@ template <typename Real> PeriodicTorsion<Real>::PeriodicTorsion(const std::vecto
         }
     }
     d_idxs_.realloc(T_ * 4);
-    if (T_ > 0)
+    if (T_ > 0) {
         d_idxs_.copy_from(torsion_idxs.data());
-        this->note_term_atoms(torsion_idxs);
+    }
+    this->note_term_atoms(torsion_idxs);
     d_u_partials_.realloc(ceil_divide(T_, 256) * 4 + 1);
 }
 
@@ -143,9 +146,10 @@ template <typename Real> ChiralAtomRestraint<Real>::ChiralAtomRestraint(const st
         throw std::runtime_error("idxs.size() must be exactly 4*k!");
     }
     d_idxs_.realloc(R_ * 4);
-    if (R_ > 0)
+    if (R_ > 0) {
         d_idxs_.copy_from(idxs.data());
-        this->note_term_atoms(idxs);
+    }
+    this->note_term_atoms(idxs);
     d_u_partials_.realloc(ceil_divide(R_, 256) * 4 + 1);
 }
 
@@ -248,9 +252,10 @@ FlatBottomBond<Real, Log>::FlatBottomBond(const std::vector<int> &bond_idxs, con
         }
     }
     d_idxs_.realloc(B_ * 2);
-    if (B_ > 0)
+    if (B_ > 0) {
         d_idxs_.copy_from(bond_idxs.data());
-        this->note_term_atoms(bond_idxs);
+    }
+    this->note_term_atoms(bond_idxs);
     d_u_partials_.realloc(ceil_divide(B_, 256) * 4 + 1);
 }
 
