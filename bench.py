@@ -63,12 +63,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # = 1/2 of the 157.3 TFLOP/s FP32 vector peak (MI3
 FP32_VALU_PEAK_TFLOPS = 157.3
 C_PAIR_FLOPS = 280.0  # per interacting pair (rsqrt, erfc, exp, sincos, LJ, fixed-point conversions)
 C_SLOT_FLOPS = 20.0  # per evaluated slot (min-image distance + cutoff test)
-# The same two figures counted on THIS kernel's ISA (f64 forces-only batch body / compact filter round, DESIGN.md section 4.2;
-# an FMA = 2): displacement 4, d^2 7, table index + degree-5 Horner 11, charges 2, LJ 20, prefactor 1, fixed-point products +
-# magic adds 6 = 51 per interacting pair; filter: 4 subtractions + mul + 3 FMA = 11 per evaluated slot.  The table-driven
-# kernel simply executes fewer flops than the reference formula SURVEY priced.
-OWN_PAIR_FLOPS = {"f64": 51.0, "f32": 78.0}  # f32: analytic erfc / exp / switch instead of the table (rsq, rcp, exp, sin, cos count 1)
-OWN_SLOT_FLOPS = 11.0
+# The same two figures counted on THIS kernel's ISA (f64 forces-only batch body on a flat item / Gram-form filter round, DESIGN.md
+# section 4.2; an FMA = 2): displacement 3, d^2 5, table index + degree-5 Horner 11, charges 2, LJ 20, prefactor 1, fixed-point
+# products + magic adds 6 = 48 per interacting pair; filter: 3 FMA = 6 per evaluated slot (the row's |r|^2 arrives by a move, the
+# threshold carries the column's |c|^2).  The table-driven kernel simply executes fewer flops than the reference formula SURVEY priced.
+OWN_PAIR_FLOPS = {"f64": 48.0, "f32": 75.0}  # f32: analytic erfc / exp / switch instead of the table (rsq, rcp, exp, sin, cos count 1)
+OWN_SLOT_FLOPS = 6.0
 CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; used only to turn a kernel time into cycles for valu_busy
 METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
@@ -660,7 +660,7 @@ def run_md(args, rank, local_rank, world, backend):
         rv["own_isa"] = {"flops_per_pair": OWN_PAIR_FLOPS[args.precision], "flops_per_slot": OWN_SLOT_FLOPS, "flops_per_launch": own,
                          "achieved": own / t_s / 1e12, "frac": own / t_s / 1e12 / peak_fl,
                          "note": "flops this kernel's ISA executes per pair / per filter slot (FMA = 2); the fraction of peak a flop count can reach is "
-                                 "bounded by the share of FMA among the issued instructions -- the kernel is VALU-ISSUE bound, see valu_busy"}
+                                 "bounded by the share of FMA among the issued instructions -- the kernel is bound by instruction ISSUE (all types), see insts_all_per_launch / valu_busy"}
         sq = pmc.get("sq") or {}
         if sq.get("SQ_INSTS_VALU"):
             kernel_cycles = t_s * CLOCK_GHZ * 1e9
@@ -668,6 +668,7 @@ def run_md(args, rank, local_rank, world, backend):
             rv["lane_ops_per_pair"] = sq["SQ_INSTS_VALU"] * 64.0 / p_int
             # SQ_ACTIVE_INST_VALU counts quad-cycles the VALUs spend executing; 1024 SIMDs x kernel cycles are available
             rv["valu_busy"] = sq.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024.0 * kernel_cycles)
+            rv["insts_all_per_launch"] = sq.get("SQ_INSTS")  # every instruction type: the kernel is bound by issue, not by VALU time alone
             rv["insts_salu_per_launch"] = sq.get("SQ_INSTS_SALU")
             rv["insts_lds_per_launch"] = sq.get("SQ_INSTS_LDS")
             rv["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT")

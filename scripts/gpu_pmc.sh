@@ -14,7 +14,7 @@ pass() { # name, counters...
   echo "pmc pass $name exit $?"
 }
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS
-pass sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+pass sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 cd $ROOT
@@ -42,7 +42,7 @@ for f in sorted(glob.glob(sys.argv[1]+'/*/*counter_collection.csv')):
             if 'tiles' in k or 'find_ixns' in k or 'baoab' in k: print(line)
             # the MD-step variant of the tile kernel: forces only (<Real, false, true, false>)
             if k.startswith('k_nonbonded_tiles<%s, false, true, false' % {'f64': 'double', 'f32': 'float'}[sys.argv[2]]) and disp[k] > 50:
-                for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT',
+                for c in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_LDS_BANK_CONFLICT',
                           'SQ_ACTIVE_INST_LDS', 'SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS', 'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'):
                     if c in agg[k]: traffic[c] = agg[k][c] / disp[k]
 if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:

@@ -85,25 +85,31 @@ template <int OFFSET> __device__ __forceinline__ double lds_read_f64_async(const
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_offset), "n"(OFFSET));
     return v;
 }
-// (SKIP_W: component 3 is not read)
-template <int C, int ROW_STRIDE, int COL_STRIDE, bool SKIP_W = false> __device__ __forceinline__ void lds_read14(const unsigned int ra, const unsigned int ca, double (&ri)[7], double (&cj)[7]) {
+// (COL_BASE: byte distance of the column array from the row array, both addressed from the row array's base; SKIP_W: component
+// 3 is neither read nor waited for)
+template <int C, int ROW_STRIDE, int COL_STRIDE, int COL_BASE, bool SKIP_W = false> __device__ __forceinline__ void lds_read14(const unsigned int ra, const unsigned int ca, double (&ri)[7], double (&cj)[7]) {
     if constexpr (C < 7) {
         if constexpr (!(SKIP_W && C == 3)) {
             ri[C] = lds_read_f64_async<C * ROW_STRIDE>(ra);
-            cj[C] = lds_read_f64_async<C * COL_STRIDE>(ca);
+            cj[C] = lds_read_f64_async<COL_BASE + C * COL_STRIDE>(ca);
         }
-        lds_read14<C + 1, ROW_STRIDE, COL_STRIDE, SKIP_W>(ra, ca, ri, cj);
+        lds_read14<C + 1, ROW_STRIDE, COL_STRIDE, COL_BASE, SKIP_W>(ra, ca, ri, cj);
     }
 }
-template <int C, int ROW_STRIDE, int COL_STRIDE, bool SKIP_W = false> __device__ __forceinline__ void lds_read14(const unsigned int, const unsigned int, float (&)[7], float (&)[7]) {}
+template <int C, int ROW_STRIDE, int COL_STRIDE, int COL_BASE, bool SKIP_W = false> __device__ __forceinline__ void lds_read14(const unsigned int, const unsigned int, float (&)[7], float (&)[7]) {}
 // waits for every outstanding LDS operation of the wave; the values pass through the statement so that no use of them can
 // be scheduled in front of it
-__device__ __forceinline__ void lds_wait14(double (&a)[7], double (&b)[7]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
-                   "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(double (&a)[7], double (&b)[7]) {
+    if constexpr (SKIP_W) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
+                       "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+    }
 }
-__device__ __forceinline__ void lds_wait14(float (&)[7], float (&)[7]) {}
+template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(float (&)[7], float (&)[7]) {}
 // one lane step to the left through the whole wave: lane l receives lane l + 1's value, lane 63 lane 0's (DPP wave_rol:1, a
 // VALU move: no LDS).  All 64 lanes must be enabled.  scripts/microbench/dpp_rotate.hip prints the mapping on the device.
 __device__ __forceinline__ float wave_rol1(const float v) {
@@ -932,10 +938,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     // fourteen (flat items: twelve) single ds_read_b64 (2 LDS cycles each; row reads are conflict free: 32 rows =
                     // 64 banks).  Left to itself the compiler pairs them into ds_read2_b64, which the LDS serves at half that rate
                     // (MI355X_MICROARCH.md, LDS table: 8 cycles per wave instruction against 2 + 2).
-                    const unsigned int ra = lds_offset(&s_row[0][pi]), ca = lds_offset(&s_col[0][pj]);
-                    ri[3] = cj[3] = 0;
-                    lds_read14<0, TILE * 8, NB_CHUNK * 8, FLAT>(ra, ca, ri, cj);
-                    lds_wait14(ri, cj);
+                    // (one base register: the column array's distance from the row array rides in the instructions' offset fields)
+                    const unsigned int ra = lds_offset(&s_row[0][0]) + pi * 8u, ca = lds_offset(&s_row[0][0]) + pj * 8u;
+                    lds_read14<0, TILE * 8, NB_CHUNK * 8, static_cast<int>(offsetof(WaveLds, col) - offsetof(WaveLds, row)), FLAT>(ra, ca, ri, cj);
+                    lds_wait14<FLAT>(ri, cj);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
