@@ -38,6 +38,11 @@ for prec, name, waves in ((np.float64, "f64", int(os.environ.get("WG_WAVES_F64",
     resid = wg_end - A @ coef
     print(f"{name}: {nwg} workgroups x {waves} waves | span {en.max() - st0:.0f} ticks | wg end pct " + " ".join(f"{np.percentile(wg_end, q):.0f}" for q in (0, 10, 50, 90, 100)))
     print(f"   items/wg pct " + " ".join(f"{np.percentile(wg_items, q):.0f}" for q in (0, 10, 50, 90, 100)) + " | batches/wg pct " + " ".join(f"{np.percentile(wg_batches, q):.0f}" for q in (0, 10, 50, 90, 100)))
+    wave_end = W(en) - st0
+    wave_start = W(st) - st0
+    idle_in_wg = (wg_end[:, None] - wave_end).mean(axis=1)  # ticks a wave idles, on average, before its workgroup ends
+    print(f"   inside a workgroup: waves start {wave_start.mean():.0f} +- {wave_start.std():.0f} ticks after the first; a wave is done {idle_in_wg.mean():.0f} ticks before its workgroup on average "
+          f"(max over workgroups {idle_in_wg.max():.0f}); launch span {en.max() - st0:.0f}, mean workgroup end {wg_end.mean():.0f}, mean wave end {wave_end.mean():.0f}")
     print(f"   fit end = {coef[0]:.1f}*items + {coef[1]:.2f}*batches + {coef[2]:.0f}; residual std {resid.std():.0f} ticks; corr(end,batches) {np.corrcoef(wg_end, wg_batches)[0,1]:.2f} corr(end,items) {np.corrcoef(wg_end, wg_items)[0,1]:.2f}")
     print("   mean end per xcc: " + " ".join(f"{wg_end[wg_xcc == k].mean():.0f}" for k in range(8)) + " | mean batches per xcc: " + " ".join(f"{wg_batches[wg_xcc == k].mean():.0f}" for k in range(8)))
     order = np.argsort(wg_end)
