@@ -623,20 +623,33 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // so one L2 round trip (the index load) is exposed per item instead of three dependent hops.
     const unsigned int uK = static_cast<unsigned int>(K);
     const unsigned int NO_ITEM = 0xffffffffu;
-    unsigned int bucket_end; // lane l: end (exclusive prefix sum) of bucket number l in class-major order
+    // f64: this thread's share of the force-factor table is REQUESTED first of all (the L2 is cold at a kernel boundary: ~2.5k
+    // cycles) and written to LDS behind the three dependent hops of the first item's fetch, instead of being fetched after them
+    constexpr int ES_TAB_PER_THREAD = (ES_TAB_DOUBLES + WAVES * 64 - 1) / (WAVES * 64);
+    [[maybe_unused]] double es_tab_mine[sizeof(Real) == 8 ? ES_TAB_PER_THREAD : 1];
+    if constexpr (sizeof(Real) == 8) {
+#pragma unroll
+        for (int k = 0; k < ES_TAB_PER_THREAD; k++) {
+            const int i = static_cast<int>(threadIdx.x) + k * WAVES * 64;
+            es_tab_mine[k] = i < ES_TAB_DOUBLES ? es_table[i] : 0.0;
+        }
+    }
+    unsigned int bucket_end; // lane l: end (inclusive prefix sum) of bucket number l in class-major order
     {
         const unsigned int cls = lane / NB_SHARDS, sh = lane % NB_SHARDS;
-        unsigned int v = class_counts[sh * NB_CLASSES + cls];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned int up = __shfl_up(v, o, 64);
-            if (lane >= o) {
-                v += up;
-            }
-        }
-        bucket_end = v;
+        // inclusive wave scan on the VALU: row_shr 1, 2, 4, 8 inside the 16-lane rows (sources beyond a row read 0), then row
+        // 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the lower half's total into the upper (row_bcast:31)
+        // -- six DPP adds instead of six dependent LDS shuffles
+        int v = static_cast<int>(class_counts[sh * NB_CLASSES + cls]);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true); // row_bcast:15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true); // row_bcast:31 into rows 2 and 3
+        bucket_end = static_cast<unsigned int>(v);
     }
-    const unsigned int n_items_total = __shfl(bucket_end, 63, 64);
+    const unsigned int n_items_total = static_cast<unsigned int>(__builtin_amdgcn_readlane(static_cast<int>(bucket_end), 63));
     auto next_position = [&]() -> unsigned int {
         // The pool of workgroup b: round r of the cost-sorted order contributes position r * G + (r even ? b : G-1-b)
         // (serpentine deal over the G workgroups: the one that drew the heaviest item of a round draws the lightest of
@@ -724,12 +737,19 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         load_indices(items[item], cur);
         load_records(cur);
     }
+    TM_T(tp_fetch);
     if constexpr (sizeof(Real) == 8) {
-        for (int i = threadIdx.x; i < ES_TAB_DOUBLES; i += WAVES * 64) {
-            s_es_tab[i] = es_table[i];
+#pragma unroll
+        for (int k = 0; k < ES_TAB_PER_THREAD; k++) {
+            const int i = static_cast<int>(threadIdx.x) + k * WAVES * 64;
+            if (i < ES_TAB_DOUBLES) {
+                s_es_tab[i] = es_tab_mine[k];
+            }
         }
     }
+    TM_T(tp_copy);
     __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
+    TM_T(tp_barrier);
 
     if constexpr (!COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) {
         if (fused) {
@@ -749,6 +769,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         }
     }
 
+#ifdef TM_TIMING_PRO
+    const long long tp_loop = clock64();
+#endif
     while (item != NO_ITEM) {
         TM_T(t_a);
         // ---- stage A happens late in this item (see the round loop): the later a wave draws its next item, the better
@@ -1209,7 +1232,12 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #ifdef TM_TIMING
     if (lane == 0 && timing) {
         long long *t = timing + static_cast<size_t>(global_wave) * 8;
+#ifdef TM_TIMING_PRO
+        // prologue view: cycles to [first fetch issued | table copy issued | barrier passed | item loop entered]
+        t[0] = (tp_fetch - tm_begin) | ((tp_copy - tm_begin) << 16) | ((tp_barrier - tm_begin) << 32) | ((tp_loop - tm_begin) << 48);
+#else
         t[0] = tm_setup;
+#endif
         t[1] = tm_p1;
         t[2] = tm_p2;
         t[3] = tm_flush | (static_cast<long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 56) | (static_cast<long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff) << 40);
