@@ -748,13 +748,10 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         }
     }
     TM_T(tp_copy);
-    // The only workgroup-wide barrier (the table copy and the ticket counter must be in place before the first batch / the first
-    // draw): f32 takes it here; f64 -- whose waves would wait here for the slowest wave's table loads, ~1.2k cycles -- takes it
-    // behind the staging of the first item, just in front of its rounds (a wave without any item: after the item loop).
-    [[maybe_unused]] bool barrier_pending = F64;
-    if constexpr (!F64) {
-        __syncthreads();
-    }
+    // (measured: f64 waves wait ~1.2k cycles here for the slowest wave's table loads.  Taking the barrier later -- behind the first
+    // item's staging -- saves 0.4 us per launch without a ForcePlan table on board and COSTS 8 us with one: the waves that run a
+    // slice of bonded terms in front of their first item then hold everybody at the barrier.)
+    __syncthreads(); // the only workgroup-wide barrier: from here on the waves run independently
     TM_T(tp_barrier);
 
     if constexpr (!COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) {
@@ -1157,12 +1154,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             }
             group(r_end - 4, fast_tag, std::true_type{});
         };
-        if constexpr (F64) {
-            if (barrier_pending) {
-                __syncthreads();
-                barrier_pending = false;
-            }
-        }
         if (hint<F64>(fast, true)) {
             run_rounds(std::true_type{});
         } else {
@@ -1240,11 +1231,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         cur = nxt;
         item = item_next;
         sub_cur = sub_next;
-    }
-    if constexpr (F64) {
-        if (barrier_pending) {
-            __syncthreads();
-        }
     }
 #ifdef TM_TIMING
     if (lane == 0 && timing) {
