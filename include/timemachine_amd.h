@@ -275,6 +275,9 @@ int tm_debug_set_static_list_max_k(int max_atoms, int *previous);
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
  * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */
 int tm_es_force_table(double beta, double *out);
+/* the same layout for the energy factor G(d^2) = erfc(beta d) S(d) / d that calls asking for energies or du/dp read
+ * (u_es = charge_scale q_i q_j G; k_nonbonded_common.cuh:184-212).  out: double[1536]. */
+int tm_es_energy_table(double beta, double *out);
 
 /* ---- HREX: a batch of neighbour-swap Metropolis moves on the state -> replica permutation (host only; no device work)
  * replaces the jitted loop timemachine/md/hrex.py:50-130 (_run_neighbor_swaps): for attempt t, pair k = pair_idxs[t] =

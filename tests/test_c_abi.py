@@ -200,3 +200,13 @@ def test_es_force_table_matches_the_analytic_function():
         # F -> 0 at the end of the switch: an absolute floor there (1e-10 in F = 6e-9 kJ/mol/nm on a water O-H pair)
         assert np.all(np.abs(p - F) < 3e-11 * np.abs(F) + 1e-10)
         assert np.max(np.abs(p - F)[s < 1.0] / np.abs(F)[s < 1.0]) < (6e-12 if beta == 2.0 else 3e-11)
+        # the energy factor G(d^2) = erfc(beta d) S(d) / d of the calls that ask for energies / du/dp: same layout, same bound
+        gtab = custom_ops.es_energy_table(beta)
+        assert gtab.shape == (256, 6) and np.all(np.isfinite(gtab))
+        c = gtab[idx]
+        p = c[:, 5]
+        for k in (4, 3, 2, 1, 0):
+            p = p * t + c[:, k]
+        G = e * S / d
+        assert np.all(np.abs(p - G) < 3e-11 * np.abs(G) + 1e-11)
+        assert np.max(np.abs(p - G)[s < 1.0] / np.abs(G)[s < 1.0]) < (6e-12 if beta == 2.0 else 3e-11)

@@ -867,6 +867,11 @@ int tm_es_force_table(double beta, double *out) {
     es_force_table_host(beta, out);
     TM_CATCH
 }
+int tm_es_energy_table(double beta, double *out) {
+    TM_TRY
+    es_energy_table_host(beta, out);
+    TM_CATCH
+}
 int tm_hrex_run_neighbor_swaps(
     int n_replicas, int n_states, const int64_t *replica_idx_by_state, int n_pairs, const int64_t *neighbor_pairs, const double *log_q_kl,
     int n_attempts, const int64_t *pair_idxs, const double *uniform_samples, int64_t *out_replica_idx_by_state, uint32_t *proposed,

@@ -551,7 +551,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     __shared__ WaveLds s_wave[WAVES];
     __shared__ unsigned int s_ticket; // next position of this workgroup's pool
     // f64: the workgroup's copy of the electrostatic force-factor table (12 KB, read-only after the barrier below)
-    __shared__ __attribute__((aligned(16))) double s_es_tab[sizeof(Real) == 8 ? ES_TAB_DOUBLES : 2];
+    // (energy launches keep the energy-factor table behind it; the du/dp variants, whose per-wave LDS is the largest, read
+    // that one from global memory)
+    constexpr bool G_IN_LDS = sizeof(Real) == 8 && COMPUTE_U && !COMPUTE_DU_DP;
+    constexpr int ES_TAB_LDS_DOUBLES = (G_IN_LDS ? 2 : 1) * ES_TAB_DOUBLES;
+    __shared__ __attribute__((aligned(16))) double s_es_tab[sizeof(Real) == 8 ? ES_TAB_LDS_DOUBLES : 2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -573,9 +577,15 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // copy's L2 round trip then runs alongside the three dependent hops of that fetch instead of in front of them)
     // how phase 2 reaches the table: f64 reads the LDS copy with three ds_read_b128 per pair
     struct EsTableLds {
-        const double *tab;
+        const double *tab;  // force factor F: the workgroup's LDS copy
+        const double *gtab; // energy factor G: the LDS copy (energy launches) or the table in global memory (du/dp variants)
         __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
             const double2 *p = reinterpret_cast<const double2 *>(tab + idx * ES_TAB_COEFFS);
+            const double2 a = p[0], b = p[1], e = p[2];
+            c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
+        }
+        __device__ __forceinline__ void load_g(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
+            const double2 *p = reinterpret_cast<const double2 *>(gtab + idx * ES_TAB_COEFFS);
             const double2 a = p[0], b = p[1], e = p[2];
             c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
         }
@@ -584,6 +594,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     TileTab es_tab{};
     if constexpr (sizeof(Real) == 8) {
         es_tab.tab = s_es_tab;
+        es_tab.gtab = G_IN_LDS ? s_es_tab + ES_TAB_DOUBLES : es_table + ES_TAB_DOUBLES;
     }
     constexpr bool F64 = sizeof(Real) == 8; // (hints for the f32 kernels too: re-measured at the end of round 2, +0.1 %, not applied)
     const NbBox<Real> bx = load_box<Real>(box);
@@ -625,13 +636,13 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     const unsigned int NO_ITEM = 0xffffffffu;
     // f64: this thread's share of the force-factor table is REQUESTED first of all (the L2 is cold at a kernel boundary: ~2.5k
     // cycles) and written to LDS behind the three dependent hops of the first item's fetch, instead of being fetched after them
-    constexpr int ES_TAB_PER_THREAD = (ES_TAB_DOUBLES + WAVES * 64 - 1) / (WAVES * 64);
+    constexpr int ES_TAB_PER_THREAD = (ES_TAB_LDS_DOUBLES + WAVES * 64 - 1) / (WAVES * 64);
     [[maybe_unused]] double es_tab_mine[sizeof(Real) == 8 ? ES_TAB_PER_THREAD : 1];
     if constexpr (sizeof(Real) == 8) {
 #pragma unroll
         for (int k = 0; k < ES_TAB_PER_THREAD; k++) {
             const int i = static_cast<int>(threadIdx.x) + k * WAVES * 64;
-            es_tab_mine[k] = i < ES_TAB_DOUBLES ? es_table[i] : 0.0;
+            es_tab_mine[k] = i < ES_TAB_LDS_DOUBLES ? es_table[i] : 0.0;
         }
     }
     unsigned int bucket_end; // lane l: end (inclusive prefix sum) of bucket number l in class-major order
@@ -742,7 +753,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #pragma unroll
         for (int k = 0; k < ES_TAB_PER_THREAD; k++) {
             const int i = static_cast<int>(threadIdx.x) + k * WAVES * 64;
-            if (i < ES_TAB_DOUBLES) {
+            if (i < ES_TAB_LDS_DOUBLES) {
                 s_es_tab[i] = es_tab_mine[k];
             }
         }

@@ -15,8 +15,12 @@
 //     code does), to <= 5e-12 relative -- tighter than the 3e-11 polynomials of the analytic f64 path (nb_math.hip.hpp);
 //   * s below the table (d < 0.088 nm: clashing atoms only) takes the analytic form behind a wave-uniform branch.
 // Every kernel that evaluates a pair (tiles, pair lists, exclusions, fused plan) goes through es_force_factor() with a
-// table made by the same host routine from the same beta, so excluded pairs still cancel bit for bit.  Energies and
-// du/dp keep the analytic damping function: they are not on the MD path.
+// table made by the same host routine from the same beta, so excluded pairs still cancel bit for bit.
+//
+// A second table of the same layout holds the ENERGY factor
+//   G(s) = D(d) / d        (u_es = charge_scale * q_i q_j * G(d^2);  du/dq_i = charge_scale * q_j * G(d^2))
+// for the calls that ask for energies or du/dp (barostat attempts, HREX energy rows, free-energy derivatives): it sits
+// behind the force table in the same device array (es_force_table_device() returns 2 * ES_TAB_DOUBLES doubles).
 #pragma once
 #include "common.hpp"
 
@@ -33,10 +37,12 @@ static const unsigned int ES_TAB_IDX0 = static_cast<unsigned int>(1023 + ES_TAB_
 #define TM_ES_TAB_S_MIN 0.0078125          // 2^-7
 #define TM_ES_SWITCH_D 1.2                 // k_nonbonded_common.cuh:16-30: the switch ends here whatever `cutoff` is
 
-// host: the table for `beta` as a device array of ES_TAB_DOUBLES doubles (built once per beta and device, never freed)
+// host: the tables for `beta` as ONE device array of 2 * ES_TAB_DOUBLES doubles -- force factor F, then energy factor G
+// (built once per beta and device, never freed)
 const double *es_force_table_device(double beta);
-// host: the same coefficients on the host (tests / documentation)
+// host: the same coefficients on the host (tests / documentation): ES_TAB_DOUBLES doubles each
 void es_force_table_host(double beta, double *out);
+void es_energy_table_host(double beta, double *out);
 
 #ifdef __HIPCC__
 // index and in-interval position from the bits of s; idx >= ES_TAB_INTERVALS (as unsigned) <=> s outside [2^-7, 2)

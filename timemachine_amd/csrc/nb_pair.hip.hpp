@@ -153,9 +153,14 @@ __device__ __forceinline__ void nb_pair(
 // Where a kernel keeps the table: LDS (tile kernel: a copy made at kernel start) or global memory (pair lists).  Both
 // hold the same doubles and feed the same arithmetic, so the two give identical bits.
 struct EsTableGlobal {
-    const double *__restrict__ tab;
+    const double *__restrict__ tab; // force factor F; the energy factor G follows it (nb_es_table.hip.hpp)
     __device__ __forceinline__ void load(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
         const double2 *p = reinterpret_cast<const double2 *>(tab + static_cast<size_t>(idx) * ES_TAB_COEFFS);
+        const double2 a = p[0], b = p[1], e = p[2];
+        c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
+    }
+    __device__ __forceinline__ void load_g(const unsigned int idx, double (&c)[ES_TAB_COEFFS]) const {
+        const double2 *p = reinterpret_cast<const double2 *>(tab + ES_TAB_DOUBLES + static_cast<size_t>(idx) * ES_TAB_COEFFS);
         const double2 a = p[0], b = p[1], e = p[2];
         c[0] = a.x; c[1] = a.y; c[2] = b.x; c[3] = b.y; c[4] = e.x; c[5] = e.y;
     }
@@ -212,6 +217,37 @@ template <typename Tab> __device__ __forceinline__ double es_force_factor(const 
     return f;
 }
 
+// G(d2) = erfc(beta d) S(d) / d from the second table: the electrostatic energy of a pair is charge_scale * q_i q_j * G(d2)
+// and du/dq_i = charge_scale * q_j * G(d2).  0 beyond the end of the switch; the analytic form under the table.
+__device__ __attribute__((noinline, cold)) double es_energy_factor_below_table(const double beta, const double d2) {
+    const double inv = tm_rsqrt_f64(d2);
+    double damping;
+    (void)real_es_factor(beta, d2 * inv, inv, inv * inv, damping);
+    return inv * damping;
+}
+template <typename Tab> __device__ __forceinline__ double es_energy_factor(const double beta, const double d2, const Tab &tab) {
+    double t;
+    unsigned int idx = es_tab_index(d2, t);
+    const bool outside = idx >= static_cast<unsigned int>(ES_TAB_INTERVALS); // d2 < 2^-7 or d2 >= 2 (or NaN)
+    idx = outside ? 0u : idx;
+    double c[ES_TAB_COEFFS];
+    tab.load_g(idx, c);
+    double p = __builtin_fma(c[5], t, c[4]);
+    p = __builtin_fma(p, t, c[3]);
+    p = __builtin_fma(p, t, c[2]);
+    p = __builtin_fma(p, t, c[1]);
+    p = __builtin_fma(p, t, c[0]);
+    const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
+    double g = (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
+    const bool below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
+    if (__ballot(below) != 0ull) { // clashing atoms (d < 0.088 nm) only
+        if (below) {
+            g = es_energy_factor_below_table(beta, d2);
+        }
+    }
+    return g;
+}
+
 // The forces-only f64 pair function with its two rare cases left to the caller (the tile kernel folds them into ONE
 // wave-uniform escape together with the fixed-point overflow case): the operations of nb_pair<false> below in the same
 // order, so the same bits.  `below`: d2 lies under the table, the value returned is not to be used --
@@ -257,7 +293,7 @@ __device__ __attribute__((noinline, cold)) double nb_pair_prefactor_below_table(
 // The f64 pair function.  WANT_U_DP = false (MD: forces only) never forms 1/d, erfc, exp or the switch function:
 //   prefactor = s_q q_i q_j F(d2) - s_lj eps_ij sig6 (48 sig6 - 24) / d2,   sig6 = (sig_ij^2 / d2)^3
 // WANT_U_DP = true adds, on top of the SAME prefactor arithmetic (so du/dx has the same bits whichever outputs are asked
-// for), the analytic damping function for the energy and du/dq, and the LJ parameter derivatives.
+// for), the tabulated energy factor G(d2) for the energy and du/dq, and the LJ parameter derivatives.
 template <bool WANT_U_DP, typename Tab>
 __device__ __forceinline__ void nb_pair(
     double charge_scale, double lj_scale, double qi, double qj, double sig_i, double sig_j, double eps_i, double eps_j, double d2ij,
@@ -287,13 +323,11 @@ __device__ __forceinline__ void nb_pair(
         }
     }
     if constexpr (WANT_U_DP) {
-        const double inv_dij = tm_rsqrt_f64(d2ij);
-        const double dij = d2ij * inv_dij;
-        double damping;
-        (void)real_es_factor(beta, dij, inv_dij, inv_dij * inv_dij, damping);
-        u += charge_scale * qij * inv_dij * damping;
-        o.inv_dij = inv_dij;
-        o.ebd = damping;
+        // (PairOut carries the factor as inv_dij * ebd: the callers' q_j * inv_dij * ebd is q_j * G exactly)
+        const double g = es_energy_factor(beta, d2ij, tab);
+        u += charge_scale * qij * g;
+        o.inv_dij = 1.0;
+        o.ebd = g;
     }
     o.prefactor = prefactor;
     o.u = u;

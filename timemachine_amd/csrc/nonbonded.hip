@@ -53,8 +53,17 @@ static long double es_force_factor_reference(const long double beta, const long 
     const long double damp = e * S, dprime = e * dS + de * S;
     return inv * (dprime * inv - damp * inv * inv);
 }
+// G(s) = erfc(beta d) S(d) / d, continued the same way
+static long double es_energy_factor_reference(const long double beta, const long double s) {
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const long double d = sqrtl(s);
+    const long double x = d / 1.2L;
+    const long double x2 = x * x, x4 = x2 * x2, q = x4 * x4;
+    const long double c = cosl(0.5L * pi * q);
+    return erfcl(beta * d) * c * c * c / d;
+}
 
-void es_force_table_host(const double beta, double *out) {
+static void es_table_fit(long double (*fn)(long double, long double), const double beta, double *out) {
     const int n = ES_TAB_COEFFS;
     const long double pi = 3.14159265358979323846264338327950288L;
     for (int iv = 0; iv < ES_TAB_INTERVALS; iv++) {
@@ -70,7 +79,7 @@ void es_force_table_host(const double beta, double *out) {
                 A[k][c] = pw;
                 pw *= t;
             }
-            A[k][n] = es_force_factor_reference(beta, lo + (hi - lo) * t);
+            A[k][n] = fn(beta, lo + (hi - lo) * t);
         }
         for (int c = 0; c < n; c++) { // Gauss-Jordan with partial pivoting (6 x 6, long double)
             int piv = c;
@@ -97,6 +106,9 @@ void es_force_table_host(const double beta, double *out) {
     }
 }
 
+void es_force_table_host(const double beta, double *out) { es_table_fit(es_force_factor_reference, beta, out); }
+void es_energy_table_host(const double beta, double *out) { es_table_fit(es_energy_factor_reference, beta, out); }
+
 const double *es_force_table_device(const double beta) {
     // one table per (device, beta), kept for the life of the process: potentials of one state share it.  Constructors may run
     // on several host threads at once (the bindings release the GIL around calls): the cache is guarded.
@@ -115,11 +127,12 @@ const double *es_force_table_device(const double beta) {
     if (it != cache.end()) {
         return it->second;
     }
-    std::vector<double> host(ES_TAB_DOUBLES);
+    std::vector<double> host(2 * ES_TAB_DOUBLES);
     es_force_table_host(beta, host.data());
+    es_energy_table_host(beta, host.data() + ES_TAB_DOUBLES);
     double *d = nullptr;
-    HIP_CHECK(hipMalloc(&d, ES_TAB_DOUBLES * sizeof(double)));
-    HIP_CHECK(hipMemcpy(d, host.data(), ES_TAB_DOUBLES * sizeof(double), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&d, host.size() * sizeof(double)));
+    HIP_CHECK(hipMemcpy(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
     cache[key] = d;
     return d;
 }

@@ -1068,6 +1068,14 @@ void declare_functions(py::module &m) {
         },
         py::arg("beta"));
     m.def(
+        "es_energy_table",
+        [](const double beta) { // host only: [256, 6] coefficients of the f64 kernels' electrostatic energy factor G(d^2)
+            arr_d out(std::vector<py::ssize_t>{256, 6});
+            check(tm_es_energy_table(beta, out.mutable_data()));
+            return out;
+        },
+        py::arg("beta"));
+    m.def(
         "hrex_run_neighbor_swaps",
         [](const arr_i64 &replica_idx_by_state, const arr_i64 &neighbor_pairs, const arr_d &log_q_kl, const arr_i64 &pair_idxs, const arr_d &uniform_samples) {
             // the swap chain of one HREX exchange step, natively (timemachine/md/hrex.py:50-130 is a jitted lax.scan)

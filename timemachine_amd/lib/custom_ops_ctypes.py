@@ -984,6 +984,13 @@ def es_force_table(beta):
     return out
 
 
+def es_energy_table(beta):
+    """Host-only: [256, 6] polynomial coefficients of the f64 kernels' electrostatic energy factor G(d^2) (nb_es_table.hip.hpp)."""
+    out = np.zeros((256, 6), dtype=np.float64)
+    _check(_lib.tm_es_energy_table(_c_double(float(beta)), _ptr(out)))
+    return out
+
+
 def hrex_run_neighbor_swaps(replica_idx_by_state, neighbor_pairs, log_q_kl, pair_idxs, uniform_samples):
     """The swap chain of one HREX exchange step, in native code (timemachine/md/hrex.py:50-130 is a jitted lax.scan; a
     Python loop over n_states**3 attempts costs 25 ms at 24 states).  -> (replica_idx_by_state, proposed, accepted)"""
