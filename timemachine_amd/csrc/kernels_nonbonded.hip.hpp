@@ -9,12 +9,14 @@
 //   items         int4         work items {row_block, col_start, col_count, 0}: 32 rows x <=64 columns each
 //
 // Tile kernel design (one wave per work item; persistent workgroups of 8-12 waves drawing items from a per-CU pool):
-//   phase 1  every lane owns one column atom in registers; 32 rounds, lane l meets row (round + l) & 31
-//            (rotation => the rows, and the columns, hit in one round are all distinct).  All 32x64 slots get a CHEAP,
-//            CONSERVATIVE distance filter in f32 on coordinates taken relative to the tile's first row atom (so f32
-//            resolution does not depend on how far the unwrapped coordinates have drifted): it keeps every pair whose
-//            exact d2 could be below cutoff^2 (margin >> f32 rounding error).  Survivors are compacted with
-//            ballot + popcount into an LDS queue of (row, col) byte pairs.
+//   phase 1  every lane owns one column atom in registers; 32 rounds; the row atoms sit, as two replicated halves, in
+//            registers that every round reads ROTATED through the DPP control of the arithmetic itself: in round r lane l
+//            meets row ((l - r) & 15) + 16 * (((l >> 5) ^ (r >> 4)) & 1) -- every row is met by exactly two lanes per round.
+//            All 32x64 slots get a CHEAP, CONSERVATIVE distance filter in f32 on coordinates taken relative to the tile's
+//            first row atom (so f32 resolution does not depend on how far the unwrapped coordinates have drifted), in the
+//            Gram form |r|^2 - 2 r.c < cut2 - |c|^2 (5 vector instructions per round): it keeps every pair whose exact d2
+//            could be below cutoff^2 (margin >> f32 rounding error).  Survivors are compacted with mask + mbcnt into an
+//            LDS queue of 16-bit (round, column lane) entries, four rounds per asm statement.
 //   phase 2  whenever >= 64 pairs are queued, all 64 lanes pop one pair each, redo the distance in Real precision
 //            with the exact strict test `d2 < cutoff^2` (the only test that decides anything), and run the expensive
 //            erfc/exp/sincos path at full lane occupancy (the reference leaves ~2/3 of the lanes idle inside
@@ -110,12 +112,6 @@ template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(double
     }
 }
 template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(float (&)[7], float (&)[7]) {}
-// one lane step to the left through the whole wave: lane l receives lane l + 1's value, lane 63 lane 0's (DPP wave_rol:1, a
-// VALU move: no LDS).  All 64 lanes must be enabled.  scripts/microbench/dpp_rotate.hip prints the mapping on the device.
-__device__ __forceinline__ float wave_rol1(const float v) {
-    const int b = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x134, 0xf, 0xf, true));
-}
 // branch-probability hint for the block placement of the f64 kernels (measured: +0.5 % there, -2 % on the f32 kernels)
 template <bool ON> __device__ __forceinline__ bool hint(const bool c, const bool expected) {
     if constexpr (ON) {
