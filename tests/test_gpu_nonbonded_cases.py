@@ -466,3 +466,65 @@ def test_static_complete_list_of_small_systems_changes_no_bit(co, P, precision):
         np.testing.assert_array_equal(a[k], b[k])
     assert a[3] == b[3] and a[7] == b[7] and a[7][0] > 0
     assert b[6] < a[6] and b[6] <= 8, (a[6], b[6])  # listed: a rebuild every few steps; static: only with a new order
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("static_list", [True, False])
+@pytest.mark.parametrize("case", ["dense_alchemical", "sparse_large_box", "drifted_images", "tiny_box"])
+def test_tile_filter_paths_against_the_oracle(co, P, precision, case, static_list):
+    """The tile kernel's phase-1 filter has a fast path (Gram form, no w term: flat items off the list's diagonal) and general
+    ones (per-atom w; items whose extent exceeds the Gram form's bound or half a box length: explicit differences with the
+    minimum image; diagonal tiles with the row < col test), chosen per item.  Whatever the filter does, the exact test in
+    phase 2 decides -- so every combination must reproduce the oracle: a dense box with per-atom w (all items non-flat), a
+    sparse 60 nm box (row blocks span many nm: no Gram form), coordinates drifted by whole box lengths per atom (wrapped on the
+    way to the tile origin: phase 2 re-images), and a box barely twice the cutoff (hardly any item is compact) -- each on the
+    static complete list these sizes get by default (items then pair every row block with every column block, however far
+    apart) and on a built neighbor list."""
+    from oracle import ref_potentials as rp
+    from test_gpu_parity import compare_forces
+
+    rng = np.random.default_rng({"dense_alchemical": 1, "sparse_large_box": 2, "drifted_images": 3, "tiny_box": 4}[case])
+    cutoff, beta = 1.2, 2.0
+    if case == "sparse_large_box":
+        n, edge = 700, 60.0
+        # clusters, so that pairs inside the cutoff exist at all at this density
+        centres = rng.uniform(0.0, edge, (35, 3))
+        x = (centres[rng.integers(0, 35, n)] + rng.normal(0.0, 0.45, (n, 3))) % edge
+    elif case == "tiny_box":
+        n, edge = 500, 2.45
+        x = rng.uniform(0.0, edge, (n, 3))
+    else:
+        n, edge = 900, 3.0
+        x = rng.uniform(0.0, edge, (n, 3))
+    # keep clear of clashes: the oracle and the kernels agree there too, but tolerances are relative to huge numbers then
+    box = np.eye(3) * edge
+    for _ in range(50):
+        d = x[:, None, :] - x[None, :, :]
+        d -= edge * np.round(d / edge)
+        r = np.sqrt((d * d).sum(-1)) + np.eye(n) * 10.0
+        i, j = np.nonzero(r < 0.17)
+        if len(i) == 0:
+            break
+        x[i] += rng.normal(0.0, 0.1, (len(i), 3))
+        x %= edge
+    if case == "drifted_images":
+        # (f32: one box length -- at +-9 nm the f32 coordinates themselves carry 1e-6 nm, 1.2e-4 of a steep LJ force)
+        reach = 3 if precision == np.float64 else 1
+        x = x + edge * rng.integers(-reach, reach + 1, (n, 3))
+    x = x.astype(np.float32).astype(np.float64)
+    params = np.zeros((n, 4))
+    params[:, 0] = rng.normal(0.0, 0.4, n)
+    params[:, 1] = rng.uniform(0.05, 0.17, n)
+    params[:, 2] = np.where(rng.random(n) < 0.4, rng.uniform(0.2, 1.0, n), 0.0)
+    if case in ("dense_alchemical", "tiny_box"):
+        params[:, 3] = np.where(rng.random(n) < 0.5, rng.uniform(0.0, cutoff, n), 0.0)
+    params = params.astype(np.float32).astype(np.float64)
+    excl = np.zeros((0, 2), dtype=np.int32)
+    scales = np.zeros((0, 2))
+    pot = P.Nonbonded(n, excl, scales, beta, cutoff)
+    u, du_dx, du_dp = rp.nonbonded(x, params, box, excl, scales, beta, cutoff)
+    previous = co.debug_set_static_list_max_k(4608 if static_list else 0)
+    try:
+        compare_forces(pot.to_gpu(precision).unbound_impl, x, params, box, float(u), du_dx, du_dp, precision)
+    finally:
+        co.debug_set_static_list_max_k(previous)
