@@ -31,20 +31,21 @@
 
 namespace tmamd {
 
-// Waves per SIMD the tile kernel is register-budgeted for (512 / waves VGPRs per lane).  f64: the pair math plus the
-// VGPR-resident erfcx coefficients need ~130 registers -- 3 waves without spills beats 4 waves with 60+ spilled
-// dwords (measured: 148 vs 167 us per launch at 23.5k atoms).  f32: ~100 registers -> 4 waves (5 fit with 96,
+// Waves per SIMD the tile kernel is register-budgeted for (512 / waves VGPRs per lane).  f64: 4 waves = 128 registers since the
+// general filter paths became asm statements too (round 3: in plain C++ they took the whole kernel from 130 to 156 registers
+// and 4 waves meant 60 spilled dwords; measured then: 63.2 / 68 us against 63.9 / 62 at 3 waves; now 55.9 against 58.9 on a bare
+// tile launch, 57.2 against 57.8 with a step's bonded terms on board).  f32: ~100 registers -> 4 waves (5 would fit with 96,
 // but only in a workgroup shape whose item pools are too small, see TileShape).
 template <typename Real> struct TileWaves {
 #ifndef TM_TILE_WAVES_F64
-#define TM_TILE_WAVES_F64 3
+#define TM_TILE_WAVES_F64 4
 #endif
 #ifndef TM_TILE_WAVES_F32
 #define TM_TILE_WAVES_F32 4
 #endif
     static const int value = sizeof(Real) == 8 ? TM_TILE_WAVES_F64 : TM_TILE_WAVES_F32;
 };
-// Workgroup shape of the tile kernel.  f64: one workgroup owns a whole CU (12 waves = 3 per SIMD).  f32: two 8-wave
+// Workgroup shape of the tile kernel.  f64: one workgroup owns a whole CU (16 waves = 4 per SIMD; the du/dp variants 12).  f32: two 8-wave
 // workgroups per CU = 4 waves per SIMD -- the registers would admit 5, but 20 waves only tile a CU as five 4-wave
 // groups, and pools of ~10 items for 4 waves end 29 % apart (measured: 5 x 4 waves 2740 ns/day, 2 x 8 2920, 1 x 16 2905).  Its waves draw work items from a
 // pool that belongs to the workgroup through an LDS ticket counter: static, cost-sorted pools across CUs (sums over
@@ -188,6 +189,111 @@ __device__ __forceinline__ void filter4_gram_flat(
         "v_cmp_lt_f32_e64 %[m3], %[a3], %[thr]"
         : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
         : [rx] "v"(rx), [ry] "v"(ry), [rz] "v"(rz), [rr] "v"(rr), [c2x] "v"(c2x), [c2y] "v"(c2y), [c2z] "v"(c2z), [thr] "v"(thr));
+}
+// The same with the w term (items whose atoms differ in w, and the general path's Gram items): one more multiply-add per round.
+__device__ __forceinline__ void filter4_gram_w(
+    const float rx, const float ry, const float rz, const float rw, const float rr, const float c2x, const float c2y, const float c2z,
+    const float c2w, const float thr, u64 &m0, u64 &m1, u64 &m2, u64 &m3) {
+    float a0, a1, a2, a3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mov_b32_e32 %[a0], %[rr]\n\t"
+        "v_mov_b32_dpp %[a1], %[rr] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[a2], %[rr] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[a3], %[rr] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_e32 %[a0], %[rx], %[c2x]\n\t"
+        "v_fmac_f32_dpp %[a1], %[rx], %[c2x] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[rx], %[c2x] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[rx], %[c2x] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_e32 %[a0], %[ry], %[c2y]\n\t"
+        "v_fmac_f32_dpp %[a1], %[ry], %[c2y] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[ry], %[c2y] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[ry], %[c2y] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_e32 %[a0], %[rz], %[c2z]\n\t"
+        "v_fmac_f32_dpp %[a1], %[rz], %[c2z] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[rz], %[c2z] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[rz], %[c2z] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_e32 %[a0], %[rw], %[c2w]\n\t"
+        "v_fmac_f32_dpp %[a1], %[rw], %[c2w] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a2], %[rw], %[c2w] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %[a3], %[rw], %[c2w] row_ror:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cmp_lt_f32_e64 %[m0], %[a0], %[thr]\n\t"
+        "v_cmp_lt_f32_e64 %[m1], %[a1], %[thr]\n\t"
+        "v_cmp_lt_f32_e64 %[m2], %[a2], %[thr]\n\t"
+        "v_cmp_lt_f32_e64 %[m3], %[a3], %[thr]"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+        : [rx] "v"(rx), [ry] "v"(ry), [rz] "v"(rz), [rw] "v"(rw), [rr] "v"(rr), [c2x] "v"(c2x), [c2y] "v"(c2y), [c2z] "v"(c2z), [c2w] "v"(c2w),
+          [thr] "v"(thr));
+}
+// Four rounds of the explicit form for items the Gram form does not cover (large extents, sparse boxes): differences through the
+// same DPP operands, the minimum image per component (box edges and their inverses as scalars), the squared distance against
+// the padded cutoff.  One round after the other on four scratch registers: these items are rare, what matters is that this
+// path does not cost the kernel registers (in plain C++ the compiler interleaved the four rounds and the whole kernel went
+// from 130 to 156 VGPRs).
+#define TM_EXPLICIT_ROUND(CTRL_SUB, MASK)                                                                              \
+    "v_sub_f32_" CTRL_SUB(dx, rx, cfx) "\n\t"                                                                          \
+    "v_sub_f32_" CTRL_SUB(dy, ry, cfy) "\n\t"                                                                          \
+    "v_sub_f32_" CTRL_SUB(dz, rz, cfz) "\n\t"                                                                          \
+    "v_mul_f32_e32 %[t], %[ibx], %[dx]\n\t"                                                                            \
+    "v_rndne_f32_e32 %[t], %[t]\n\t"                                                                                   \
+    "v_fma_f32 %[dx], -%[bx], %[t], %[dx]\n\t"                                                                         \
+    "v_mul_f32_e32 %[t], %[iby], %[dy]\n\t"                                                                            \
+    "v_rndne_f32_e32 %[t], %[t]\n\t"                                                                                   \
+    "v_fma_f32 %[dy], -%[by], %[t], %[dy]\n\t"                                                                         \
+    "v_mul_f32_e32 %[t], %[ibz], %[dz]\n\t"                                                                            \
+    "v_rndne_f32_e32 %[t], %[t]\n\t"                                                                                   \
+    "v_fma_f32 %[dz], -%[bz], %[t], %[dz]\n\t"                                                                         \
+    "v_mul_f32_e32 %[t], %[dx], %[dx]\n\t"                                                                             \
+    "v_fmac_f32_e32 %[t], %[dy], %[dy]\n\t"                                                                            \
+    "v_fmac_f32_e32 %[t], %[dz], %[dz]\n\t"                                                                            \
+    "v_sub_f32_" CTRL_SUB(dx, rw, cfw) "\n\t"                                                                          \
+    "v_fmac_f32_e32 %[t], %[dx], %[dx]\n\t"                                                                            \
+    "v_cmp_lt_f32_e64 %[" MASK "], %[t], %[cut2]\n\t"
+#define TM_SUB_PLAIN(D, R, C) "e32 %[" #D "], %[" #R "], %[" #C "]"
+#define TM_SUB_ROR1(D, R, C) "dpp %[" #D "], %[" #R "], %[" #C "] row_ror:1 row_mask:0xf bank_mask:0xf"
+#define TM_SUB_ROR2(D, R, C) "dpp %[" #D "], %[" #R "], %[" #C "] row_ror:2 row_mask:0xf bank_mask:0xf"
+#define TM_SUB_ROR3(D, R, C) "dpp %[" #D "], %[" #R "], %[" #C "] row_ror:3 row_mask:0xf bank_mask:0xf"
+__device__ __forceinline__ void filter4_explicit(
+    const float rx, const float ry, const float rz, const float rw, const float cfx, const float cfy, const float cfz, const float cfw,
+    const float bx, const float by, const float bz, const float ibx, const float iby, const float ibz, const float cut2, u64 &m0, u64 &m1,
+    u64 &m2, u64 &m3) {
+    float dx, dy, dz, t;
+    asm volatile("s_nop 1\n\t" TM_EXPLICIT_ROUND(TM_SUB_PLAIN, "m0") TM_EXPLICIT_ROUND(TM_SUB_ROR1, "m1") TM_EXPLICIT_ROUND(TM_SUB_ROR2, "m2")
+                     TM_EXPLICIT_ROUND(TM_SUB_ROR3, "m3") "s_nop 0"
+                 : [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [t] "=&v"(t), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+                 : [rx] "v"(rx), [ry] "v"(ry), [rz] "v"(rz), [rw] "v"(rw), [cfx] "v"(cfx), [cfy] "v"(cfy), [cfz] "v"(cfz), [cfw] "v"(cfw),
+                   [bx] "s"(bx), [by] "s"(by), [bz] "s"(bz), [ibx] "s"(ibx), [iby] "s"(iby), [ibz] "s"(ibz), [cut2] "v"(cut2));
+}
+#undef TM_EXPLICIT_ROUND
+#undef TM_SUB_PLAIN
+#undef TM_SUB_ROR1
+#undef TM_SUB_ROR2
+#undef TM_SUB_ROR3
+// The row < col test of the tiles on the list's diagonal, on four rounds' masks: round r0 + k keeps lane l's hit iff the row slot
+// it meets, ((l - (r0 + k)) & 15) | half_bit, lies below jrel (= the column's index minus the row block's first index).
+__device__ __forceinline__ void order4(const int lane, const int r0, const unsigned int half_bit, const int jrel, u64 &m0, u64 &m1, u64 &m2, u64 &m3) {
+    int t;
+    u64 o;
+    asm volatile(
+        "v_subrev_u32_e32 %[t], %[r0], %[lane]\n\t"
+        "v_and_or_b32 %[t], %[t], 15, %[hb]\n\t"
+        "v_cmp_lt_i32_e64 %[o], %[t], %[jrel]\n\t"
+        "s_and_b64 %[m0], %[m0], %[o]\n\t"
+        "v_subrev_u32_e32 %[t], %[r1], %[lane]\n\t"
+        "v_and_or_b32 %[t], %[t], 15, %[hb]\n\t"
+        "v_cmp_lt_i32_e64 %[o], %[t], %[jrel]\n\t"
+        "s_and_b64 %[m1], %[m1], %[o]\n\t"
+        "v_subrev_u32_e32 %[t], %[r2], %[lane]\n\t"
+        "v_and_or_b32 %[t], %[t], 15, %[hb]\n\t"
+        "v_cmp_lt_i32_e64 %[o], %[t], %[jrel]\n\t"
+        "s_and_b64 %[m2], %[m2], %[o]\n\t"
+        "v_subrev_u32_e32 %[t], %[r3], %[lane]\n\t"
+        "v_and_or_b32 %[t], %[t], 15, %[hb]\n\t"
+        "v_cmp_lt_i32_e64 %[o], %[t], %[jrel]\n\t"
+        "s_and_b64 %[m3], %[m3], %[o]"
+        : [t] "=&v"(t), [o] "=&s"(o), [m0] "+s"(m0), [m1] "+s"(m1), [m2] "+s"(m2), [m3] "+s"(m3)
+        : [lane] "v"(lane), [hb] "v"(half_bit), [jrel] "v"(jrel), [r0] "s"(r0), [r1] "s"(r0 + 1), [r2] "s"(r0 + 2), [r3] "s"(r0 + 3)
+        : "scc");
 }
 // Compaction of four rounds' hits into the wave's LDS queue: the lanes set in mask k write `e0 | k << 11` to consecutive
 // 16-bit slots from byte address `qaddr` on (ballot rank = v_mbcnt), and qaddr advances by two bytes per hit.  One asm
@@ -549,7 +655,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // f64: the workgroup's copy of the electrostatic force-factor table (12 KB, read-only after the barrier below)
     // (energy launches keep the energy-factor table behind it; the du/dp variants, whose per-wave LDS is the largest, read
     // that one from global memory)
-    constexpr bool G_IN_LDS = sizeof(Real) == 8 && COMPUTE_U && !COMPUTE_DU_DP;
+    // (... and so does any shape whose waves' scratch leaves no room for a second 12 KB table in the CU's 160 KB)
+    constexpr bool G_IN_LDS = sizeof(Real) == 8 && COMPUTE_U && !COMPUTE_DU_DP && WAVES * sizeof(WaveLds) + 2 * ES_TAB_DOUBLES * sizeof(double) + 64 <= 160 * 1024;
     constexpr int ES_TAB_LDS_DOUBLES = (G_IN_LDS ? 2 : 1) * ES_TAB_DOUBLES;
     __shared__ __attribute__((aligned(16))) double s_es_tab[sizeof(Real) == 8 ? ES_TAB_LDS_DOUBLES : 2];
 
@@ -1057,51 +1164,39 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         // FAST: flat Gram items off the diagonal -- almost every item of a production system.
         auto group = [&](const int r0, auto fast_tag, auto last_tag) {
             constexpr bool FAST = decltype(fast_tag)::value, LAST = decltype(last_tag)::value;
-            u64 m0, m1, m2, m3;
+            const unsigned int e0 = (static_cast<unsigned int>(r0) << 11) | static_cast<unsigned int>(lane);
             if constexpr (FAST) {
+                u64 m0, m1, m2, m3;
                 filter4_gram_flat(rx, ry, rz, rq, c2x, c2y, c2z, thr, m0, m1, m2, m3);
+                compact4(m0, m1, m2, m3, e0, qaddr);
             } else {
-                u64 m[4];
-                auto general4 = [&](auto gram_tag, auto wrap_tag) {
-                    auto round = [&](auto k_tag) {
-                        constexpr int k = decltype(k_tag)::value;
-                        const float x = row_ror<k>(rx), y = row_ror<k>(ry), z = row_ror<k>(rz), w = row_ror<k>(rw);
-                        bool ok;
-                        if constexpr (decltype(gram_tag)::value) {
-                            const float acc = __builtin_fmaf(w, c2w, __builtin_fmaf(z, c2z, __builtin_fmaf(y, c2y, __builtin_fmaf(x, c2x, row_ror<k>(rq)))));
-                            ok = acc < thr;
-                        } else {
-                            float fdx = x - cfx, fdy = y - cfy, fdz = z - cfz;
-                            if constexpr (decltype(wrap_tag)::value) {
-                                fdx = __builtin_fmaf(-fbx, __builtin_rintf(fdx * fibx), fdx);
-                                fdy = __builtin_fmaf(-fby, __builtin_rintf(fdy * fiby), fdy);
-                                fdz = __builtin_fmaf(-fbz, __builtin_rintf(fdz * fibz), fdz);
-                            }
-                            const float fdw = w + 0.5f * c2w; // row w - column w (padded column: +1e18)
-                            const float fd2 = __builtin_fmaf(fdw, fdw, __builtin_fmaf(fdz, fdz, __builtin_fmaf(fdy, fdy, fdx * fdx)));
-                            ok = fd2 < fcut2;
-                        }
-                        if (needs_order) {
-                            // upper-triangular launches keep only row < col (sorted indices; the row index is row_first + slot)
-                            const int slot_i = static_cast<int>(((lane - (r0 + k)) & 15) | half_bit);
-                            ok = ok && slot_i < jrel;
-                        }
-                        m[k] = __ballot(ok);
-                    };
-                    round(std::integral_constant<int, 0>{});
-                    round(std::integral_constant<int, 1>{});
-                    round(std::integral_constant<int, 2>{});
-                    round(std::integral_constant<int, 3>{});
-                };
+                // the general path: Gram form with the w term, or the explicit form where the Gram form's bounds do not hold;
+                // then the row < col test on diagonal tiles (all asm statements for the registers' sake, see above; four
+                // straight-line combinations: masks that merge behind a branch are no longer scalar as far as the compiler
+                // can tell)
+                u64 m0, m1, m2, m3;
                 if (gram) {
-                    general4(std::true_type{}, std::false_type{});
+                    if (needs_order) {
+                        filter4_gram_w(rx, ry, rz, rw, rq, c2x, c2y, c2z, c2w, thr, m0, m1, m2, m3);
+                        order4(lane, r0, half_bit, jrel, m0, m1, m2, m3);
+                        compact4(m0, m1, m2, m3, e0, qaddr);
+                    } else {
+                        filter4_gram_w(rx, ry, rz, rw, rq, c2x, c2y, c2z, c2w, thr, m0, m1, m2, m3);
+                        compact4(m0, m1, m2, m3, e0, qaddr);
+                    }
                 } else {
-                    general4(std::false_type{}, std::true_type{});
+                    const auto uni = [](const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+                    if (needs_order) {
+                        filter4_explicit(rx, ry, rz, rw, -0.5f * c2x, -0.5f * c2y, -0.5f * c2z, -0.5f * c2w, uni(fbx), uni(fby), uni(fbz), uni(fibx), uni(fiby), uni(fibz), fcut2, m0, m1, m2, m3);
+                        order4(lane, r0, half_bit, jrel, m0, m1, m2, m3);
+                        compact4(m0, m1, m2, m3, e0, qaddr);
+                    } else {
+                        filter4_explicit(rx, ry, rz, rw, -0.5f * c2x, -0.5f * c2y, -0.5f * c2z, -0.5f * c2w, uni(fbx), uni(fby), uni(fbz), uni(fibx), uni(fiby), uni(fibz), fcut2, m0, m1, m2, m3);
+                        compact4(m0, m1, m2, m3, e0, qaddr);
+                    }
                 }
-                m0 = m[0];
-                m1 = m[1];
-                m2 = m[2];
-                m3 = m[3];
+                // (an asm result that merges behind a branch counts as divergent: say that it is not)
+                qaddr = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(qaddr)));
             }
             // the next group reads the rows rotated by four more
             rx = row_ror<4>(rx);
@@ -1111,7 +1206,6 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             if constexpr (!FAST) {
                 rw = row_ror<4>(rw);
             }
-            compact4(m0, m1, m2, m3, (static_cast<unsigned int>(r0) << 11) | static_cast<unsigned int>(lane), qaddr);
 #if defined(TM_ABLATE) && TM_ABLATE == 1
             qaddr = qbase; // ablation: no phase 2 at all
 #endif
