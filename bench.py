@@ -289,10 +289,37 @@ def find_nonbonded(bps):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle timed on the host cores; kind "port": a restatement of the reference's JAX path, not JAX)
 # ---------------------------------------------------------------------------------------------------------------------
+def _cpu_quota():
+    """CPUs this process may actually use at once: the scheduler affinity, cut down to the cgroup's CPU quota (cpu.max / the v1
+    cfs files) where there is one.  The GPU boxes show 256 logical CPUs and grant 16: 64 threads on a 16-CPU quota are throttled
+    by the scheduler in bursts -- the cpu_baseline passes of one run then read 44 / 43 / 37 s."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota|max> <period>"
+            q, period = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n
+
+
 def _cpu_threads(limit=64):
     import torch
 
-    cores = min(os.cpu_count() or 1, limit)  # torch's elementwise kernels stop scaling long before 256 threads
+    cores = min(_cpu_quota(), limit)  # torch's elementwise kernels stop scaling long before 256 threads
     torch.set_num_threads(cores)
     return cores
 
@@ -308,11 +335,11 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
+def cpu_baseline(system, x, cutoff, reps=5, slabs_per_rep=8, rows_per_slab=384):
     """config 3: du/dx of NonbondedAllPairs on a sample of the i<j pair matrix (row-blocked dense evaluation == the reference's
     JAX formulation): `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see ~N columns, rows near N almost
     none: one slab says little about the whole, eight evenly spaced ones see its average), scaled to the full matrix by pair
-    count.  The same sample is timed `reps` times (after an untimed pass over it); the median is reported, the spread is timing noise."""
+    count.  The same sample is timed `reps` times (after three untimed passes over it); the median is reported, the spread is timing noise."""
     import torch
 
     from oracle import ref_potentials as rp
@@ -325,8 +352,8 @@ def cpu_baseline(system, x, cutoff, reps=3, slabs_per_rep=8, rows_per_slab=384):
     spacing = (N - 1) // slabs_per_rep
     starts = [k * spacing + spacing // 2 for k in range(slabs_per_rep)]  # the SAME slabs every repetition: the spread is timing noise only
     estimates, seconds = [], []
-    for rep in range(-1, reps):  # rep -1: one untimed pass over the whole sample (thread pool, allocator, clocks: measured 61 / 51 / 40 s
-        # for three passes when only a single slab came first)
+    for rep in range(-3, reps):  # reps -3 .. -1: three untimed passes over the whole sample (thread pool, allocator, clocks: measured 61 / 51 /
+        # 40 s for three passes when only a single slab came first, and 48.9 / 47.5 / 44.4 -- still falling -- after one full pass)
         xt = torch.tensor(x, requires_grad=True)
         el, pairs_sample = 0.0, 0
         for start in starts:
