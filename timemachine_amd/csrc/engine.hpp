@@ -193,6 +193,9 @@ public:
         return false;
     }
 
+    // Offer of a ForcePlan table to run inside this potential's NEXT energy-only partial-sum evaluation (execute_energy_partials):
+    // the table's energies then arrive in that call's partial sums.  true = accepted (the plan skips its own energy launch).
+    virtual bool piggyback_energy(const FusedTable *d_table, const int blocks, const int precision_bytes) { return false; }
     // Energy-only evaluation that leaves per-wave partial sums (to be added up by the caller) in a buffer of the potential's
     // own instead of reducing them into a d_u -- saves a launch per evaluation.  false = not supported (nothing was run).
     virtual bool execute_energy_partials(
@@ -528,6 +531,7 @@ public:
     int precision_bytes() const override { return static_cast<int>(sizeof(Real)); }
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool piggyback_lands_in_own_accumulator() const override;
+    bool piggyback_energy(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
@@ -580,6 +584,8 @@ protected:
     const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
+    const FusedTable *piggyback_energy_table_ = nullptr; // consumed by the next energy-only partial-sum call
+    int piggyback_energy_blocks_ = 0;
     bool box_scales_ = false; // a barostat works on this potential (expect_box_scaling)
     // scale-aware rebuild test (kernels_nonbonded.hip.hpp: k_check_gather_scaled): on when a mover is at work and the padding
     // leaves room for the scale allowance

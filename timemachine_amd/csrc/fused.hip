@@ -20,44 +20,6 @@ __global__ __launch_bounds__(256) void k_fused_forces(
                          (lds_int_ptr)(&s_window_rows[threadIdx.x >> 6][0]));
 }
 
-// The energy-only twin of fused_dispatch: same table, same per-term device functions with no force outputs asked for;
-// returns the term's fixed-point energy (0 for threads past a segment's end).
-template <typename Real>
-__device__ __forceinline__ i128 fused_dispatch_energy(
-    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
-    const double *__restrict__ box) {
-    const int n = table->n;
-    int s = 0, first = 0;
-    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
-        const int end = table->block_end[k];
-        if (block >= end) {
-            s = k + 1;
-            first = end;
-        }
-    }
-    const FusedSegment seg = table->seg[s];
-    const int idx = (block - first) * 256 + thread;
-    if (idx >= seg.count) {
-        return 0;
-    }
-    switch (seg.kind) {
-    case FUSED_BOND: return harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
-    case FUSED_ANGLE: return harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
-    case FUSED_TORSION: return periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
-    case FUSED_PAIR_LIST:
-        return nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
-    case FUSED_PAIR_LIST_NEGATED:
-        return nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
-    case FUSED_PAIR_LIST_PRECOMPUTED:
-        return nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, nullptr, nullptr, true);
-    case FUSED_CHIRAL_ATOM: return chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
-    case FUSED_CHIRAL_BOND: return chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, nullptr, nullptr, true);
-    case FUSED_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
-    case FUSED_LOG_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
-    default: return 0;
-    }
-}
-
 // every wave of every block writes its partial sum (zero included): the buffer needs no clearing
 template <typename Real>
 __global__ __launch_bounds__(256) void k_fused_energy(
@@ -158,7 +120,19 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
     d_e_slots_.reserve(std::max(n_rest, 1));
     int n_slots = 0;
     bool slots_zeroed = false;
-    // 1. the tables: one launch per precision, per-wave partial sums
+    // 0. a potential whose own energy launch is long (the nonbonded tile kernel) may take a table of its precision along
+    for (const Rest &r : rest_) {
+        bool shared = false;
+        for (const Rest &q : rest_) {
+            shared = shared || (&q != &r && q.pot == r.pot);
+        }
+        for (int prec = 0; prec < 2 && !shared && src.n < ENERGY_MAX_SOURCES - 1; prec++) {
+            if (pending[prec] && r.pot->piggyback_energy(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4)) {
+                pending[prec] = false;
+            }
+        }
+    }
+    // 1. the tables nobody took: one launch per precision, per-wave partial sums
     for (int prec = 0; prec < 2; prec++) {
         if (!pending[prec]) {
             continue;

@@ -601,6 +601,12 @@ __device__ __attribute__((noinline)) void fused_dispatch(
     const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
     const double *__restrict__ box, u64 *__restrict__ du_dx, ForceLayout fl, lds_u64_ptr window, lds_int_ptr window_rows);
 
+// (energy-only twin, defined at the end of this header)
+template <typename Real>
+__device__ __forceinline__ i128 fused_dispatch_energy(
+    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
+    const double *__restrict__ box);
+
 // ---- K4: the tile kernel ------------------------------------------------------------------------------------
 // Registers holding one work item's inputs while they are in flight from HBM/L2 (software pipeline, see below).
 template <typename Real> struct TileRegs {
@@ -889,6 +895,15 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #ifdef TM_TIMING_PRO
     const long long tp_loop = clock64();
 #endif
+    if constexpr (COMPUTE_U && !COMPUTE_DU_DX && !COMPUTE_DU_DP) {
+        if (fused) {
+            // the energy twin: the plan's bonded terms and pair lists add their energies to this wave's partial sum
+            for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
+                energy += fused_dispatch_energy<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box);
+            }
+        }
+    }
+
     while (item != NO_ITEM) {
         TM_T(t_a);
         // ---- stage A happens late in this item (see the round loop): the later a wave draws its next item, the better
@@ -1629,5 +1644,44 @@ __device__ __attribute__((noinline)) void fused_dispatch(
         wave_lds_sync();
     }
 }
+
+// The energy-only twin of fused_dispatch: same table, same per-term device functions with no force outputs asked for;
+// returns the term's fixed-point energy (0 for threads past a segment's end).
+template <typename Real>
+__device__ __forceinline__ i128 fused_dispatch_energy(
+    const FusedTable *__restrict__ table, const int block, const int thread, const double *__restrict__ coords,
+    const double *__restrict__ box) {
+    const int n = table->n;
+    int s = 0, first = 0;
+    for (int k = 0; k + 1 < n; k++) { // wave-uniform: scalar loads
+        const int end = table->block_end[k];
+        if (block >= end) {
+            s = k + 1;
+            first = end;
+        }
+    }
+    const FusedSegment seg = table->seg[s];
+    const int idx = (block - first) * 256 + thread;
+    if (idx >= seg.count) {
+        return 0;
+    }
+    switch (seg.kind) {
+    case FUSED_BOND: return harmonic_bond_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_ANGLE: return harmonic_angle_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_TORSION: return periodic_torsion_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST:
+        return nonbonded_pair_list_term<Real, false>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST_NEGATED:
+        return nonbonded_pair_list_term<Real, true>(idx, coords, seg.params, box, seg.idxs, seg.scales, seg.beta, seg.cutoff, seg.es_table, nullptr, nullptr, true);
+    case FUSED_PAIR_LIST_PRECOMPUTED:
+        return nonbonded_precomputed_term<Real>(idx, coords, seg.params, box, seg.idxs, seg.beta, seg.cutoff, nullptr, nullptr, true);
+    case FUSED_CHIRAL_ATOM: return chiral_atom_term<Real>(idx, coords, seg.params, seg.idxs, nullptr, nullptr, true);
+    case FUSED_CHIRAL_BOND: return chiral_bond_term<Real>(idx, coords, seg.params, seg.idxs, seg.aux, nullptr, nullptr, true);
+    case FUSED_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, false>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
+    case FUSED_LOG_FLAT_BOTTOM_BOND: return flat_bottom_bond_term<Real, true>(idx, coords, box, seg.params, seg.idxs, seg.beta, nullptr, nullptr, true);
+    default: return 0;
+    }
+}
+
 
 } // namespace tmamd

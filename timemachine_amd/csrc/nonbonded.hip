@@ -629,6 +629,15 @@ bool NonbondedAllPairs<Real>::piggyback_forces(
 
 template <typename Real> bool NonbondedAllPairs<Real>::piggyback_lands_in_own_accumulator() const { return piggyback_table_ != nullptr && piggyback_redirect_; }
 
+template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const FusedTable *d_table, const int blocks, const int precision_bytes) {
+    if (precision_bytes != static_cast<int>(sizeof(Real)) || piggyback_energy_table_ != nullptr || empty_) {
+        return false;
+    }
+    piggyback_energy_table_ = d_table;
+    piggyback_energy_blocks_ = blocks;
+    return true;
+}
+
 template <typename Real> std::vector<long long> NonbondedAllPairs<Real>::debug_timing() {
     std::vector<long long> raw(static_cast<size_t>(grid_) * 8);
     HIP_CHECK(hipDeviceSynchronize());
@@ -816,8 +825,15 @@ void NonbondedAllPairs<Real>::run_pipeline(
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
     // a ForcePlan table offered through piggyback_forces() rides on the forces-only launch; any other call drops it
     // back to its owner's stand-alone path by never having accepted it (the plan only offers it for forces-only calls)
-    const FusedTable *pig_table = sel == 2 ? piggyback_table_ : nullptr;
-    const int pig_blocks = sel == 2 ? piggyback_blocks_ : 0;
+    // (an energy table offered through piggyback_energy() rides on the energy-only launch whose partial sums the caller adds up)
+    const bool pig_energy = sel == 4 && defer_u_reduce_ && piggyback_energy_table_ != nullptr;
+    if (piggyback_energy_table_ != nullptr && !pig_energy) {
+        throw std::runtime_error("NonbondedAllPairs: a piggy-backed energy table is pending but this call is not an energy-only partial-sum evaluation");
+    }
+    const FusedTable *pig_table = sel == 2 ? piggyback_table_ : (pig_energy ? piggyback_energy_table_ : nullptr);
+    const int pig_blocks = sel == 2 ? piggyback_blocks_ : (pig_energy ? piggyback_energy_blocks_ : 0);
+    piggyback_energy_table_ = nullptr;
+    piggyback_energy_blocks_ = 0;
     const bool pig_redirect = pig_table != nullptr && piggyback_redirect_;
     u64 *pig_acc = pig_redirect ? d_g_du_dx_.data : piggyback_acc_;
     const int pig_atom_stride = pig_redirect ? 1 : piggyback_atom_stride_, pig_comp_stride = pig_redirect ? acc_stride_ : piggyback_comp_stride_;
