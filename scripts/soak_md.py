@@ -1,0 +1,22 @@
+import os, sys, numpy as np, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from timemachine_amd import potentials as P, testsystems as ts
+from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+co.set_device(0)
+s = ts.dhfr_shaped_box(seed=2025, hmr=True)
+def make_bps(p, padding=0.18):
+    bps = ts.bound_potentials(s, p, nblist_padding=padding)
+    summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps])
+    return [summed.bind_params_list([bp.params for bp in bps]).to_gpu(p).bound_impl]
+x, v = bench.equilibrate(co, LangevinIntegrator, s, make_bps, 1234)
+for prec in (np.float64, np.float32):
+    ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, 7).impl(), make_bps(prec))
+    t0 = time.time()
+    for chunk in range(4):
+        ctxt.multiple_steps(50000, 0)
+        xx, vv = ctxt.get_x_t(), ctxt.get_v_t()
+        ke = 0.5 * (s.masses[:, None] * vv * vv).sum()
+        T = 2 * ke / (3 * s.num_atoms * 0.0083144626)
+        print(prec.__name__, "steps", (chunk + 1) * 50000, "T = %.1f K" % T, "finite", bool(np.all(np.isfinite(xx)) and np.all(np.isfinite(vv))), "max |v| %.2f" % np.abs(vv).max(), flush=True)
+    print("  wall %.1f s for 200k steps" % (time.time() - t0))
