@@ -43,6 +43,10 @@ for prec, name, waves in ((np.float64, "f64", int(os.environ.get("WG_WAVES_F64",
     idle_in_wg = (wg_end[:, None] - wave_end).mean(axis=1)  # ticks a wave idles, on average, before its workgroup ends
     print(f"   inside a workgroup: waves start {wave_start.mean():.0f} +- {wave_start.std():.0f} ticks after the first; a wave is done {idle_in_wg.mean():.0f} ticks before its workgroup on average "
           f"(max over workgroups {idle_in_wg.max():.0f}); launch span {en.max() - st0:.0f}, mean workgroup end {wg_end.mean():.0f}, mean wave end {wave_end.mean():.0f}")
+    xcc_wave = W(xcc)
+    per_xcc_wave_end = [wave_end[xcc_wave == k].mean() for k in range(8)]
+    print("   mean WAVE end per xcc: " + " ".join(f"{v:.0f}" for v in per_xcc_wave_end) + f" | largest {max(per_xcc_wave_end):.0f} vs launch span {en.max() - st0:.0f}"
+          f" (what per-XCD dynamic pools could reach: every wave of an XCD ending together)")
     print(f"   fit end = {coef[0]:.1f}*items + {coef[1]:.2f}*batches + {coef[2]:.0f}; residual std {resid.std():.0f} ticks; corr(end,batches) {np.corrcoef(wg_end, wg_batches)[0,1]:.2f} corr(end,items) {np.corrcoef(wg_end, wg_items)[0,1]:.2f}")
     print("   mean end per xcc: " + " ".join(f"{wg_end[wg_xcc == k].mean():.0f}" for k in range(8)) + " | mean batches per xcc: " + " ".join(f"{wg_batches[wg_xcc == k].mean():.0f}" for k in range(8)))
     order = np.argsort(wg_end)
