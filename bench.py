@@ -335,25 +335,49 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(system, x, cutoff, reps=5, slabs_per_rep=8, rows_per_slab=384):
-    """config 3: du/dx of NonbondedAllPairs on a sample of the i<j pair matrix (row-blocked dense evaluation == the reference's
-    JAX formulation): `slabs_per_rep` row slabs spread EVENLY over the triangle (rows near 0 see ~N columns, rows near N almost
-    none: one slab says little about the whole, eight evenly spaced ones see its average), scaled to the full matrix by pair
-    count.  The same sample is timed `reps` times (after three untimed passes over it); the median is reported, the spread is timing noise."""
+def _keep_host_heap():
+    """Every torch op of the CPU baseline allocates tens of MB of temporaries; glibc serves requests beyond its mmap threshold
+    with mmap / munmap -- a fresh, zero-filled mapping and its page faults per op, serialised on the process's mm lock with
+    every worker thread, a third of the CPU time of a pass and the noisiest part of it.  Raise the threshold to its maximum
+    (32 MB: the slabs are sized to stay below it) and keep freed memory in the heap: after the untimed passes the same
+    pages are reused."""
+    import ctypes
+
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        ok = libc.mallopt(-3, 1 << 25) and libc.mallopt(-1, (1 << 31) - 1) and libc.mallopt(-2, 1 << 28)  # M_MMAP_THRESHOLD, M_TRIM_THRESHOLD, M_TOP_PAD
+        return bool(ok)
+    except OSError:
+        return False
+
+
+def cpu_baseline(system, x, cutoff, reps=5, slabs_per_rep=None, rows_per_slab=64):
+    """config 3: du/dx of NonbondedAllPairs over the i<j pair matrix, row-blocked dense evaluation (== the reference's JAX
+    formulation) in slabs of `rows_per_slab` rows -- by default EVERY slab, i.e. one whole force evaluation per pass, nothing
+    extrapolated (`slabs_per_rep` = k: k slabs spread evenly over the triangle, scaled by pair count).  The pass is timed `reps`
+    times after two untimed ones (thread pool, heap, clocks); the median is reported, the spread is timing noise.
+    Slabs are sized so that (nearly) every temporary stays below glibc's largest mmap threshold (_keep_host_heap): with 384-row
+    slabs and the default threshold the same arithmetic read 26-32 s per evaluation instead of 3 -- more kernel time (mmap, page
+    faults, munmap per op) than user time, and a spread of 0.07-0.45.  Measured on a GPU box's host (16 threads, whole matrix,
+    scripts/cpu_baseline_only.py): 128-row slabs 2.6-2.8 s per evaluation, spread 0.06 (the [128, N, 3] difference tensor is
+    72 MB and still mapped per slab: 5-16 s of kernel time per run); 64-row slabs 2.9 s, spread 0.018 (1.5 s)."""
     import torch
 
     from oracle import ref_potentials as rp
 
     cores = _cpu_threads()
+    heap_kept = _keep_host_heap()
     N = system.num_atoms
     pt = torch.tensor(system.nb_params)
     bt = torch.tensor(system.box)
     pairs_full = N * (N - 1) // 2
-    spacing = (N - 1) // slabs_per_rep
-    starts = [k * spacing + spacing // 2 for k in range(slabs_per_rep)]  # the SAME slabs every repetition: the spread is timing noise only
+    if slabs_per_rep is None:
+        starts = list(range(0, N - 1, rows_per_slab))
+    else:
+        spacing = (N - 1) // slabs_per_rep
+        starts = [k * spacing + spacing // 2 for k in range(slabs_per_rep)]
     estimates, seconds = [], []
-    for rep in range(-3, reps):  # reps -3 .. -1: three untimed passes over the whole sample (thread pool, allocator, clocks: measured 61 / 51 /
-        # 40 s for three passes when only a single slab came first, and 48.9 / 47.5 / 44.4 -- still falling -- after one full pass)
+    for rep in range(-2, reps):  # the SAME slabs every pass: the spread is timing noise only
         xt = torch.tensor(x, requires_grad=True)
         el, pairs_sample = 0.0, 0
         for start in starts:
@@ -371,18 +395,20 @@ def cpu_baseline(system, x, cutoff, reps=5, slabs_per_rep=8, rows_per_slab=384):
             continue
         estimates.append(el * pairs_full / pairs_sample)
         seconds.append(el)
-    slabs = ["+".join(str(st) for st in starts)]
     t_step = float(np.median(estimates))
+    whole = pairs_sample == pairs_full
     return {
         "value": 86400.0 * DT * 1e-3 / t_step,
         "unit": "ns/day",
         "cores": cores,
         "cpu": _cpu_model(),
         "kind": "port",
-        "sample": f"config 3: du/dx of NonbondedAllPairs on {slabs_per_rep} slabs of {rows_per_slab} rows spread evenly over the i<j pair matrix (first rows "
-        f"{'; '.join(slabs)}), scaled to the full matrix by pair count, {reps} repetitions of the same sample ({sum(seconds):.1f} s of CPU work, median taken); "
-        f"torch f64 on {cores} threads; oracle restatement of the reference's dense JAX path, not JAX itself",
+        "sample": (f"config 3: du/dx of NonbondedAllPairs over the WHOLE i<j pair matrix in {len(starts)} slabs of {rows_per_slab} rows (one force evaluation per pass, nothing extrapolated)"
+                   if whole else f"config 3: du/dx of NonbondedAllPairs on {len(starts)} slabs of {rows_per_slab} rows spread evenly over the i<j pair matrix, scaled to the full matrix by pair count")
+        + f", {reps} timed passes after two untimed ones ({sum(seconds):.1f} s of CPU work, median taken); "
+        f"torch f64 on {cores} threads{', temporaries served from a kept heap (no mmap per op)' if heap_kept else ''}; oracle restatement of the reference's dense JAX path, not JAX itself",
         "estimates_s": [float(e) for e in estimates],
+        "seconds_per_force_eval": t_step,
         "seconds_per_force_eval_extrapolated": t_step,
         "repetitions": reps,
         "spread_rel": float((max(estimates) - min(estimates)) / t_step),
