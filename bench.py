@@ -35,8 +35,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  (HIP events on its launch stream) against the 8 TB/s HBM peak -- required form; the kernel is NOT
                  HBM-bound, so see roofline_valu for the roofline that actually binds it
   roofline_valu  algorithmic f64 flops per launch / duration against the 78.6 TFLOP/s FP64 vector peak
-  cpu_baseline   the oracle's torch-f64 restatement of the reference's JAX path timed on the host cores on a bounded
-                 sample of the same workload, 3 repetitions (rank 0, N == 1 only); cpu_baseline_configs: BASELINE
+  cpu_baseline   the oracle's torch-f64 restatement of the reference's JAX path timed on the host cores: one whole force
+                 evaluation of the same workload per pass, 5 timed passes (rank 0, N == 1 only); cpu_baseline_configs: BASELINE
                  configs 1 (500 BAOAB steps in each box) and 2 (u + du_dx + du_dp, 10 repetitions) the same way
 """
 import argparse
