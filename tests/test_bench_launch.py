@@ -70,3 +70,23 @@ def test_bench_hrex_mode_two_ranks():
     # resident replicas per rank: round-robin placement (parallel.windows_for_rank), every window exactly once
     assert [r["resident_replicas"] for r in out["per_rank"]] == [[0, 2, 4], [1, 3, 5]]
     assert out["value_per_gpu"] == pytest.approx(out["value"] / 2) and out["rccl_ranks"] is None
+
+
+def test_cpu_baseline_times_whole_force_evaluations():
+    """bench.py's config-3 CPU baseline (the oracle's dense restatement on the host cores): by default every row slab of the
+    pair matrix, i.e. one whole force evaluation per timed pass and nothing extrapolated; a slab sample is scaled by pair count.
+    Both must describe themselves, agree on what a pass covers, and keep the process's heap settings harmless."""
+    import numpy as np
+
+    import bench
+    from timemachine_amd import testsystems as ts
+
+    s = ts.build_water_box(300, 3.0)
+    whole = bench.cpu_baseline(s, s.coords, 1.2, reps=2)
+    assert whole["kind"] == "port" and whole["unit"] == "ns/day" and whole["cores"] >= 1
+    assert "WHOLE i<j pair matrix" in whole["sample"] and "nothing extrapolated" in whole["sample"]
+    assert len(whole["estimates_s"]) == 2 and all(e > 0 for e in whole["estimates_s"])
+    assert np.isclose(whole["value"], 86400.0 * bench.DT * 1e-3 / whole["seconds_per_force_eval"])
+    assert whole["spread_rel"] >= 0.0
+    sampled = bench.cpu_baseline(s, s.coords, 1.2, reps=1, slabs_per_rep=3, rows_per_slab=32)
+    assert "scaled to the full matrix by pair count" in sampled["sample"] and sampled["estimates_s"][0] > 0
