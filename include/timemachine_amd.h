@@ -271,6 +271,11 @@ int tm_debug_set_box_scaling_reuse(int enabled);
  * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.
  * Results are bit-identical either way. */
 int tm_debug_set_static_list_max_k(int max_atoms, int *previous);
+/* debugging / A-B aid: forces-only nonbonded launches over at least `min_atoms` atoms run the row-block kernel (one workgroup per
+ * row block and column range, lane-owned columns regrouped by hit count: csrc/kernels_nonbonded_rowblock.hip.hpp); smaller ones the
+ * wave-per-item kernel.  Process-wide; applies from the next call; 0 = always, INT_MAX = never; *previous (may be NULL) receives
+ * the old value.  Results are bit-identical either way (both replace k_nonbonded_unified, cpp/src/kernels/k_nonbonded.cuh:109-327). */
+int tm_debug_set_rowblock_min_k(int min_atoms, int *previous);
 /* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.hip.hpp):
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).
  * out: double[1536].  The analytic function it replaces: k_nonbonded_common.cuh:16-94 (real_es_factor / d). */

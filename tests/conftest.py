@@ -42,6 +42,23 @@ def any_binding(request):
     return load_binding(request.param)
 
 
+NEVER = 2**31 - 1  # (int: both debug knobs take a C int)
+# which list and which force kernel a Nonbonded potential runs on: (static complete list up to K atoms, row-block kernel from K atoms)
+NB_PATHS = {"static+items": (4608, NEVER), "listed+items": (0, NEVER), "listed+rowblocks": (0, 0)}
+
+
+@pytest.fixture(params=list(NB_PATHS))
+def nb_path(request, co):
+    """Small systems get a static complete list by default, large ones a built neighbor list; forces-only launches can run the
+    wave-per-item kernel (the product) or the row-block kernel (csrc/kernels_nonbonded_rowblock.hip.hpp, an independent second
+    implementation kept for A/B runs): the golden comparisons below run on every combination, whatever the size."""
+    static_k, rowblock_k = NB_PATHS[request.param]
+    before = co.debug_set_static_list_max_k(static_k), co.debug_set_rowblock_min_k(rowblock_k)
+    yield request.param
+    co.debug_set_static_list_max_k(before[0])
+    co.debug_set_rowblock_min_k(before[1])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -154,3 +154,27 @@ def test_array_arguments_convert_like_the_binding_layer(co):
         for bad in (lambda: co._u32([-1]), lambda: co._i32([2**40]), lambda: co._i32([0.5]), lambda: co._f64(np.array([1j]))):
             with pytest.raises(TypeError):
                 bad()
+
+
+def test_potential_lookup_helpers_behave_like_the_reference():
+    """timemachine/potentials/potential.py:82-116: get_bound_potential_by_type / get_potential_by_type return the FIRST match
+    (by isinstance, so subclasses count) and raise ValueError naming the type when there is none; md/minimizer.py,
+    md/barostat/moves.py, fe/free_energy.py and fe/absolute_hydration.py import them from timemachine.potentials."""
+    import numpy as np
+
+    from timemachine_amd import potentials as P
+
+    bond = P.HarmonicBond(np.array([[0, 1]], dtype=np.int32))
+    angle_a = P.HarmonicAngle(np.array([[0, 1, 2]], dtype=np.int32))
+    angle_b = P.HarmonicAngle(np.array([[2, 1, 0]], dtype=np.int32))
+    pots = [bond, angle_a, angle_b]
+    assert P.get_potential_by_type(pots, P.HarmonicAngle) is angle_a
+    assert P.get_potential_by_type(pots, P.Potential) is bond  # isinstance: the base class matches the first entry
+    with pytest.raises(ValueError, match="Unable to find potential of type"):
+        P.get_potential_by_type(pots, P.PeriodicTorsion)
+    bps = [bond.bind(np.zeros((1, 2))), angle_a.bind(np.zeros((1, 2))), angle_b.bind(np.ones((1, 2)))]
+    assert P.get_bound_potential_by_type(bps, P.HarmonicAngle) is bps[1]
+    with pytest.raises(ValueError, match="Unable to find potential of type"):
+        P.get_bound_potential_by_type(bps, P.Nonbonded)
+    with pytest.raises(ValueError):
+        P.get_bound_potential_by_type([], P.HarmonicBond)

@@ -332,7 +332,7 @@ def test_energy_overflows_with_summation_of_energies(co, P, precision):
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 @pytest.mark.parametrize("tag", ["vacuum", "pbc"])
-def test_config1_both_boxes(co, P, tag, precision):
+def test_config1_both_boxes(co, P, tag, precision, nb_path):
     """In the 100 nm box the Hilbert grid's bins are 0.79 nm wide (the whole cluster sits in a handful of bins) and every
     block bound is a sliver of the box: list build and tile kernel must not care."""
     from timemachine_amd import testsystems as ts

@@ -81,7 +81,7 @@ def compare_forces(impl, x, params, box, ref_u, ref_du_dx, ref_du_dp, precision)
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 @pytest.mark.parametrize("name", ["nb_small_w0", "nb_small_wrand", "nb_small_whalf"])
-def test_nonbonded_golden(co, P, name, precision):
+def test_nonbonded_golden(co, P, name, precision, nb_path):
     g = load(name + ".npz")
     beta, cutoff = float(g["beta"]), float(g["cutoff"])
     x, p, box = g["x"], g["params"], g["box"]
@@ -104,7 +104,7 @@ def test_nonbonded_golden(co, P, name, precision):
 
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 @pytest.mark.parametrize("lamb", ["0.0", "0.3", "1.0"])
-def test_config2_all_terms(co, P, lamb, precision):
+def test_config2_all_terms(co, P, lamb, precision, nb_path):
     """BASELINE config 2: ~2 300-atom solvated ligand, every term + du/dp vs the reference potentials."""
     from timemachine_amd import testsystems as ts
 
@@ -1182,46 +1182,69 @@ def test_dhfr_sized_box_properties(co, P):
     assert_equal_vectors(ref, du_dx[sample], 1e-8)
 
 
-def test_dhfr_shaped_box_all_terms(co, P):
+@pytest.mark.parametrize("precision,cutoff", [(np.float64, 1.2), (np.float32, 1.2), (np.float64, 1.0), (np.float32, 1.0)])
+def test_dhfr_shaped_box_all_terms(co, P, precision, cutoff):
     """The bench workload (testsystems.dhfr_shaped_box: 7 023 waters + a 2 490-atom solute with every bonded term kind and
     1-4 exclusions at partial scales), coordinates jittered by 0.004 nm so that every term pulls: the bonded terms against the
     oracle over the whole system, the Nonbonded force on 256 sampled atoms (half of them solute atoms, whose exclusions carry
     the partial scales) against the oracle's pair function with the reference's semantics -- all pairs minus scale x pair
-    (potentials/nonbonded.py:221-399) -- and the size-independent properties of test_dhfr_sized_box_properties."""
+    (potentials/nonbonded.py:221-399) -- and the size-independent properties of test_dhfr_sized_box_properties.
+    In both precisions and at both cutoffs the bench line quotes: rc 1.2 (BASELINE config 3) and rc 1.0 / f32, the reference's own
+    dhfr-apo configuration (testsystems/dhfr.py:21, tests/test_benchmark.py:219); f32 tolerance: 1e-4 of the force norm, the
+    reference's (tests/common.py:250-334).  The f32 kernels have their own workgroup shape and pool split at this size."""
     import torch
 
     from oracle import ref_potentials as rp
     from timemachine_amd import testsystems as ts
 
-    s = ts.dhfr_shaped_box()
+    s = ts.dhfr_shaped_box(cutoff=cutoff)
     N = s.num_atoms
-    assert N == 23559 and len(s.torsion_idxs) == 8610 and np.sum(s.scale_factors[:, 0] != 1.0) == 7020
+    assert N == 23559 and len(s.torsion_idxs) == 8610 and np.sum(s.scale_factors[:, 0] != 1.0) == 7020 and s.cutoff == cutoff
     rng = np.random.default_rng(11)
     x = s.coords + rng.normal(0.0, 0.004, s.coords.shape)
+    if precision == np.float32:
+        x = x.astype(np.float32).astype(np.float64)  # both sides see the coordinates the f32 kernels see
     p, box = s.nb_params, s.box
-    for cls, idxs, prm, ref_fn in (
-        (P.HarmonicBond, s.bond_idxs, s.bond_params, rp.harmonic_bond),
-        (P.HarmonicAngle, s.angle_idxs, s.angle_params, rp.harmonic_angle),
-        (P.PeriodicTorsion, s.torsion_idxs, s.torsion_params, rp.periodic_torsion),
-    ):
-        du_dx, du_dp, u = cls(idxs).to_gpu(np.float64).unbound_impl.execute(x, prm, box)
-        ref_u, ref_dx, ref_dp = ref_fn(x, prm, box, idxs)
-        assert abs(u - ref_u) <= 1e-8 * max(1.0, abs(ref_u)), cls.__name__
-        assert_equal_vectors(ref_dx, du_dx, 1e-7)
-        assert np.abs(du_dp - ref_dp).max() <= 1e-7 * max(1.0, np.abs(ref_dp).max()), cls.__name__
-        assert np.linalg.norm(ref_dx[s.num_water_atoms :], axis=1).max() > 100.0  # the solute's terms do pull
-    nb = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(np.float64).unbound_impl
+    f64 = precision == np.float64
+    if cutoff == 1.2:
+        for cls, idxs, prm, ref_fn in (
+            (P.HarmonicBond, s.bond_idxs, s.bond_params, rp.harmonic_bond),
+            (P.HarmonicAngle, s.angle_idxs, s.angle_params, rp.harmonic_angle),
+            (P.PeriodicTorsion, s.torsion_idxs, s.torsion_params, rp.periodic_torsion),
+        ):
+            du_dx, du_dp, u = cls(idxs).to_gpu(precision).unbound_impl.execute(x, prm, box)
+            ref_u, ref_dx, ref_dp = ref_fn(x, prm, box, idxs)
+            brt = 1e-7 if f64 else 1e-4
+            assert abs(u - ref_u) <= (0.1 * brt) * max(1.0, abs(ref_u)) if f64 else abs(u - ref_u) <= brt * max(1.0, abs(ref_u)), cls.__name__
+            if f64:
+                assert_equal_vectors(ref_dx, du_dx, brt)
+            else:
+                # f32: the absolute error of a stiff bond is k * eps_f32 * r ~ 4.6e5 * 6e-8 * 0.1 = 3e-3 kJ/mol/nm whatever the
+                # arithmetic, and among 23.5k atoms some have bonded forces that cancel to < 1 kJ/mol/nm (measured: 7.0e-3 absolute
+                # on an atom whose bond forces sum to 0.34): the error is taken relative to max(|F|, 100) -- the terms pull with
+                # ~1e3 on these strained coordinates
+                norms = np.maximum(np.linalg.norm(ref_dx, axis=1, keepdims=True), 100.0)
+                assert (np.abs(ref_dx - du_dx) / norms).max() <= brt, cls.__name__
+            assert np.abs(du_dp - ref_dp).max() <= brt * max(1.0, np.abs(ref_dp).max()), cls.__name__
+            assert np.linalg.norm(ref_dx[s.num_water_atoms :], axis=1).max() > 100.0  # the solute's terms do pull
+    nb = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(precision).unbound_impl
     a = nb.execute_raw(x, p, box)
     b = nb.execute_raw(x, p, box)
     np.testing.assert_array_equal(a[0], b[0])
     assert a[2] == b[2]
     with np.errstate(over="ignore"):
         assert np.all(a[0].sum(axis=0, dtype=np.uint64) == 0)  # Newton's third law, exactly
-    c = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, disable_hilbert_sort=True).to_gpu(np.float64).unbound_impl.execute_raw(x, p, box)
+    c = P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff, disable_hilbert_sort=True).to_gpu(precision).unbound_impl.execute_raw(x, p, box)
     np.testing.assert_array_equal(a[0], c[0])
     assert a[2] == c[2]
-    # forces-only (the MD form: table-driven electrostatics) gives the same bits as the full call
-    np.testing.assert_array_equal(nb.execute_raw(x, p, box, True, False, False)[0], a[0])
+    # forces-only (the MD form; f64: table-driven electrostatics) gives the same bits as the full call -- on the wave-per-item
+    # kernel (the product) and on the row-block kernel (the second implementation of the same contract)
+    for rowblock_min_k in (2**31 - 1, 0):
+        before = co.debug_set_rowblock_min_k(rowblock_min_k)
+        try:
+            np.testing.assert_array_equal(nb.execute_raw(x, p, box, True, False, False)[0], a[0])
+        finally:
+            co.debug_set_rowblock_min_k(before)
 
     sample = np.sort(np.concatenate([rng.choice(s.num_water_atoms, 128, replace=False), s.num_water_atoms + rng.choice(N - s.num_water_atoms, 128, replace=False)]))
     row_of = {int(i): r for r, i in enumerate(sample)}
@@ -1247,4 +1270,4 @@ def test_dhfr_shaped_box_all_terms(co, P):
         lj, es = rp._pair_energies(torch.sqrt(d2), pt[idx, 0][:, None] * pt[None, :, 0], pt[idx, 1][:, None] + pt[None, :, 1], pt[idx, 2][:, None] * pt[None, :, 2], s.beta, s.cutoff)
         total = (lj * torch.tensor(keep_lj[k0 : k0 + 64])).sum() + (es * torch.tensor(keep_q[k0 : k0 + 64])).sum()
         ref[k0 : k0 + 64] = torch.autograd.grad(total, xi)[0].numpy()
-    assert_equal_vectors(ref, du_dx[sample], 1e-8)
+    assert_equal_vectors(ref, du_dx[sample], 1e-8 if f64 else 1e-4)

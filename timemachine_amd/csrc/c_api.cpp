@@ -4,6 +4,7 @@
 #include "engine.hpp"
 #include "profiler.hpp"
 
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -39,7 +40,15 @@ struct tm_hilbert_sort_s {
 
 static thread_local std::string g_last_error;
 
-#define TM_TRY try {
+// Threading contract of the C ABI: every entry point runs under ONE process-wide lock.  The objects behind the handles keep
+// host-side state between calls (pre-gathered inputs, piggy-backed tables, launch parities, uploaded plans) and the reference
+// never runs two of these calls at once either -- its pybind11 layer holds the GIL through every one of them.  The compiled
+// binding here releases the GIL around device calls (a Python thread doing I/O keeps running); this lock is what keeps two
+// Python threads from entering the same Potential / Context meanwhile.  Recursive: entry points call each other.
+static std::recursive_mutex g_api_mutex;
+#define TM_TRY                                                                                                         \
+    std::lock_guard<std::recursive_mutex> tm_api_lock_(g_api_mutex);                                                   \
+    try {
 #define TM_CATCH                                                                                                       \
     }                                                                                                                  \
     catch (const InvalidHardware &e) {                                                                                 \
@@ -845,6 +854,14 @@ int tm_debug_set_static_list_max_k(int max_atoms, int *previous) {
         *previous = g_static_list_max_k;
     }
     g_static_list_max_k = max_atoms;
+    TM_CATCH
+}
+int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_rowblock_min_k;
+    }
+    g_rowblock_min_k = min_atoms;
     TM_CATCH
 }
 int tm_profile_set_enabled(int enabled) {

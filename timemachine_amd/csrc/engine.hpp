@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "nb_es_table.hip.hpp"
 
+#include <algorithm>
 #include <limits>
 #include <memory>
 #include <optional>
@@ -153,15 +154,15 @@ public:
     // exclusions -- and costs a lone wave 1-2 us where they do not (water: 2 bonds, 1 angle, 2 exclusions per atom).
     int max_atom_incidence() const { return max_atom_incidence_; }
     void note_term_atoms(const std::vector<int> &idxs) {
-        int hi = -1;
-        for (const int a : idxs) {
-            hi = a > hi ? a : hi;
-        }
-        std::vector<int> count(static_cast<size_t>(hi + 1), 0);
-        int most = 0;
-        for (const int a : idxs) {
-            if (a >= 0) {
-                most = ++count[a] > most ? count[a] : most;
+        // counted on a sorted copy: nothing here is sized by the caller's indices (constructors call this before or after
+        // their range checks; a garbage index must cost nothing but its own entry)
+        std::vector<int> sorted(idxs);
+        std::sort(sorted.begin(), sorted.end());
+        int most = 0, run = 0;
+        for (size_t i = 0; i < sorted.size(); i++) {
+            run = (i > 0 && sorted[i] == sorted[i - 1]) ? run + 1 : 1;
+            if (sorted[i] >= 0 && run > most) {
+                most = run;
             }
         }
         max_atom_incidence_ = most;
@@ -196,6 +197,9 @@ public:
     // Offer of a ForcePlan table to run inside this potential's NEXT energy-only partial-sum evaluation (execute_energy_partials):
     // the table's energies then arrive in that call's partial sums.  true = accepted (the plan skips its own energy launch).
     virtual bool piggyback_energy(const FusedTable *d_table, const int blocks, const int precision_bytes) { return false; }
+    // forget a table accepted through piggyback_forces / piggyback_energy that the plan can no longer deliver a call for (an
+    // exception between the offer and the call): without this the next call of any other form would refuse to run
+    virtual void drop_piggybacks() {}
     // Energy-only evaluation that leaves per-wave partial sums (to be added up by the caller) in a buffer of the potential's
     // own instead of reducing them into a d_u -- saves a launch per evaluation.  false = not supported (nothing was run).
     virtual bool execute_energy_partials(
@@ -484,6 +488,7 @@ public:
     const int4 *d_items() const { return d_items_.data; }
     unsigned int items_cap() const { return static_cast<unsigned int>(items_cap_); }
     const unsigned int *d_col_atoms() const { return d_col_atoms_.data; }
+    const int2 *d_row_segments() const { return d_row_segments_.data; } // per row block {start in d_col_atoms, listed columns}
 
 private:
     const int max_size_;
@@ -502,6 +507,7 @@ private:
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
+extern int g_rowblock_min_k;     // forces-only launches over at least this many atoms run the row-block kernel (tm_debug_set_rowblock_min_k)
 extern int g_static_list_max_k;  // potentials over at most this many atoms keep a static, complete list (tm_debug_set_static_list_max_k)
 
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
@@ -532,6 +538,12 @@ public:
     bool piggyback_forces(const FusedTable *d_table, const int blocks, const int precision_bytes, u64 *acc, const int atom_stride, const int comp_stride) override;
     bool piggyback_lands_in_own_accumulator() const override;
     bool piggyback_energy(const FusedTable *d_table, const int blocks, const int precision_bytes) override;
+    void drop_piggybacks() override {
+        piggyback_table_ = nullptr;
+        piggyback_blocks_ = 0;
+        piggyback_energy_table_ = nullptr;
+        piggyback_energy_blocks_ = 0;
+    }
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
@@ -605,7 +617,13 @@ protected:
     // up, and no list kernel is launched on MD steps at all -- at this size a step is three kernel launches' worth of latency,
     // not work, and the launch that only reads the flag is one of them.  The phase-2 test `d2 < cutoff^2` decides alone, as
     // always: same bits.  nblist_padding_ stays what the caller asked for (get_nblist_padding); this is what the list is built with.
-    bool static_list() const { return K_ <= static_list_max_k() && group_rows_ == 0; }
+    // (latched per potential by run_pipeline when the limit or the atom set changed -- the switch forces a rebuild --, so that the
+    // rebuild threshold, the padding and the list that exists always belong to the same mode: tm_debug_set_static_list_max_k
+    // may be called at any time)
+    bool static_list() const { return static_mode_; }
+    bool wants_static_list() const { return K_ <= static_list_max_k() && group_rows_ == 0; }
+    bool static_mode_ = false;
+    void sync_list_mode();
     double list_padding() const { return static_list() ? 1.0e3 : nblist_padding_; }
     static int static_list_max_k();
     bool static_list_built_ = false; // the complete list of the current order exists

@@ -1,6 +1,7 @@
 // ForcePlan: all bonded terms and pair lists of a step in one kernel launch per precision (see engine.hpp).
 // The per-term device functions are the ones the stand-alone kernels call (kernels_bonded.hip.hpp, kernels_nonbonded.hip.hpp),
 // so a fused launch produces the same bits as separate launches.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -120,18 +121,26 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
     d_e_slots_.reserve(std::max(n_rest, 1));
     int n_slots = 0;
     bool slots_zeroed = false;
-    // 0. a potential whose own energy launch is long (the nonbonded tile kernel) may take a table of its precision along
+    // 0. a potential whose own energy launch is long (the nonbonded tile kernel) may take a table of its precision along.
+    // A carrier MUST be evaluated through execute_energy_partials in step 2, so its source slot is reserved here: room is kept
+    // for both tables (step 1), the carriers accepted so far and the slot array (at the end).
+    std::vector<Potential *> carriers;
     for (const Rest &r : rest_) {
         bool shared = false;
         for (const Rest &q : rest_) {
             shared = shared || (&q != &r && q.pot == r.pot);
         }
-        for (int prec = 0; prec < 2 && !shared && src.n < ENERGY_MAX_SOURCES - 1; prec++) {
+        for (int prec = 0; prec < 2 && !shared && 2 + static_cast<int>(carriers.size()) + 1 < ENERGY_MAX_SOURCES - 1; prec++) {
             if (pending[prec] && r.pot->piggyback_energy(d_table_[prec].data, host_[prec].block_end[host_[prec].n - 1], prec ? 8 : 4)) {
                 pending[prec] = false;
+                if (std::find(carriers.begin(), carriers.end(), r.pot) == carriers.end()) {
+                    carriers.push_back(r.pot);
+                }
             }
         }
     }
+    int carriers_left = static_cast<int>(carriers.size());
+    try {
     // 1. the tables nobody took: one launch per precision, per-wave partial sums
     for (int prec = 0; prec < 2; prec++) {
         if (!pending[prec]) {
@@ -160,7 +169,13 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
         }
         const i128 *partials = nullptr;
         int count = 0;
-        if (!shared && src.n < ENERGY_MAX_SOURCES - 1 && r.pot->execute_energy_partials(N, r.P, d_x, r.d_p, d_box, stream, partials, count)) {
+        const bool carrier = std::find(carriers.begin(), carriers.end(), r.pot) != carriers.end();
+        // (a carrier's slot was reserved in step 0; anybody else leaves the carriers still to come their room)
+        const bool room = carrier || src.n + carriers_left < ENERGY_MAX_SOURCES - 1;
+        if (carrier) {
+            carriers_left--;
+        }
+        if (!shared && room && r.pot->execute_energy_partials(N, r.P, d_x, r.d_p, d_box, stream, partials, count)) {
             if (count > 0) {
                 src.p[src.n] = partials;
                 src.count[src.n] = count;
@@ -183,6 +198,12 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
     // 3. one reduction over everything
     k_reduce_i128_sources<<<1, 256, 0, stream>>>(src, d_u);
     HIP_CHECK(hipGetLastError());
+    } catch (...) {
+        for (Potential *c : carriers) { // a table offered above may never have met its call
+            c->drop_piggybacks();
+        }
+        throw;
+    }
 }
 
 bool ForcePlan::run(
@@ -209,6 +230,7 @@ bool ForcePlan::run(
         }
     }
     // 3. the potentials that launch their own kernels
+    try {
     for (const Rest &r : rest_) {
         DeferredForces df;
         // a potential bound more than once is never deferred: its other call would zero and reuse the accumulator this
@@ -224,6 +246,12 @@ bool ForcePlan::run(
             r.pot->execute_device(N, r.P, d_x, r.d_p, d_box, d_du_dx, nullptr, nullptr, stream);
             wrote_du_dx = true;
         }
+    }
+    } catch (...) {
+        for (const Rest &r : rest_) { // a table offered in step 2 may never have met its call
+            r.pot->drop_piggybacks();
+        }
+        throw;
     }
     // 4. tables nobody took
     for (int prec = 0; prec < 2; prec++) {

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "kernels_nblist.hip.hpp"
+#include "kernels_nonbonded_rowblock.hip.hpp"
 #include "profiler.hpp"
 
 #include <rocprim/rocprim.hpp>
@@ -595,6 +596,17 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
 #endif
 int g_static_list_max_k = std::getenv("TM_AMD_STATIC_LIST_MAX_K") ? std::atoi(std::getenv("TM_AMD_STATIC_LIST_MAX_K")) : TM_STATIC_LIST_MAX_K;
 template <typename Real> int NonbondedAllPairs<Real>::static_list_max_k() { return g_static_list_max_k; }
+// Forces-only launches over at least this many atoms run the row-block kernel (kernels_nonbonded_rowblock.hip.hpp: one workgroup
+// per (row block, <= 1024 listed columns), lane-owned columns regrouped by hit count).  OFF by default (INT_MAX): round 4 built it as
+// the re-decomposition of the tile kernel, it passes the whole GPU suite bit for bit, and it measures 74 us per launch against the
+// item kernel's 55 on the DHFR-shaped box (EXPERIMENTS.md, "row-block kernel": the pair loop of BOTH kernels runs at ~65 % of its
+// VALU bound, the row-block form's trips are 77 % occupied against the queue's 95 %, and its barrier phases and 2.4 units per
+// workgroup cost what its cheaper filter saves).  Kept selectable for A/B runs and as the second, independent implementation the
+// parity tests compare bit for bit.
+#ifndef TM_ROWBLOCK_MIN_K
+#define TM_ROWBLOCK_MIN_K 2147483647
+#endif
+int g_rowblock_min_k = std::getenv("TM_AMD_ROWBLOCK_MIN_K") ? std::atoi(std::getenv("TM_AMD_ROWBLOCK_MIN_K")) : TM_ROWBLOCK_MIN_K;
 
 template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::vector<int> &atom_idxs) {
     verify_atom_idxs(N_, atom_idxs);
@@ -651,6 +663,16 @@ template <typename Real> std::vector<int> NonbondedAllPairs<Real>::get_atom_idxs
     return std::vector<int>(u.begin(), u.end());
 }
 
+// the static-list limit (a process-wide debug knob) or the atom set changed: switch modes with a fresh list, before any caller
+// decides whether pre-gathered state may be used
+template <typename Real> void NonbondedAllPairs<Real>::sync_list_mode() {
+    if (wants_static_list() != static_mode_) {
+        static_mode_ = wants_static_list();
+        static_list_built_ = false;
+        force_rebuild_ = true;
+    }
+}
+
 template <typename Real>
 bool NonbondedAllPairs<Real>::execute_forces_deferred(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
@@ -659,6 +681,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     if (empty_) {
         return false; // nothing to hand over; the caller falls back to execute_device (a no-op)
     }
+    sync_list_mode();
     // positions pre-gathered by the consumer of the previous deferred call are usable iff they were made from exactly
     // these inputs and the order they were written in still stands (no re-sort, no forced rebuild on this call)
     const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
@@ -704,6 +727,7 @@ void NonbondedAllPairs<Real>::execute_device(
     if (empty_) {
         return; // reference: nonbonded_interaction_group.cu:171-174 (outputs untouched, d_u left as the caller set it)
     }
+    sync_list_mode();
     // An energy-only call on exactly the inputs the last MD step left pre-gathered (the barostat's "before" energy,
     // a frame's energy right after multiple_steps) reads the sorted records as they are: no gather, no bounds kernel, and
     // above all no forced list rebuild -- the update kernel has already made the displacement test for these coordinates.
@@ -723,6 +747,7 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
         count = 0;
         return true;
     }
+    sync_list_mode();
     const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
                              calls_since_sort_ % steps_per_sort_ != 0;
     defer_u_reduce_ = true;
@@ -755,6 +780,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
     const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, const bool scatter_du_dx,
     hipStream_t stream, const bool pregathered) {
     const int tpb = DEFAULT_TPB;
+    sync_list_mode();
     pre_valid_ = false; // consumed by this call or stale after it
     // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker
     // does that whenever it raises the rebuild flag, and the host cannot know): the list has to be rebuilt whatever the
@@ -868,7 +894,22 @@ void NonbondedAllPairs<Real>::run_pipeline(
         // MD: the f64 kernel has a form for cutoffs that do not reach beyond the end of the electrostatic switch (all of the
         // reference's callers: cutoff == 1.2 nm); see INSIDE_SWITCH.
         const bool inside = sizeof(Real) == 8 && cutoff_ <= TM_ES_SWITCH_D;
-        if (inside) {
+        if (K_ >= g_rowblock_min_k && nblist_.num_row_blocks() <= RB_MAX_ROW_BLOCKS) {
+            // large systems: one workgroup per (row block, column range) unit, see kernels_nonbonded_rowblock.hip.hpp
+#define TM_LAUNCH_ROWBLOCKS(INSIDE)                                                                                    \
+    k_nonbonded_rowblocks<Real, INSIDE><<<n_cus * RB_WGS_PER_CU, RB_THREADS, 0, stream>>>(                             \
+        K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(), nblist_.num_row_blocks(), \
+        nblist_.d_row_segments(), nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, acc_stride_, \
+        pig_table, pig_blocks, d_x, pig_acc, pig_atom_stride, pig_comp_stride, pig_remap, d_timing_.data)
+            if (inside) {
+                if constexpr (sizeof(Real) == 8) {
+                    TM_LAUNCH_ROWBLOCKS(true);
+                }
+            } else {
+                TM_LAUNCH_ROWBLOCKS(false);
+            }
+#undef TM_LAUNCH_ROWBLOCKS
+        } else if (inside) {
             if constexpr (sizeof(Real) == 8) {
                 if (split == 4) {
                     TM_LAUNCH_TILES(false, true, false, true, 4);

@@ -1127,6 +1127,14 @@ void declare_functions(py::module &m) {
             return previous;
         },
         py::arg("max_atoms"));
+    m.def(
+        "debug_set_rowblock_min_k",
+        [](const int min_atoms) { // A/B aid: forces-only launches over >= min_atoms atoms run the row-block kernel; -> the old value
+            int previous = 0;
+            check(tm_debug_set_rowblock_min_k(min_atoms, &previous));
+            return previous;
+        },
+        py::arg("min_atoms"));
     m.def("debug_check_guards", []() { // -DTM_GUARD builds: violated guard zones so far; -1 in product builds
         int n = 0;
         check(tm_debug_check_guards(&n));

@@ -1051,6 +1051,14 @@ def debug_set_static_list_max_k(max_atoms):
     return prev.value
 
 
+def debug_set_rowblock_min_k(min_atoms):
+    """A/B aid: forces-only nonbonded launches over at least `min_atoms` atoms run the row-block kernel (0: always); -> the old
+    value.  Results are bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_rowblock_min_k(_c_int(int(min_atoms)), ctypes.byref(prev)))
+    return prev.value
+
+
 def profile_set_enabled(enabled):
     _check(_lib.tm_profile_set_enabled(_c_int(1 if enabled else 0)))
 

@@ -87,3 +87,24 @@ class BoundGpuImplWrapper:
     def __call__(self, conf: NDArray, box: NDArray) -> float:
         _, u = self.bound_impl.execute(conf, box, False, True)
         return u
+
+
+def _first_of_type(items, kind, of=lambda item: item):
+    hits = (item for item in items if isinstance(of(item), kind))
+    try:
+        return next(hits)
+    except StopIteration:
+        raise ValueError(f"Unable to find potential of type: {kind}") from None
+
+
+def get_bound_potential_by_type(bps, pot_type):
+    """The first bound potential of `bps` whose potential is a `pot_type`; ValueError when there is none.
+    reference: timemachine/potentials/potential.py:82-98 (callers: md/minimizer.py, md/enhanced.py, md/barostat/moves.py,
+    fe/free_energy.py, fe/absolute_hydration.py)."""
+    return _first_of_type(bps, pot_type, of=lambda bp: bp.potential)
+
+
+def get_potential_by_type(pots, pot_type):
+    """The first potential of `pots` that is a `pot_type`; ValueError when there is none.
+    reference: timemachine/potentials/potential.py:101-116."""
+    return _first_of_type(pots, pot_type)
