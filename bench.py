@@ -73,6 +73,9 @@ CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; used only to turn a k
 METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
 
+PINNED_CPUS = None  # set by main(): the CPUs this rank was given (pin_rank_to_cpus)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +319,26 @@ def _cpu_quota():
     return n
 
 
+def pin_rank_to_cpus(local_rank, local_world):
+    """One process per GPU shares the host: give each rank its own slice of the CPUs this job may use, so that eight ranks' launch
+    threads (three launches per ~70 us step each) and their HIP runtime helper threads do not migrate over each other.  The slice
+    is cut from the scheduler affinity (the cgroup's cpu.max quota limits CPU TIME, not which CPUs: it is reported in the bench
+    line as cpu_quota).  Returns the CPUs of this rank."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        return None
+    if local_world <= 1 or len(cpus) < 2 * local_world:
+        return cpus
+    per = len(cpus) // local_world
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:  # pragma: no cover
+        return cpus
+    return mine
+
+
 def _cpu_threads(limit=64):
     import torch
 
@@ -546,6 +569,7 @@ def run_md(args, rank, local_rank, world, backend):
         N, system = 23559, None
 
     rank_ms_per_step = []  # one entry per run() call; [0] is the headline run
+    rank_cpu_us_per_step = []  # process CPU time of the timed multiple_steps call / steps, same indexing
 
     def run(prec, steps, warmup, profile_steps, barostat_interval=0, cutoff=None):
         if args.stub:
@@ -566,9 +590,11 @@ def run_md(args, rank, local_rank, world, backend):
         parallel.barrier()
         device_sync(co)
         t0 = time.perf_counter()
+        c0 = time.process_time()  # user + system CPU time of this process, all threads (the HIP runtime's included)
         ctxt.multiple_steps(steps, 0)
         dev_s = 1e-3 * ctxt.last_multiple_steps_ms()
         device_sync(co)
+        rank_cpu_us_per_step.append(1e6 * (time.process_time() - c0) / steps)
         parallel.barrier()
         host_s = time.perf_counter() - t0
         rank_ms_per_step.append(1e3 * dev_s / steps)  # this rank's own clock, before the max over ranks
@@ -583,6 +609,7 @@ def run_md(args, rank, local_rank, world, backend):
             co.profile_set_enabled(True)
             ctxt.multiple_steps(profile_steps, 0)
             total_ms, launches = co.profile_read("nonbonded_tiles")
+            per_kernel = {name: co.profile_read(name) for name in ("nonbonded_tiles", "nblist_build", "integrator_update")}
             co.profile_set_enabled(False)
             co.profile_reset()
             tiles = nb.get_tile_ixn_count()
@@ -592,7 +619,8 @@ def run_md(args, rank, local_rank, world, backend):
                 ctxt.multiple_steps(1, 0)
                 tiles = nb.get_tile_ixn_count()
             prof = {"kernel_ms": total_ms / max(launches, 1), "launches": launches, "tiles": tiles,
-                    "run_ms": ctxt.last_multiple_steps_ms(), "steps": profile_steps, "builds": nb.get_build_count() - builds0}
+                    "run_ms": ctxt.last_multiple_steps_ms(), "steps": profile_steps, "builds": nb.get_build_count() - builds0,
+                    "per_kernel": per_kernel, "listed_atoms": nb.get_tile_ixn_count() * 32}
         return dev_s, host_s, xf, bps, prof
 
     dev_s, host_s, xf, bps, prof = run(None if args.stub else precision, args.steps, args.warmup, args.profile_steps if rank == 0 else 0)
@@ -617,6 +645,7 @@ def run_md(args, rank, local_rank, world, backend):
     # who ran what, so that an N > 1 record explains itself: every rank's own ms per step, device and bus id
     per_rank = parallel.gather_objects({
         "rank": rank, "local_rank": local_rank, "ms_per_step": rank_ms_per_step[0], "windows": my_windows,
+        "host_cpu_us_per_step": rank_cpu_us_per_step[0], "cpus": len(PINNED_CPUS) if PINNED_CPUS else None,
         "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
     })
 
@@ -650,6 +679,12 @@ def run_md(args, rank, local_rank, world, backend):
         },
         "timing": f"HIP events on the Context stream around the {args.steps} timed steps (max over ranks), after {SETTLE_STEPS} settle + {args.warmup} warm-up steps",
         "host_ms_per_step": 1e3 * host_s / args.steps,
+        # what the host spends to drive one step (process CPU time of the timed multiple_steps call / steps: the launch thread and the
+        # HIP runtime's helpers), the CPUs the job may use (scheduler affinity cut to the cgroup quota) and what N ranks of this kind
+        # ask of them: host_cpu_load = n_gpus * host_cpu_us_per_step / (1e3 * ms_per_step) CPUs busy, to be held against cpu_quota
+        "host_cpu_us_per_step": max(r["host_cpu_us_per_step"] for r in per_rank),
+        "cpu_quota": _cpu_quota(),
+        "host_cpu_load": sum(r["host_cpu_us_per_step"] for r in per_rank) / (1e3 * (1e3 * dev_s / args.steps)),
         "host_ns_day": args.steps / host_s * 86400.0 * DT * 1e-3 * world,
         "world_size": world,
         "backend": backend,
@@ -693,6 +728,47 @@ def run_md(args, rank, local_rank, world, backend):
             "launches_timed": prof["launches"],
             "note": "required HBM form; this kernel is VALU-bound, not HBM-bound (SURVEY.md F10) -- see roofline_valu",
         }
+        # the whole step, kernel by kernel (per-launch HIP events of the profiled steps: each bracket includes ~1-3 us of dispatch,
+        # so the small kernels read larger here than in rocprofv3's kernel trace, profiles/r04_*_per_step_*.txt)
+        steps_p = max(prof["steps"], 1)
+        real = 8 if args.precision == "f64" else 4
+        builds = max(prof["builds"], 1)
+        alg_bytes = {
+            # per launch: one gathered record read + one u64 x 3 accumulator RMW per atom; 4 B id + 128 B column indices per tile
+            "nonbonded_tiles": bytes_alg,
+            # per REBUILD (amortised below): x y z of every atom once per row block that lists it is L2 traffic; from HBM: the
+            # records once (3 * sizeof(Real) * N), block bounds (2 x 3 x sizeof(Real) per 32 atoms), 4 B per listed column atom
+            # written, 16 B per 64-column work item, the snapshot copy (48 B per atom)
+            "nblist_build": (3 * real + 48) * N + 6 * real * (N // 32 + 1) + 4 * prof["listed_atoms"] + 16 * (prof["listed_atoms"] // 64 + 1),
+            # per launch (sorted hand-over form): read perm 4, x v (slot order) 48, cb cc 8, sorted accumulator 24, snapshot 24;
+            # write x v twice (atom order + slot order) 96, the sorted record's x y z 3 * sizeof(Real), the accumulator's zeros 24
+            "integrator_update": (4 + 48 + 8 + 24 + 24 + 96 + 3 * real + 24) * N,
+        }
+        out["kernels"] = []
+        for name, (ms_k, n_k) in prof["per_kernel"].items():
+            if not n_k:
+                continue
+            us_per_step = 1e3 * ms_k / steps_p
+            b = alg_bytes[name] * (builds if name == "nblist_build" else n_k) / steps_p  # algorithmic bytes per STEP
+            out["kernels"].append({
+                "name": name, "us_per_step": us_per_step, "launches_per_step": n_k / steps_p, "us_per_launch": 1e3 * ms_k / n_k,
+                "algorithmic_bytes_per_step": b, "frac_of_hbm_peak": b / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "share_of_step": us_per_step / (1e6 * dev_s / args.steps),  # of the TIMED step (the brackets' dispatch latency makes the shares sum to ~1.1)
+            })
+        out["kernels_note"] = ("per-launch HIP events on the Context stream over the profiled steps; nblist_build = every launch of the list kernels "
+                               "(rebuilds, amortised, and the launches that only read the rebuild flag); frac_of_hbm_peak uses the algorithmic bytes "
+                               "spelt out in bench.py (alg_bytes) -- none of these kernels is HBM-bound: the tile kernel is bound by VALU issue "
+                               "(roofline_valu), the other two by launch and dependent-load latency")
+        # the committed PMC summary belongs to ONE build of the library: say so when this run's library is another
+        stamp = None
+        try:
+            with open(os.path.join(REPO, "timemachine_amd", "csrc", ".build_stamp")) as fh:
+                stamp = fh.read().strip()
+        except OSError:
+            pass
+        out["roofline"]["traffic_build_stamp"] = pmc.get("build_stamp")
+        out["roofline"]["library_build_stamp"] = stamp
+        out["roofline"]["traffic_stale"] = bool(pmc.get("build_stamp")) and pmc.get("build_stamp") != stamp if stamp else None
         out["roofline_valu"] = {
             "bound": "valu_" + args.precision,
             "kernel": "k_nonbonded_tiles",
@@ -913,6 +989,8 @@ def main(argv=None):
     maybe_self_launch(args)
     protect_stdout()
     rank, local_rank, world, backend = init_distributed(args)
+    global PINNED_CPUS
+    PINNED_CPUS = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     try:
         if args.mode == "hrex":
             run_hrex(args, rank, local_rank, world, backend)

@@ -51,7 +51,10 @@ if 'FETCH_SIZE' in traffic and 'WRITE_SIZE' in traffic:
     rec = {"bytes": b, "fetch_kb_raw": traffic['FETCH_SIZE'], "write_kb_raw": traffic['WRITE_SIZE'],
            "correction": "2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)", "source": "profiles/pmc_md_%s.txt" % sys.argv[2],
            # per-dispatch averages of the SQ passes of the same command (instruction counts; cycle counters in quad-cycles)
-           "sq": {k: v for k, v in traffic.items() if k.startswith('SQ_') or k.startswith('GRBM')}}
+           "sq": {k: v for k, v in traffic.items() if k.startswith('SQ_') or k.startswith('GRBM')},
+           # which build of the library these counters belong to (csrc/.build_stamp: hash of sources + flags); bench.py prints
+           # traffic_stale: true when it times another build
+           "build_stamp": open('timemachine_amd/csrc/.build_stamp').read().strip()}
     json.dump({sys.argv[2]: rec}, open(sys.argv[1] + '/pmc_traffic.json', 'w'))
     print('traffic bytes per launch', b)
 PY

@@ -90,3 +90,42 @@ def test_cpu_baseline_times_whole_force_evaluations():
     assert whole["spread_rel"] >= 0.0
     sampled = bench.cpu_baseline(s, s.coords, 1.2, reps=1, slabs_per_rep=3, rows_per_slab=32)
     assert "scaled to the full matrix by pair count" in sampled["sample"] and sampled["estimates_s"][0] > 0
+
+
+def test_bench_eight_ranks_on_a_small_cpu_set():
+    """The driver's largest job: `--gpus 8` = eight ranks on one host.  Its launch / barrier / max-over-ranks / gather path at the
+    REAL rank count, with the whole job confined to as few CPUs as the GPU boxes' cgroup grants in the worst case seen (this
+    machine's share, at most 16): every rank pins itself to its own slice of the allowed CPUs (bench.pin_rank_to_cpus) and reports
+    what it spends per step, so that an N = 8 record shows whether the host could have been the limit."""
+    allowed = sorted(os.sched_getaffinity(0))[:16]
+    prefix = ["taskset", "-c", ",".join(str(c) for c in allowed)] if len(allowed) >= 8 else []
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        e.pop(k, None)
+    r = subprocess.run(prefix + [sys.executable, os.path.join(REPO, "bench.py"), "--stub", "--gpus", "8", "--steps", "40", "--warmup", "10"],
+                       capture_output=True, text=True, timeout=600, env=e, cwd=REPO)
+    out = _line(r)
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["backend"] == "gloo" and out["config"]["replicas"] == 8
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and [p["windows"] for p in out["per_rank"]] == [[k] for k in range(8)]
+    assert out["mbar_gather_ok"] is True
+    assert out["value_per_gpu"] == pytest.approx(out["value"] / 8)
+    # host-side cost of a step, per rank and for the job, against what the job may use
+    assert out["cpu_quota"] >= 1 and out["host_cpu_us_per_step"] > 0 and out["host_cpu_load"] > 0
+    for p in out["per_rank"]:
+        assert p["host_cpu_us_per_step"] > 0
+        if prefix and len(allowed) >= 16:
+            assert p["cpus"] == len(allowed) // 8  # each rank has its own slice
+
+
+def test_pin_rank_to_cpus_slices_the_allowed_set():
+    import bench
+
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        if len(before) >= 4:
+            mine = bench.pin_rank_to_cpus(1, 2)
+            assert mine == before[len(before) // 2:2 * (len(before) // 2)] and sorted(os.sched_getaffinity(0)) == mine
+            os.sched_setaffinity(0, before)
+        assert bench.pin_rank_to_cpus(0, 1) == before  # a single rank keeps everything
+    finally:
+        os.sched_setaffinity(0, before)

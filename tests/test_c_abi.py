@@ -164,6 +164,18 @@ def test_committed_bench_lines_follow_the_contract():
     assert c["kind"] in ("reference", "port")
     # value == steps / time: ns/day from ms per step at 2.5 fs
     assert abs(d["value"] - d["n_gpus"] * 86400.0 * 2.5e-6 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    if os.path.basename(paths[-1]) >= "r04":  # (round 4 on) the line tracks the whole step and what the host spends on it
+        names = {k["name"] for k in d["kernels"]}
+        assert {"nonbonded_tiles", "nblist_build", "integrator_update"} <= names
+        for k in d["kernels"]:
+            for key in ("us_per_step", "launches_per_step", "us_per_launch", "algorithmic_bytes_per_step", "frac_of_hbm_peak", "share_of_step"):
+                assert key in k and k[key] >= 0, (k["name"], key)
+        # three kernels make the step: together they account for (nearly) all of it
+        assert 0.9 < sum(k["share_of_step"] for k in d["kernels"]) < 1.3
+        for key in ("host_cpu_us_per_step", "cpu_quota", "host_cpu_load"):
+            assert key in d and d[key] > 0, key
+        for key in ("traffic_build_stamp", "library_build_stamp", "traffic_stale"):
+            assert key in r, key
 
 
 def test_es_force_table_matches_the_analytic_function():

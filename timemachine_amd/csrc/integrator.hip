@@ -11,6 +11,7 @@
 #include "engine.hpp"
 #include "fixed_point.hip.hpp"
 #include "philox.hip.hpp"
+#include "profiler.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -332,6 +333,7 @@ void LangevinIntegrator<Real>::step_fwd(
     const bool pregather = d_idxs == nullptr;
     // one producer whose sorted order covers every atom: walk its slots (and leave its block bounds done as well)
     const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n == N_ && df0.next.perm != nullptr;
+    const int prof = Profiler::get().begin("integrator_update", stream);
     if (sorted) {
         u64 *dx = wrote_du_dx ? d_du_dx_.data : nullptr;
         // the slot-ordered copies of x, v, cb, cc are current iff the last launch here wrote them for this producer and these
@@ -369,6 +371,7 @@ void LangevinIntegrator<Real>::step_fwd(
             N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, cm, cm_stride_, dt_,
             df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1);
     }
+    Profiler::get().end("integrator_update", prof, stream);
     HIP_CHECK(hipGetLastError());
     if (pregather) {
         for (const DeferredForces &df : deferred_) {

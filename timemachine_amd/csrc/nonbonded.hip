@@ -830,9 +830,11 @@ void NonbondedAllPairs<Real>::run_pipeline(
         // the complete list of this order exists and nothing can invalidate it: no list kernel on this call
     } else {
         const bool bounds_done = pregathered && sorted_pending && !force; // (a forced build computes its own bounds and counters)
+        const int prof_list = Profiler::get().begin("nblist_build", stream); // rebuilds AND the launches that only read the flag
         nblist_.build_device(
             d_gathered_.data, d_box, cutoff_ + list_padding(), cutoff_, flag_now, force, N_ * 3, d_x, d_snap_x_.data, d_snap_box_.data, stream,
             bounds_done, !pregathered && scale_aware());
+        Profiler::get().end("nblist_build", prof_list, stream);
         static_list_built_ = static_list() && force != 0;
     }
 
