@@ -260,7 +260,11 @@ __device__ __forceinline__ double nb_pair_prefactor_deferred(
     const double es_prefactor = charge_scale * qij * es_force_factor_table<INSIDE_SWITCH>(d2ij, tab, below);
     const double inv_d2ij = tm_rcp_f64(d2ij);
     double prefactor = es_prefactor;
+#if defined(TM_ABLATE) && TM_ABLATE == 9 // ablation (timing only): what the MD kernel would gain if no batch ever ran the LJ block
+    if (false) {
+#else
     if (eps_i != 0 && eps_j != 0) {
+#endif
         const double eps_ij = eps_i * eps_j;
         const double sig_ij = sig_i + sig_j;
         const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
