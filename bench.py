@@ -768,7 +768,8 @@ def run_md(args, rank, local_rank, world, backend):
             pass
         out["roofline"]["traffic_build_stamp"] = pmc.get("build_stamp")
         out["roofline"]["library_build_stamp"] = stamp
-        out["roofline"]["traffic_stale"] = bool(pmc.get("build_stamp")) and pmc.get("build_stamp") != stamp if stamp else None
+        # (a PMC record without a stamp cannot vouch for any build: stale)
+        out["roofline"]["traffic_stale"] = (pmc.get("build_stamp") != stamp) if stamp else None
         out["roofline_valu"] = {
             "bound": "valu_" + args.precision,
             "kernel": "k_nonbonded_tiles",

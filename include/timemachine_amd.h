@@ -263,11 +263,11 @@ int tm_profile_set_enabled(int enabled);
 int tm_profile_read(const char *kernel_name, double *total_ms, long long *launches); /* "nonbonded_tiles" */
 int tm_profile_reset(void);
 /* debugging / A-B aid: potentials a barostat works on follow small box changes without rebuilding their neighbor list
- * (DESIGN.md section 9, item 6).  0 turns that off process-wide (every box change rebuilds, as in the reference);
+ * (EXPERIMENTS.md, History, item 6).  0 turns that off process-wide (every box change rebuilds, as in the reference);
  * results are bit-identical either way -- the test suite checks exactly that. */
 int tm_debug_set_box_scaling_reuse(int enabled);
 /* debugging / A-B aid: nonbonded potentials over at most `max_atoms` atoms keep a STATIC, complete interaction list (every column
- * block listed for every row block: nothing can invalidate it, no list kernel runs on MD steps).
+ * block listed for every row block: nothing can invalidate it, no list kernel runs on MD steps; EXPERIMENTS.md, History, item 11).
  * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.
  * Results are bit-identical either way. */
 int tm_debug_set_static_list_max_k(int max_atoms, int *previous);

@@ -431,7 +431,7 @@ def test_nonbonded_pair_list_precomputed_correctness(co, P, precision, cutoff, i
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 def test_static_complete_list_of_small_systems_changes_no_bit(co, P, precision):
     """Potentials over few atoms keep a static, complete interaction list (every column block listed for every row block: no
-    displacement can invalidate it, no list kernel runs on MD steps).  The exact test d2 < cutoff^2 of the
+    displacement can invalidate it, no list kernel runs on MD steps; EXPERIMENTS.md, History, item 11).  The exact test d2 < cutoff^2 of the
     tile kernel decides alone either way, so forces, energies, du/dp and whole trajectories -- through Hilbert re-sorts, a
     barostat and host-API calls in between -- must be bit-identical to the listed pipeline; and the static one never rebuilds."""
     from timemachine_amd import testsystems as ts

@@ -3,7 +3,7 @@
 // systems) keeps k_nonbonded_tiles (kernels_nonbonded.hip.hpp), and integer accumulation makes the two interchangeable bit for
 // bit.  reference being replaced: cpp/src/kernels/k_nonbonded.cuh:109-327 (k_nonbonded_unified).
 //
-// Why a second decomposition (costed on the CPU first, scripts/decomp_stats.py): the wave-per-item
+// Why a second decomposition (costed on the CPU first, scripts/decomp_stats.py; EXPERIMENTS.md round 4): the wave-per-item
 // kernel spends about as many instructions on FINDING pairs (32 filter rounds + queue compaction per 2048 slots, of which 30 %
 // hit) and on moving operands (14 LDS reads + 6 LDS atomics per pair) as on the pair function.  Here
 //   phase 1  every lane owns one listed column atom; the unit's 32 row atoms sit in two register quadruples replicated in every
@@ -25,7 +25,7 @@
 // (the upper-triangular list makes that order roughly largest first).  Static, so that the NEXT unit is known while the current
 // one computes: its column indices are requested a unit ahead, its row atoms are staged into a second row buffer underneath the
 // current unit's pops (a unit fetched from scratch is a chain of five dependent memory hops), and a device-wide ticket would
-// come back microseconds late on this memory system anyway.
+// come back microseconds late on this memory system anyway (EXPERIMENTS.md, round 3: device-wide tickets).
 #pragma once
 #include "kernels_nonbonded.hip.hpp"
 
