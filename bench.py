@@ -98,6 +98,9 @@ def parse_args(argv=None):
     ap.add_argument("--equil-scale", type=float, default=1.0, help="scale the untimed equilibration (profiling runs)")
     ap.add_argument("--equil-precision", choices=["f64", "f32"], default="f32")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto")
+    ap.add_argument("--replica-group", type=int, default=4,
+                    help="replicas of one rank stepped together on its GPU (custom_ops.multiple_steps_group): hrex mode's MD phase, and the "
+                         "replicas_per_gpu legs of md mode; 1 = one after the other, as the reference does")
     ap.add_argument("--stub", action="store_true", help="no GPU work: a stand-in Context that sleeps (CPU tests of the launch / collective / report plumbing)")
     return ap.parse_args(argv)
 
@@ -842,6 +845,31 @@ def run_md(args, rank, local_rank, world, backend):
             pass
         except Exception as exc:  # pragma: no cover
             out["npt_error"] = str(exc)
+        # several independent replicas of the same box on this ONE GPU, stepped together (free-energy windows / HREX replicas that
+        # share a device): NOT `value` -- that is one trajectory, as the reference's benchmark times it -- but what the device delivers
+        # per day when it has more than one window to run
+        if not args.no_npt and args.replica_group > 1:
+            try:
+                out["replicas_per_gpu"] = {}
+                for n_rep in sorted({2, args.replica_group}):
+                    group = [co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed + 17 * k).impl(), make_bps(precision))
+                             for k in range(n_rep)]
+                    co.multiple_steps_group(group, SETTLE_STEPS)
+                    device_sync(co)
+                    t0 = time.perf_counter()
+                    co.multiple_steps_group(group, n_sec)
+                    wall = time.perf_counter() - t0
+                    assert all(np.all(np.isfinite(c.get_x_t())) for c in group), "trajectory diverged"
+                    out["replicas_per_gpu"][str(n_rep)] = {
+                        "aggregate_ns_day": n_rep * n_sec / wall * 86400.0 * DT * 1e-3, "us_per_replica_step": 1e6 * wall / (n_sec * n_rep),
+                        "device_ms_per_step_each": [c.last_multiple_steps_ms() / n_sec for c in group], "dtype": args.precision}
+                    del group
+                out["replicas_per_gpu"]["note"] = (
+                    "independent replicas of the same box stepped together on one GPU by one host thread (custom_ops.multiple_steps_group: steps "
+                    "interleaved on the contexts' own streams; one replica's list / update kernels run underneath another's force kernel); "
+                    "host wall clock of the call; trajectories bit-identical to stepping alone (tests/test_gpu_parity.py)")
+            except Exception as exc:  # pragma: no cover
+                out["replicas_per_gpu_error"] = str(exc)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system, xf, args.cutoff)
             out["cpu_baseline_configs"] = cpu_baseline_configs()
@@ -902,8 +930,7 @@ def run_hrex(args, rank, local_rank, world, backend):
 
     def frame(it, timed):
         t0 = time.perf_counter()
-        for c in ctxts:
-            c.multiple_steps(steps_per_frame, 0)
+        hrex.step_replicas(ctxts, steps_per_frame, group=args.replica_group)  # the rank's replicas, `group` at a time on one GPU
         device_sync(co)
         t1 = time.perf_counter()
         if args.stub:

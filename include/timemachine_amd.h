@@ -207,6 +207,12 @@ int tm_context_finalize(tm_context_t ctxt);
 int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, double *xs, double *boxes);
 /* measurement aid (bench.py): device time, in ms, of the steps of the last tm_context_multiple_steps call -- HIP events
  * on the context's stream around the first .. last step (the final frame's device-to-host copy is outside) */
+/* n_steps of several DISTINCT contexts, interleaved step by step on the contexts' own streams by the calling thread (no frames are
+ * stored: as tm_context_multiple_steps with n_samples = 0 on each).  The device runs one context's list / update kernels and kernel
+ * boundaries underneath another's force kernel: the way free-energy windows or HREX replicas that share a GPU should be stepped.
+ * Trajectories are exactly those of separate calls (the contexts share no state).  No counterpart in wrap_kernels.cpp: the
+ * reference steps the contexts of a device one after the other (fe/free_energy.py:1537-1551 loops over windows). */
+int tm_context_multiple_steps_group(const tm_context_t *ctxts, int n_ctxts, int n_steps);
 int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms);
 /* ---- local MD                                   wrap_kernels.cpp:399-631; context.cu:90-213; local_md_potentials.cu ----
  * Context.setup_local_md(temperature, freeze_reference): idempotent for equal arguments, "local md configured with

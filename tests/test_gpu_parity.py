@@ -1271,3 +1271,47 @@ def test_dhfr_shaped_box_all_terms(co, P, precision, cutoff):
         total = (lj * torch.tensor(keep_lj[k0 : k0 + 64])).sum() + (es * torch.tensor(keep_q[k0 : k0 + 64])).sum()
         ref[k0 : k0 + 64] = torch.autograd.grad(total, xi)[0].numpy()
     assert_equal_vectors(ref, du_dx[sample], 1e-8 if f64 else 1e-4)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
+    """custom_ops.multiple_steps_group steps several contexts interleaved on streams of their own (windows / HREX replicas that
+    share a GPU: one context's list and update kernels run underneath another's force kernel).  The contexts share no state, so
+    every trajectory must be, bit for bit, the one the same context takes through multiple_steps alone -- across list rebuilds, a
+    Hilbert re-sort (call 100), a barostat in one of the contexts, and mixed with ordinary calls before and after."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    N = s.num_atoms
+    x0 = s.coords.astype(np.float32).astype(np.float64)
+
+    def contexts():
+        out = []
+        for k in range(3):
+            bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s, precision)]
+            movers = [MonteCarloBarostat(N, 1.0, 300.0, ts.molecule_groups(s), 10, 5).impl(bps)] if k == 1 else []
+            out.append(co.Context(x0, np.zeros_like(x0), s.box, LangevinIntegrator(300.0, 1.5e-3, 2.0, s.masses, 40 + k).impl(), bps, movers=movers))
+        return out
+
+    alone, grouped = contexts(), contexts()
+    for c in alone:
+        c.multiple_steps(30, 0)
+        c.multiple_steps(120, 0)
+        c.multiple_steps(7, 0)
+    for c in grouped:
+        c.multiple_steps(30, 0)
+    co.multiple_steps_group(grouped, 120)
+    for c in grouped:
+        assert c.last_multiple_steps_ms() > 0
+    co.multiple_steps_group(grouped[:1], 7)  # a group of one
+    co.multiple_steps_group(grouped[1:], 7)
+    for a, g in zip(alone, grouped):
+        np.testing.assert_array_equal(a.get_x_t(), g.get_x_t())
+        np.testing.assert_array_equal(a.get_v_t(), g.get_v_t())
+        np.testing.assert_array_equal(a.get_box(), g.get_box())
+    assert not np.array_equal(alone[0].get_x_t(), alone[2].get_x_t())  # different seeds: different trajectories
+    co.multiple_steps_group([], 5)  # nothing to do
+    co.multiple_steps_group(grouped, 0)
+    with pytest.raises(RuntimeError, match="distinct"):
+        co.multiple_steps_group([grouped[0], grouped[0]], 1)

@@ -632,6 +632,17 @@ int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, dou
     ctxt->p->multiple_steps(n_steps, n_samples, xs, boxes);
     TM_CATCH
 }
+int tm_context_multiple_steps_group(const tm_context_t *ctxts, int n_ctxts, int n_steps) {
+    TM_TRY
+    require(n_ctxts >= 0 && (n_ctxts == 0 || ctxts != nullptr), "multiple_steps_group: bad context list");
+    std::vector<Context *> group;
+    for (int i = 0; i < n_ctxts; i++) {
+        require(ctxts[i] != nullptr, "multiple_steps_group: null context");
+        group.push_back(ctxts[i]->p.get());
+    }
+    Context::multiple_steps_group(group, n_steps);
+    TM_CATCH
+}
 int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms) {
     TM_TRY
     *ms = ctxt->p->last_multiple_steps_ms();

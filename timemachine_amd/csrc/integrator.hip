@@ -600,6 +600,75 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+// The streams a group of contexts is stepped on: created once, one after the other, so that the runtime hands them distinct
+// hardware queues (streams that share a hardware queue serialise: two contexts on streams created at unrelated times stepped no
+// faster together than alone).  Every Context entry point ends with a synchronisation of the stream it used, so a context can be
+// stepped on the null stream by one call and on a group stream by the next.
+static hipStream_t group_stream(const size_t k) {
+    static std::vector<hipStream_t> pool;
+    if (pool.empty()) {
+        const char *e = std::getenv("TM_AMD_GROUP_STREAMS");
+        const int n = e ? std::max(1, std::atoi(e)) : 8;
+        pool.resize(static_cast<size_t>(n));
+        for (hipStream_t &st : pool) {
+            HIP_CHECK(hipStreamCreate(&st));
+        }
+    }
+    return pool[k % pool.size()];
+}
+
+void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const int n_steps) {
+    if (n_steps < 0) {
+        throw std::runtime_error("n_steps < 0");
+    }
+    for (size_t a = 0; a < ctxts.size(); a++) {
+        for (size_t b = a + 1; b < ctxts.size(); b++) {
+            if (ctxts[a] == ctxts[b]) {
+                throw std::runtime_error("multiple_steps_group: the contexts must be distinct");
+            }
+        }
+    }
+    std::vector<hipStream_t> st(ctxts.size());
+    for (size_t k = 0; k < ctxts.size(); k++) {
+        st[k] = group_stream(k);
+    }
+    try {
+        for (size_t k = 0; k < ctxts.size(); k++) {
+            Context *c = ctxts[k];
+            c->intg_->initialize(c->bps_, c->d_x_t_.data, c->d_v_t_.data, c->d_box_t_.data, nullptr, st[k]);
+            if (c->ev_start_ == nullptr) {
+                HIP_CHECK(hipEventCreate(&c->ev_start_));
+                HIP_CHECK(hipEventCreate(&c->ev_stop_));
+            }
+            c->ev_valid_ = false;
+            if (n_steps > 0) {
+                HIP_CHECK(hipEventRecord(c->ev_start_, st[k]));
+            }
+        }
+        for (int i = 1; i <= n_steps; i++) {
+            for (size_t k = 0; k < ctxts.size(); k++) { // one step of every context per round: their launches alternate in the device's queues
+                ctxts[k]->_step(st[k]);
+            }
+        }
+        for (size_t k = 0; k < ctxts.size(); k++) {
+            Context *c = ctxts[k];
+            if (n_steps > 0) {
+                HIP_CHECK(hipEventRecord(c->ev_stop_, st[k]));
+                c->ev_valid_ = true;
+            }
+            c->intg_->finalize(c->bps_, c->d_x_t_.data, c->d_v_t_.data, c->d_box_t_.data, nullptr, st[k]);
+        }
+    } catch (...) {
+        for (hipStream_t q : st) {
+            (void)hipStreamSynchronize(q);
+        }
+        throw;
+    }
+    for (hipStream_t q : st) {
+        HIP_CHECK(hipStreamSynchronize(q));
+    }
+}
+
 double Context::_get_temperature() const {
     // reference: context.cu:80-88 (only a Langevin thermostat knows a temperature)
     if (auto li = std::dynamic_pointer_cast<LangevinIntegrator<float>>(intg_)) {

@@ -1128,6 +1128,22 @@ void declare_functions(py::module &m) {
         },
         py::arg("max_atoms"));
     m.def(
+        "multiple_steps_group",
+        [](const std::vector<std::shared_ptr<PyContext>> &ctxts, const int n_steps) {
+            // not in the reference surface: n_steps of several distinct Contexts interleaved on their own streams (windows or HREX
+            // replicas that share a GPU: one context's list / update kernels run underneath another's force kernel)
+            std::vector<tm_context_t> hs;
+            for (const auto &c : ctxts) {
+                if (!c) {
+                    throw std::runtime_error("multiple_steps_group: None in the context list");
+                }
+                hs.push_back(c->h);
+            }
+            py::gil_scoped_release nogil;
+            check(tm_context_multiple_steps_group(hs.data(), static_cast<int>(hs.size()), n_steps));
+        },
+        py::arg("contexts"), py::arg("n_steps"));
+    m.def(
         "debug_set_rowblock_min_k",
         [](const int min_atoms) { // A/B aid: forces-only launches over >= min_atoms atoms run the row-block kernel; -> the old value
             int previous = 0;

@@ -1051,6 +1051,14 @@ def debug_set_static_list_max_k(max_atoms):
     return prev.value
 
 
+def multiple_steps_group(contexts, n_steps):
+    """n_steps of several distinct Contexts, interleaved step by step on their own streams (not in the reference surface: windows or
+    HREX replicas that share a GPU; one context's list / update kernels run underneath another's force kernel)."""
+    contexts = list(contexts)
+    arr = (_vp * max(len(contexts), 1))(*[c._h.value for c in contexts])
+    _check(_lib.tm_context_multiple_steps_group(arr, _c_int(len(contexts)), _c_int(int(n_steps))))
+
+
 def debug_set_rowblock_min_k(min_atoms):
     """A/B aid: forces-only nonbonded launches over at least `min_atoms` atoms run the row-block kernel (0: always); -> the old
     value.  Results are bit-identical either way."""
