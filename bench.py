@@ -851,8 +851,12 @@ def run_md(args, rank, local_rank, world, backend):
         if not args.no_npt and args.replica_group > 1:
             try:
                 out["replicas_per_gpu"] = {}
-                for n_rep in sorted({2, args.replica_group}):
-                    group = [co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed + 17 * k).impl(), make_bps(precision))
+                # (the last leg: the reference benchmark's own configuration -- f32 potentials, cutoff 1.0 nm -- at the full group size)
+                legs = [(n_rep, precision, None, str(n_rep)) for n_rep in sorted({2, args.replica_group})]
+                if not args.no_rc10 and args.cutoff != 1.0:
+                    legs.append((args.replica_group, np.float32, 1.0, f"{args.replica_group}_rc1.0_f32"))
+                for n_rep, leg_prec, leg_cutoff, key in legs:
+                    group = [co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed + 17 * k).impl(), make_bps(leg_prec, leg_cutoff))
                              for k in range(n_rep)]
                     co.multiple_steps_group(group, SETTLE_STEPS)
                     device_sync(co)
@@ -860,9 +864,10 @@ def run_md(args, rank, local_rank, world, backend):
                     co.multiple_steps_group(group, n_sec)
                     wall = time.perf_counter() - t0
                     assert all(np.all(np.isfinite(c.get_x_t())) for c in group), "trajectory diverged"
-                    out["replicas_per_gpu"][str(n_rep)] = {
-                        "aggregate_ns_day": n_rep * n_sec / wall * 86400.0 * DT * 1e-3, "us_per_replica_step": 1e6 * wall / (n_sec * n_rep),
-                        "device_ms_per_step_each": [c.last_multiple_steps_ms() / n_sec for c in group], "dtype": args.precision}
+                    out["replicas_per_gpu"][key] = {
+                        "replicas": n_rep, "aggregate_ns_day": n_rep * n_sec / wall * 86400.0 * DT * 1e-3, "us_per_replica_step": 1e6 * wall / (n_sec * n_rep),
+                        "device_ms_per_step_each": [c.last_multiple_steps_ms() / n_sec for c in group],
+                        "dtype": "f64" if leg_prec == np.float64 else "f32", "cutoff": args.cutoff if leg_cutoff is None else leg_cutoff}
                     del group
                 out["replicas_per_gpu"]["note"] = (
                     "independent replicas of the same box stepped together on one GPU by one host thread (custom_ops.multiple_steps_group: steps "
