@@ -14,6 +14,7 @@
 #include "profiler.hpp"
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <iostream>
 
@@ -605,7 +606,10 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
 // faster together than alone).  Every Context entry point ends with a synchronisation of the stream it used, so a context can be
 // stepped on the null stream by one call and on a group stream by the next.
 static hipStream_t group_stream(const size_t k) {
-    static std::vector<hipStream_t> pool;
+    static std::map<int, std::vector<hipStream_t>> pools; // per device (a process that switches devices gets a pool on each)
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::vector<hipStream_t> &pool = pools[dev];
     if (pool.empty()) {
         const char *e = std::getenv("TM_AMD_GROUP_STREAMS");
         const int n = e ? std::max(1, std::atoi(e)) : 8;
