@@ -339,7 +339,7 @@ __device__ __forceinline__ void compact4(const u64 m0, const u64 m1, const u64 m
         : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [e0] "v"(e0),
           [l0] "s"(static_cast<unsigned int>(m0)), [h0] "s"(static_cast<unsigned int>(m0 >> 32)), [l1] "s"(static_cast<unsigned int>(m1)), [h1] "s"(static_cast<unsigned int>(m1 >> 32)),
           [l2] "s"(static_cast<unsigned int>(m2)), [h2] "s"(static_cast<unsigned int>(m2 >> 32)), [l3] "s"(static_cast<unsigned int>(m3)), [h3] "s"(static_cast<unsigned int>(m3 >> 32))
-        : "scc", "memory");
+        : "scc", "memory", "exec");
 }
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
