@@ -1315,3 +1315,51 @@ def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
     co.multiple_steps_group(grouped, 0)
     with pytest.raises(RuntimeError, match="distinct"):
         co.multiple_steps_group([grouped[0], grouped[0]], 1)
+
+
+def test_step_replicas_groups_of_two_equal_sequential_stepping(co, P):
+    """hrex.step_replicas (how bench.py --mode hrex and an HREX driver step the replicas that share a GPU) with five contexts in
+    groups of two (2 + 2 + 1) against the same contexts stepped one call after the other: identical bits."""
+    from timemachine_amd import hrex
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    v0 = np.zeros_like(s.coords)
+
+    def contexts():
+        return [co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 900 + k).impl(),
+                           [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]) for k in range(5)]
+
+    a, b = contexts(), contexts()
+    for c in a:
+        c.multiple_steps(60, 0)
+    hrex.step_replicas(b, 60, group=2)
+    for ca, cb in zip(a, b):
+        np.testing.assert_array_equal(ca.get_x_t(), cb.get_x_t())
+        np.testing.assert_array_equal(ca.get_v_t(), cb.get_v_t())
+
+
+def test_group_stepping_refuses_contexts_that_share_device_state(co, P):
+    """One unbound potential bound twice keeps ONE neighbor list and ONE set of accumulators: its two BoundPotentials may be used one
+    call after the other (the reference's pattern) but not on two streams at once -- multiple_steps_group says so instead of
+    computing garbage; the same contexts stepped one by one are fine."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    s = _md_system()
+    v0 = np.zeros_like(s.coords)
+    nb = P.Nonbonded(s.num_atoms, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff).to_gpu(np.float32)
+    b1, b2 = nb.bind(s.nb_params).bound_impl, nb.bind(s.nb_params * np.array([0.9, 1.0, 1.0, 1.0])).bound_impl
+    c1 = co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 1).impl(), [b1])
+    c2 = co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 2).impl(), [b2])
+    with pytest.raises(RuntimeError, match="share a potential"):
+        co.multiple_steps_group([c1, c2], 5)
+    c1.multiple_steps(5, 0)
+    c2.multiple_steps(5, 0)
+    assert np.all(np.isfinite(c1.get_x_t())) and np.all(np.isfinite(c2.get_x_t()))
+    shared_intg = LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 3).impl()
+    fresh = [[bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)] for _ in range(2)]
+    c3, c4 = (co.Context(s.coords, v0, s.box, shared_intg, fresh[k]) for k in range(2))
+    with pytest.raises(RuntimeError, match="share a potential, integrator or mover"):
+        co.multiple_steps_group([c3, c4], 5)

@@ -130,3 +130,26 @@ def test_sanitize_rejects_broken_replicas():
     assert np.isinf(out[0, 1]) and out[0, 0] == 1.0
     with pytest.raises(AssertionError, match="non-finite"):
         hrex.verify_and_sanitize_potential_matrix(np.array([[np.inf, 0.0], [0.0, 1.0]]), [0, 1])
+
+
+def test_step_replicas_falls_back_to_sequential_calls_for_stand_in_contexts():
+    """hrex.step_replicas steps real Contexts `group` at a time through custom_ops.multiple_steps_group; anything else (bench.py's
+    stand-in contexts, a single replica) is stepped one call after the other.  Either way every context takes n_steps."""
+    from timemachine_amd import hrex
+
+    class Stand:
+        def __init__(self):
+            self.calls = []
+
+        def multiple_steps(self, n, interval=0):
+            self.calls.append((n, interval))
+
+    cs = [Stand() for _ in range(5)]
+    hrex.step_replicas(cs, 40, group=4)
+    assert all(c.calls == [(40, 0)] for c in cs)
+    hrex.step_replicas(cs[:1], 7, group=4)
+    assert cs[0].calls == [(40, 0), (7, 0)]
+
+
+def test_both_bindings_offer_group_stepping(any_binding):
+    assert callable(any_binding.multiple_steps_group) and callable(any_binding.debug_set_rowblock_min_k)

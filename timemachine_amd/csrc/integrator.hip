@@ -14,6 +14,7 @@
 #include "profiler.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <map>
 #include <cmath>
 #include <iostream>
@@ -621,9 +622,51 @@ static hipStream_t group_stream(const size_t k) {
     return pool[k % pool.size()];
 }
 
+// every Potential object (containers and their children alike) reachable from a context, and its integrator and movers
+static void collect_objects(const std::shared_ptr<Potential> &pot, std::vector<const void *> &out) {
+    out.push_back(pot.get());
+    if (auto f = std::dynamic_pointer_cast<FanoutSummedPotential>(pot)) {
+        for (auto &c : f->get_potentials()) {
+            collect_objects(c, out);
+        }
+    } else if (auto sp = std::dynamic_pointer_cast<SummedPotential>(pot)) {
+        for (auto &c : sp->get_potentials()) {
+            collect_objects(c, out);
+        }
+    }
+}
+
 void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const int n_steps) {
     if (n_steps < 0) {
         throw std::runtime_error("n_steps < 0");
+    }
+    // Contexts stepped together must share NOTHING that holds device state: a Potential bound twice (one unbound potential, two
+    // BoundPotentials -- fine one call after the other) keeps ONE neighbor list and ONE set of accumulators, and an integrator or
+    // a mover handed to two contexts keeps one state.  Two streams in the same buffers would not fail, they would be wrong.
+    {
+        std::vector<std::vector<const void *>> owned(ctxts.size());
+        for (size_t k = 0; k < ctxts.size(); k++) {
+            for (auto &bp : ctxts[k]->bps_) {
+                owned[k].push_back(bp.get());
+                collect_objects(bp->potential, owned[k]);
+            }
+            owned[k].push_back(ctxts[k]->intg_.get());
+            for (auto &m : ctxts[k]->movers_) {
+                owned[k].push_back(m.get());
+            }
+            std::sort(owned[k].begin(), owned[k].end());
+        }
+        for (size_t a = 0; a < ctxts.size(); a++) {
+            for (size_t b = a + 1; b < ctxts.size(); b++) {
+                std::vector<const void *> both;
+                std::set_intersection(owned[a].begin(), owned[a].end(), owned[b].begin(), owned[b].end(), std::back_inserter(both));
+                if (!both.empty() && ctxts[a] != ctxts[b]) {
+                    throw std::runtime_error(
+                        "multiple_steps_group: contexts " + std::to_string(a) + " and " + std::to_string(b) +
+                        " share a potential, integrator or mover object; contexts stepped together need their own (bind fresh potentials per context)");
+                }
+            }
+        }
     }
     for (size_t a = 0; a < ctxts.size(); a++) {
         for (size_t b = a + 1; b < ctxts.size(); b++) {
