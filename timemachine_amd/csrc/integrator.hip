@@ -14,6 +14,10 @@
 #include "profiler.hpp"
 
 #include <algorithm>
+#include <exception>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 #include <iterator>
 #include <map>
 #include <cmath>
@@ -692,10 +696,57 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
                 HIP_CHECK(hipEventRecord(c->ev_start_, st[k]));
             }
         }
-        for (int i = 1; i <= n_steps; i++) {
-            for (size_t k = 0; k < ctxts.size(); k++) { // one step of every context per round: their launches alternate in the device's queues
-                ctxts[k]->_step(st[k]);
+        // Enqueueing a step costs the host 6-10 us (two or three launches and the plan's bookkeeping): plenty of slack against a
+        // 55 us DHFR-sized replica-step, but for small systems (8 us per replica-step on the device at 2.2k atoms) one launching
+        // thread is the limit.  So the contexts are dealt to up to TM_AMD_GROUP_THREADS (default 2) host threads, each feeding its own
+        // contexts' streams; the contexts share nothing, so the threads need no coordination beyond the join.
+        const auto t_enqueue = std::chrono::steady_clock::now();
+        const char *e_threads = std::getenv("TM_AMD_GROUP_THREADS");
+        size_t n_threads = std::min<size_t>(ctxts.size(), static_cast<size_t>(std::max(1, e_threads ? std::atoi(e_threads) : 2)));
+        if (Profiler::get().enabled()) {
+            n_threads = 1; // the per-launch profiler keeps its events in one unsynchronised table
+        }
+#ifdef TM_GUARD
+        n_threads = 1; // (so does the guard-zone allocator of debug builds)
+#endif
+        if (n_threads <= 1) {
+            for (int i = 1; i <= n_steps; i++) {
+                for (size_t k = 0; k < ctxts.size(); k++) { // one step of every context per round: their launches alternate in the device's queues
+                    ctxts[k]->_step(st[k]);
+                }
             }
+        } else {
+            int dev = 0;
+            HIP_CHECK(hipGetDevice(&dev));
+            std::vector<std::exception_ptr> failed(n_threads);
+            std::vector<std::thread> workers;
+            for (size_t w = 0; w < n_threads; w++) {
+                workers.emplace_back([&, w]() {
+                    try {
+                        HIP_CHECK(hipSetDevice(dev)); // (the current device is per-thread state)
+                        for (int i = 1; i <= n_steps; i++) {
+                            for (size_t k = w; k < ctxts.size(); k += n_threads) {
+                                ctxts[k]->_step(st[k]);
+                            }
+                        }
+                    } catch (...) {
+                        failed[w] = std::current_exception();
+                    }
+                });
+            }
+            for (std::thread &t : workers) {
+                t.join();
+            }
+            for (const std::exception_ptr &f : failed) {
+                if (f) {
+                    std::rethrow_exception(f);
+                }
+            }
+        }
+        if (std::getenv("TM_AMD_DEBUG_ENQUEUE")) { // how long the host needs to enqueue a step (meaningful while the device's queues do not fill up)
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enqueue).count();
+            fprintf(stderr, "[enqueue] %zu contexts x %d steps on %zu host thread(s): %.2f us of host wall time per context-step\n", ctxts.size(), n_steps, n_threads,
+                    us / (static_cast<double>(n_steps) * ctxts.size()));
         }
         for (size_t k = 0; k < ctxts.size(); k++) {
             Context *c = ctxts[k];
