@@ -74,6 +74,8 @@ METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
 
 PINNED_CPUS = None  # set by main(): the CPUs this rank was given (pin_rank_to_cpus)
+JOB_CPUS = None  # set by main() BEFORE pinning: the scheduler affinity of the whole job (restored around the CPU baseline)
+JOB_CPU_QUOTA = None  # ... and its CPU quota: what host_cpu_load, summed over the ranks, is to be held against
 
 
 def parse_args(argv=None):
@@ -686,7 +688,7 @@ def run_md(args, rank, local_rank, world, backend):
         # HIP runtime's helpers), the CPUs the job may use (scheduler affinity cut to the cgroup quota) and what N ranks of this kind
         # ask of them: host_cpu_load = n_gpus * host_cpu_us_per_step / (1e3 * ms_per_step) CPUs busy, to be held against cpu_quota
         "host_cpu_us_per_step": max(r["host_cpu_us_per_step"] for r in per_rank),
-        "cpu_quota": _cpu_quota(),
+        "cpu_quota": JOB_CPU_QUOTA if JOB_CPU_QUOTA is not None else _cpu_quota(),  # the whole job's (taken before the ranks pinned themselves)
         "host_cpu_load": sum(r["host_cpu_us_per_step"] for r in per_rank) / (1e3 * (1e3 * dev_s / args.steps)),
         "host_ns_day": args.steps / host_s * 86400.0 * DT * 1e-3 * world,
         "world_size": world,
@@ -756,8 +758,11 @@ def run_md(args, rank, local_rank, world, backend):
             out["kernels"].append({
                 "name": name, "us_per_step": us_per_step, "launches_per_step": n_k / steps_p, "us_per_launch": 1e3 * ms_k / n_k,
                 "algorithmic_bytes_per_step": b, "frac_of_hbm_peak": b / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "share_of_step": us_per_step / (1e6 * dev_s / args.steps),  # of the TIMED step (the brackets' dispatch latency makes the shares sum to ~1.1)
+                # of the PROFILED step -- the same run and clock the brackets come from (the profiled steps are slower than the timed
+                # ones by the brackets' own dispatch latency; dividing by the timed step made the shares sum to 1.12)
+                "share_of_step": us_per_step / (1e3 * prof["run_ms"] / steps_p),
             })
+        out["kernels_profiled_us_per_step"] = 1e3 * prof["run_ms"] / steps_p
         out["kernels_note"] = ("per-launch HIP events on the Context stream over the profiled steps; nblist_build = every launch of the list kernels "
                                "(rebuilds, amortised, and the launches that only read the rebuild flag); frac_of_hbm_peak uses the algorithmic bytes "
                                "spelt out in bench.py (alg_bytes) -- none of these kernels is HBM-bound: the tile kernel is bound by VALU issue "
@@ -876,6 +881,11 @@ def run_md(args, rank, local_rank, world, backend):
             except Exception as exc:  # pragma: no cover
                 out["replicas_per_gpu_error"] = str(exc)
         if not args.no_cpu_baseline:
+            if JOB_CPUS:  # the CPU baseline uses the job's CPUs, not this rank's slice of them
+                try:
+                    os.sched_setaffinity(0, JOB_CPUS)
+                except OSError:  # pragma: no cover
+                    pass
             out["cpu_baseline"] = cpu_baseline(system, xf, args.cutoff)
             out["cpu_baseline_configs"] = cpu_baseline_configs()
             if not args.stub:
@@ -1022,7 +1032,14 @@ def main(argv=None):
     maybe_self_launch(args)
     protect_stdout()
     rank, local_rank, world, backend = init_distributed(args)
-    global PINNED_CPUS
+    global PINNED_CPUS, JOB_CPUS, JOB_CPU_QUOTA
+    # the job-wide figures are taken BEFORE this rank cuts its affinity down to its own slice: host_cpu_load sums CPU time over
+    # ALL ranks and belongs next to the whole job's quota (after pinning, _cpu_quota() is one rank's share)
+    JOB_CPU_QUOTA = _cpu_quota()
+    try:
+        JOB_CPUS = sorted(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        JOB_CPUS = None
     PINNED_CPUS = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     try:
         if args.mode == "hrex":

@@ -14,7 +14,13 @@
  *   - handles are opaque and reference counted internally: a BoundPotential keeps its Potential alive, a
  *     Summed/Fanout potential keeps its children alive, a Context keeps integrator and potentials alive
  *     (reference: all bound classes are held by std::shared_ptr).  Destroy every handle you were given exactly once.
- *   - objects are stateful and NOT thread-safe (reference: cpp/src/potential.hpp:7).
+ *   - objects are stateful and NOT thread-safe (reference: cpp/src/potential.hpp:7).  Every entry point runs under ONE
+ *     process-wide recursive lock, held for the whole call (a tm_context_multiple_steps call included): threads that drive
+ *     different GPUs from one process are serialised -- use one process per GPU, as bench.py and the reference's
+ *     parallel/client.py do.  A binding that keeps the Python GIL while it waits for this lock stalls the interpreter; the
+ *     compiled binding releases the GIL around every call that reaches the device.
+ *   - loading the library exports GPU_MAX_HW_QUEUES=8 to the process environment unless the variable is already set (see
+ *     tm_context_multiple_steps_group); nothing else in the environment is touched.
  *   - "precision" selects the arithmetic type of the kernels (the reference's *_f32 / *_f64 classes); storage of
  *     coordinates, velocities, box and parameters is always f64.
  */
@@ -205,14 +211,21 @@ int tm_context_finalize(tm_context_t ctxt);
 /* multiple_steps(n_steps, store_x_interval): the caller computes n_samples = n_steps / (store_x_interval or n_steps)
  * exactly as the binding does (wrap_kernels.cpp:347-369) and passes xs[n_samples,N,3], boxes[n_samples,3,3]. */
 int tm_context_multiple_steps(tm_context_t ctxt, int n_steps, int n_samples, double *xs, double *boxes);
-/* measurement aid (bench.py): device time, in ms, of the steps of the last tm_context_multiple_steps call -- HIP events
- * on the context's stream around the first .. last step (the final frame's device-to-host copy is outside) */
-/* n_steps of several DISTINCT contexts, interleaved step by step on the contexts' own streams by the calling thread (no frames are
- * stored: as tm_context_multiple_steps with n_samples = 0 on each).  The device runs one context's list / update kernels and kernel
+/* n_steps of several DISTINCT contexts, interleaved step by step on streams of their own (no frames are stored: as
+ * tm_context_multiple_steps with n_samples = 0 on each).  The device runs one context's list / update kernels and kernel
  * boundaries underneath another's force kernel: the way free-energy windows or HREX replicas that share a GPU should be stepped.
- * Trajectories are exactly those of separate calls (the contexts share no state).  No counterpart in wrap_kernels.cpp: the
- * reference steps the contexts of a device one after the other (fe/free_energy.py:1537-1551 loops over windows). */
+ * Trajectories are exactly those of separate calls (the contexts share no state; contexts that do -- a potential bound twice, a
+ * shared integrator or mover, a mover built on another context's bound potentials -- are refused).  The contexts are dealt to
+ * TM_AMD_GROUP_THREADS enqueueing host threads inside the call (default: 2 while every context has at most 5000 atoms -- there the
+ * 6-10 us a host thread needs per context-step is the limit --, 1 above); the calling thread returns when all have finished.
+ * Every stream needs a hardware queue of its own: the library exports GPU_MAX_HW_QUEUES=8 (unless the variable is already set)
+ * when it is loaded, which the HIP runtime reads when it first touches the device -- a process that initialised HIP before loading
+ * this library should export the variable itself (with the runtime's default of 4, four replicas step ~10 % slower).
+ * No counterpart in wrap_kernels.cpp: the reference steps the contexts of a device one after the other
+ * (fe/free_energy.py:1537-1551 loops over windows). */
 int tm_context_multiple_steps_group(const tm_context_t *ctxts, int n_ctxts, int n_steps);
+/* measurement aid (bench.py): device time, in ms, of the steps of the last tm_context_multiple_steps[_group] call -- HIP events
+ * on the stream the context was stepped on around the first .. last step (the final frame's device-to-host copy is outside) */
 int tm_context_last_multiple_steps_ms(tm_context_t ctxt, double *ms);
 /* ---- local MD                                   wrap_kernels.cpp:399-631; context.cu:90-213; local_md_potentials.cu ----
  * Context.setup_local_md(temperature, freeze_reference): idempotent for equal arguments, "local md configured with
@@ -277,10 +290,14 @@ int tm_debug_set_box_scaling_reuse(int enabled);
  * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.
  * Results are bit-identical either way. */
 int tm_debug_set_static_list_max_k(int max_atoms, int *previous);
-/* debugging / A-B aid: forces-only nonbonded launches over at least `min_atoms` atoms run the row-block kernel (one workgroup per
- * row block and column range, lane-owned columns regrouped by hit count: csrc/kernels_nonbonded_rowblock.hip.hpp); smaller ones the
+/* debugging / A-B aid, VARIANT LIBRARY ONLY (libtimemachine_amd_rowblock.so, built with -DTM_ROWBLOCK by csrc/build.py; the product
+ * library answers anything but INT_MAX with an error): forces-only nonbonded launches over at least `min_atoms` atoms run the
+ * row-block kernel (one workgroup per row block and column range, lane-owned columns regrouped by hit count:
+ * csrc/kernels_nonbonded_rowblock.hip.hpp) -- a second, independent implementation of k_nonbonded_unified
+ * (cpp/src/kernels/k_nonbonded.cuh:109-327) that the parity tests compare with the product kernel bit for bit; smaller launches run the
  * wave-per-item kernel.  Process-wide; applies from the next call; 0 = always, INT_MAX = never; *previous (may be NULL) receives
- * the old value.  Results are bit-identical either way (both replace k_nonbonded_unified, cpp/src/kernels/k_nonbonded.cuh:109-327). */
+ * the old value.  tm_debug_rowblock_available: 1 iff the loaded library carries the kernel. */
+int tm_debug_rowblock_available(int *available);
 int tm_debug_set_rowblock_min_k(int min_atoms, int *previous);
 /* host only: the electrostatic force-factor table the f64 nonbonded kernels use for `beta` (csrc/nb_es_table.hip.hpp):
  * 256 intervals (32 per binade of d^2 from 2^-7 to 2) x 6 monomial coefficients in the in-interval position t in [0, 1).

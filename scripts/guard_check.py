@@ -64,14 +64,17 @@ for prec in (np.float32, np.float64):
     total += check(f"split kernels {prec.__name__}")
 # round 4: the row-block kernel on every forces-only launch (MD in both precisions, 4-D ligand state), and three contexts stepped
 # together on the group streams
-before = co.debug_set_rowblock_min_k(0)
-for prec in (np.float32, np.float64):
+# (the row-block kernel lives in libraries built with -DTM_ROWBLOCK only: a guard build of that variant runs this part)
+have_rb = co.debug_rowblock_available()
+before = co.debug_set_rowblock_min_k(0) if have_rb else None
+for prec in ((np.float32, np.float64) if have_rb else ()):
     for sysm in (s, small):
         bps = [bp.to_gpu(prec).bound_impl for bp in ts.bound_potentials(sysm)]
         ctxt = co.Context(sysm.coords, np.zeros_like(sysm.coords), sysm.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, sysm.masses, 1).impl(), bps)
         ctxt.multiple_steps(250, 0)
     total += check(f"row-block kernel {prec.__name__}")
-co.debug_set_rowblock_min_k(before)
+if have_rb:
+    co.debug_set_rowblock_min_k(before)
 group = [co.Context(mid.coords, np.zeros_like(mid.coords), mid.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, mid.masses, 20 + k).impl(),
                     [bp.to_gpu(np.float64 if k else np.float32).bound_impl for bp in ts.bound_potentials(mid)]) for k in range(3)]
 co.multiple_steps_group(group, 300)

@@ -34,8 +34,9 @@ for prec in (np.float64, np.float32):
             print(prec.__name__, "grouped replica", k, "steps", (chunk + 1) * 50000, "T = %.1f K" % T, "finite", ok, flush=True)
     print("  wall %.1f s for 4 x 100k steps (%.1f us per replica-step)" % (time.time() - t0, 1e6 * (time.time() - t0) / 4e5))
     del group
-co.debug_set_rowblock_min_k(0)
-ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, 9).impl(), make_bps(np.float64))
-ctxt.multiple_steps(50000, 0)
-vv = ctxt.get_v_t()
-print("row-block kernel f64, 50k steps: T = %.1f K" % ((s.masses[:, None] * vv * vv).sum() / (3 * s.num_atoms * 0.0083144626)), "finite", bool(np.all(np.isfinite(ctxt.get_x_t()))), "; %.1f us per step" % (1e3 * ctxt.last_multiple_steps_ms() / 50000))
+if co.debug_rowblock_available():  # (variant library libtimemachine_amd_rowblock.so only)
+    co.debug_set_rowblock_min_k(0)
+    ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, 9).impl(), make_bps(np.float64))
+    ctxt.multiple_steps(50000, 0)
+    vv = ctxt.get_v_t()
+    print("row-block kernel f64, 50k steps: T = %.1f K" % ((s.masses[:, None] * vv * vv).sum() / (3 * s.num_atoms * 0.0083144626)), "finite", bool(np.all(np.isfinite(ctxt.get_x_t()))), "; %.1f us per step" % (1e3 * ctxt.last_multiple_steps_ms() / 50000))

@@ -44,15 +44,19 @@ def any_binding(request):
 
 NEVER = 2**31 - 1  # (int: both debug knobs take a C int)
 # which list and which force kernel a Nonbonded potential runs on: (static complete list up to K atoms, row-block kernel from K atoms)
-NB_PATHS = {"static+items": (4608, NEVER), "listed+items": (0, NEVER), "listed+rowblocks": (0, 0)}
+NB_PATHS = {"static+items": (4608, NEVER), "listed+items": (0, NEVER), "listed+rowblocks": (0, 0), "static+rowblocks": (4608, 0)}
 
 
 @pytest.fixture(params=list(NB_PATHS))
 def nb_path(request, co):
     """Small systems get a static complete list by default, large ones a built neighbor list; forces-only launches can run the
     wave-per-item kernel (the product) or the row-block kernel (csrc/kernels_nonbonded_rowblock.hip.hpp, an independent second
-    implementation kept for A/B runs): the golden comparisons below run on every combination, whatever the size."""
+    implementation): the golden comparisons below run on every combination, whatever the size.  The row-block kernel lives in the
+    variant library libtimemachine_amd_rowblock.so only: its combinations are skipped under the product library and run when
+    tests/test_gpu_second_binding.py re-runs these tests in a child interpreter that loads the variant (TM_AMD_LIB)."""
     static_k, rowblock_k = NB_PATHS[request.param]
+    if rowblock_k != NEVER and not co.debug_rowblock_available():
+        pytest.skip("the row-block kernel is in the variant library only (run through tests/test_gpu_second_binding.py)")
     before = co.debug_set_static_list_max_k(static_k), co.debug_set_rowblock_min_k(rowblock_k)
     yield request.param
     co.debug_set_static_list_max_k(before[0])

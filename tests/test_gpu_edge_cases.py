@@ -453,14 +453,26 @@ def test_config5_sized_hrex_iteration(co, P):
     # three resident replicas (one rank's share of 24 windows over 8 GPUs), each after a short MD run under its own state
     mine = [0, 8, 16]
     coords, ctxts, bound = [], [], []
-    for r in mine:
+
+    def make_context(r):
         bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s0)]
         bps[-1].set_params(params_by_state[r].reshape(-1))
-        ctxt = co.Context(s0.coords, np.zeros_like(s0.coords), s0.box, LangevinIntegrator(300.0, 0.25e-3, 50.0, s0.masses, 40 + r).impl(), bps)
+        return co.Context(s0.coords, np.zeros_like(s0.coords), s0.box, LangevinIntegrator(300.0, 0.25e-3, 50.0, s0.masses, 40 + r).impl(), bps), bps
+
+    for r in mine:
+        ctxt, bps = make_context(r)
         ctxt.multiple_steps(25, 0)
         ctxts.append(ctxt)
         bound.append(bps[-1])
         coords.append(ctxt.get_x_t())
+    # the same three replicas stepped TOGETHER, the way bench.py --mode hrex and an HREX driver step a rank's replicas
+    # (hrex.step_replicas -> custom_ops.multiple_steps_group: 31k-atom systems on the listed pipeline, three streams): same bits
+    together = [make_context(r)[0] for r in mine]
+    hrex.step_replicas(together, 25, group=3)
+    for alone_ctxt, grouped_ctxt in zip(ctxts, together):
+        np.testing.assert_array_equal(alone_ctxt.get_x_t(), grouped_ctxt.get_x_t())
+        np.testing.assert_array_equal(alone_ctxt.get_v_t(), grouped_ctxt.get_v_t())
+    del together
     coords = np.stack(coords)
     boxes = np.stack([s0.box] * len(mine))
     dh = hrex.DistributedHREX(n_states, 300.0, max_delta_states=max_delta, world_size=8, rank=0)

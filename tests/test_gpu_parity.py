@@ -1239,7 +1239,7 @@ def test_dhfr_shaped_box_all_terms(co, P, precision, cutoff):
     assert a[2] == c[2]
     # forces-only (the MD form; f64: table-driven electrostatics) gives the same bits as the full call -- on the wave-per-item
     # kernel (the product) and on the row-block kernel (the second implementation of the same contract)
-    for rowblock_min_k in (2**31 - 1, 0):
+    for rowblock_min_k in ((2**31 - 1, 0) if co.debug_rowblock_available() else (2**31 - 1,)):  # (the variant library carries the second kernel)
         before = co.debug_set_rowblock_min_k(rowblock_min_k)
         try:
             np.testing.assert_array_equal(nb.execute_raw(x, p, box, True, False, False)[0], a[0])
@@ -1277,8 +1277,10 @@ def test_dhfr_shaped_box_all_terms(co, P, precision, cutoff):
 def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
     """custom_ops.multiple_steps_group steps several contexts interleaved on streams of their own (windows / HREX replicas that
     share a GPU: one context's list and update kernels run underneath another's force kernel).  The contexts share no state, so
-    every trajectory must be, bit for bit, the one the same context takes through multiple_steps alone -- across list rebuilds, a
-    Hilbert re-sort (call 100), a barostat in one of the contexts, and mixed with ordinary calls before and after."""
+    every trajectory must be, bit for bit, the one the same context takes through multiple_steps alone -- across a Hilbert re-sort
+    (call 100), a barostat in one of the contexts, and mixed with ordinary calls before and after.  (This system is small enough
+    for the STATIC complete list: no rebuild runs here -- test_group_stepping_on_the_listed_pipeline_... below is the one that
+    groups contexts whose lists rebuild, at the sizes bench.py groups.)"""
     from timemachine_amd import testsystems as ts
     from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
 
@@ -1315,6 +1317,114 @@ def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
     co.multiple_steps_group(grouped, 0)
     with pytest.raises(RuntimeError, match="distinct"):
         co.multiple_steps_group([grouped[0], grouped[0]], 1)
+
+
+@pytest.mark.parametrize("threads", ["1", "2"])
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("which", ["listed_small", "dhfr_shaped"])
+def test_group_stepping_on_the_listed_pipeline_is_bitwise_separate_stepping(co, P, which, precision, threads):
+    """The grouped call where bench.py runs it (`replicas_per_gpu`, `--mode hrex`): the LISTED neighbor-list pipeline -- k_find_ixns
+    rebuilds, the coordinate snapshot hand-over, the cost-bucket counters and the sorted pre-gather all running concurrently on the
+    group's streams --, a barostat in EVERY context (the production shape, fe/rbfe.py:113-121), one or two enqueueing host threads.
+    `listed_small`: the 2 243-atom solvated ligand with the static complete list switched off (four contexts, 130 steps: a rebuild
+    every few steps and the call-100 Hilbert re-sort fall inside the grouped call); `dhfr_shaped`: three contexts of the 23 559-atom
+    bench workload, 120 steps.  Against the same contexts stepped alone: identical bits."""
+    import os
+
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    if which == "listed_small":
+        s, n_ctx, n_steps, dt, friction = ts.small_solvated_ligand(lamb=0.3), 4, 130, 1.5e-3, 2.0
+    else:
+        s, n_ctx, n_steps, dt, friction = ts.dhfr_shaped_box(), 3, 120, 1.0e-3, 10.0
+    N = s.num_atoms
+    x0 = s.coords.astype(np.float32).astype(np.float64)
+    groups = ts.molecule_groups(s)
+
+    def contexts():
+        out = []
+        for k in range(n_ctx):
+            bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s, precision, nblist_padding=0.18 if which == "dhfr_shaped" else 0.1)]
+            movers = [MonteCarloBarostat(N, 1.0, 300.0, groups, 10 + k, 5 + k).impl(bps)]
+            out.append((co.Context(x0, np.zeros_like(x0), s.box, LangevinIntegrator(300.0, dt, friction, s.masses, 70 + k).impl(), bps, movers=movers), bps, movers))
+        return out
+
+    static_before = co.debug_set_static_list_max_k(0)  # every system of this test runs the listed pipeline
+    env_before = os.environ.get("TM_AMD_GROUP_THREADS")
+    os.environ["TM_AMD_GROUP_THREADS"] = threads
+    try:
+        alone, grouped = contexts(), contexts()
+        for c, _, _ in alone:
+            c.multiple_steps(n_steps, 0)
+            c.multiple_steps(9, 0)
+        co.multiple_steps_group([c for c, _, _ in grouped], n_steps)
+        co.multiple_steps_group([c for c, _, _ in grouped], 9)
+        builds = []
+        for (a, bps_a, mv_a), (g, bps_g, mv_g) in zip(alone, grouped):
+            np.testing.assert_array_equal(a.get_x_t(), g.get_x_t())
+            np.testing.assert_array_equal(a.get_v_t(), g.get_v_t())
+            np.testing.assert_array_equal(a.get_box(), g.get_box())
+            assert mv_a[0].get_counters() == mv_g[0].get_counters()
+            assert mv_a[0].get_volume_scale_factor() == mv_g[0].get_volume_scale_factor() != 0.0  # the barostats did attempt moves inside the grouped call
+            builds.append(_nonbonded_all_pairs_of(bps_g).get_build_count())
+        assert min(builds) >= 4  # ... and the lists were rebuilt inside it (not a static list)
+        assert not np.array_equal(alone[0][0].get_x_t(), alone[1][0].get_x_t())
+    finally:
+        co.debug_set_static_list_max_k(static_before)
+        if env_before is None:
+            del os.environ["TM_AMD_GROUP_THREADS"]
+        else:
+            os.environ["TM_AMD_GROUP_THREADS"] = env_before
+
+
+def _nonbonded_all_pairs_of(bound_impls):
+    """the NonbondedAllPairs implementation inside a list of bound potentials (directly, or as a child of a Fanout / Summed potential)"""
+    def walk(p):
+        name = type(p).__name__
+        if name.startswith("NonbondedAllPairs"):
+            return p
+        if hasattr(p, "get_potentials"):
+            for c in p.get_potentials():
+                r = walk(c)
+                if r is not None:
+                    return r
+        return None
+
+    for bp in bound_impls:
+        r = walk(bp.get_potential())
+        if r is not None:
+            return r
+    raise AssertionError("no NonbondedAllPairs among the bound potentials")
+
+
+def test_md_on_the_row_block_kernel_is_bitwise_md_on_the_item_kernel(co, P):
+    """(variant library only: tests/test_gpu_second_binding.py)  MD with every forces-only launch on the row-block kernel against the
+    same run on the wave-per-item kernel: the two implementations of the reference's tile kernel hand the integrator identical
+    forces step after step -- 2 243 atoms on the listed pipeline over 120 steps, and 23 559 atoms over 30."""
+    if not co.debug_rowblock_available():
+        pytest.skip("the row-block kernel is in the variant library only")
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator
+
+    static_before = co.debug_set_static_list_max_k(0)
+    try:
+        for s, n_steps, precision in ((ts.small_solvated_ligand(lamb=0.2), 120, np.float32), (ts.small_solvated_ligand(lamb=0.2), 120, np.float64), (ts.dhfr_shaped_box(), 30, np.float64)):
+            x0 = s.coords.astype(np.float32).astype(np.float64)
+            out = []
+            for min_k in (2**31 - 1, 0):
+                before = co.debug_set_rowblock_min_k(min_k)
+                try:
+                    bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s, precision)]
+                    c = co.Context(x0, np.zeros_like(x0), s.box, LangevinIntegrator(300.0, 1.0e-3, 5.0, s.masses, 3).impl(), bps)
+                    c.multiple_steps(n_steps, 0)
+                    out.append((c.get_x_t(), c.get_v_t()))
+                finally:
+                    co.debug_set_rowblock_min_k(before)
+            np.testing.assert_array_equal(out[0][0], out[1][0])
+            np.testing.assert_array_equal(out[0][1], out[1][1])
+    finally:
+        co.debug_set_static_list_max_k(static_before)
 
 
 def test_step_replicas_groups_of_two_equal_sequential_stepping(co, P):

@@ -96,7 +96,8 @@ def build_binding(verbose=True):
 def build(force=False, verbose=True):
     stamp_file = os.path.join(HERE, ".build_stamp")
     stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(BINDING) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    if (not force and os.path.exists(LIB) and os.path.exists(BINDING) and os.path.exists(os.path.join(HERE, "libtimemachine_amd_rowblock.so"))
+            and os.path.exists(stamp_file) and open(stamp_file).read() == stamp):
         return LIB
     objs = []
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -112,6 +113,9 @@ def build(force=False, verbose=True):
         print(r.stdout + r.stderr, file=sys.stderr)
         raise RuntimeError("link failed")
     build_binding(verbose)
+    # the parity tests' variant library: the product objects + nonbonded.hip once more with the row-block kernel compiled in
+    # (a second, independent implementation of the tile kernel that the GPU suite compares bit for bit; not in the product)
+    build_variant("rowblock", ["TM_ROWBLOCK"], only=("nonbonded.hip",))
     with open(stamp_file, "w") as fh:
         fh.write(stamp)
     return LIB

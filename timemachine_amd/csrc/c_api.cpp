@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <set>
 
@@ -39,6 +40,12 @@ struct tm_hilbert_sort_s {
 };
 
 static thread_local std::string g_last_error;
+
+// Streams of a stepped-together group of contexts (tm_context_multiple_steps_group) need hardware queues of their own; the HIP
+// runtime creates GPU_MAX_HW_QUEUES (default 4) per process and reads the variable when it first touches the device.  Exported
+// when the library is loaded -- before any HIP call made through this library -- unless the user chose a number; a C-ABI
+// consumer that never imports the Python package gets the same behaviour as the Python binding (include/timemachine_amd.h).
+__attribute__((constructor)) static void tm_export_hw_queue_count() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // Threading contract of the C ABI: every entry point runs under ONE process-wide lock.  The objects behind the handles keep
 // host-side state between calls (pre-gathered inputs, piggy-backed tables, launch parities, uploaded plans) and the reference
@@ -872,7 +879,14 @@ int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
     if (previous) {
         *previous = g_rowblock_min_k;
     }
+    require(g_rowblock_built || min_atoms == std::numeric_limits<int>::max(),
+            "the row-block kernel is not built into this library (load the variant libtimemachine_amd_rowblock.so: TM_AMD_LIB)");
     g_rowblock_min_k = min_atoms;
+    TM_CATCH
+}
+int tm_debug_rowblock_available(int *available) {
+    TM_TRY
+    *available = g_rowblock_built ? 1 : 0;
     TM_CATCH
 }
 int tm_profile_set_enabled(int enabled) {

@@ -508,6 +508,7 @@ void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool
 
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
 extern int g_rowblock_min_k;     // forces-only launches over at least this many atoms run the row-block kernel (tm_debug_set_rowblock_min_k)
+extern const bool g_rowblock_built; // ... which only libraries built with -DTM_ROWBLOCK carry (the variant library of the parity tests)
 extern int g_static_list_max_k;  // potentials over at most this many atoms keep a static, complete list (tm_debug_set_static_list_max_k)
 
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
@@ -774,6 +775,9 @@ public:
     // false only when the last move() call provably left coordinates and box untouched (off-interval call); the
     // Context drops the potentials' pre-gathered inputs otherwise
     bool acted_last_call() const { return acted_; }
+    // the bound potentials this mover evaluates on its own (a barostat's energy evaluations run in THEIR neighbor lists and
+    // accumulators): Context::multiple_steps_group counts them as device state of the mover's context
+    virtual std::vector<std::shared_ptr<BoundPotential>> held_potentials() const { return {}; }
 protected:
     explicit Mover(const int interval) : interval_(interval), step_(0) {}
     int interval_;
@@ -789,6 +793,7 @@ template <typename Real> class MonteCarloBarostat : public Mover {
 public:
     MonteCarloBarostat(const int N, const double pressure, const double temperature, const std::vector<std::vector<int>> &group_idxs, const int interval, const std::vector<std::shared_ptr<BoundPotential>> &bps, const int seed, const bool adaptive_scaling_enabled, const double initial_volume_scale_factor);
     void move(const int N, double *d_x, double *d_box, hipStream_t stream) override;
+    std::vector<std::shared_ptr<BoundPotential>> held_potentials() const override { return bps_; }
     double get_volume_scale_factor();
     void set_volume_scale_factor(const double volume_scale_factor);
     bool get_adaptive_scaling() const { return adaptive_; }
@@ -867,8 +872,8 @@ public:
     void initialize();
     void finalize();
     void multiple_steps(const int n_steps, const int n_samples, double *h_x, double *h_box);
-    // n_steps of SEVERAL contexts, interleaved step by step on the contexts' own streams (one host thread feeds them all): the
-    // device then runs one context's list / update kernels and kernel boundaries underneath another's force kernel.  Two
+    // n_steps of SEVERAL contexts, interleaved step by step on streams of their own (fed by one or two enqueueing host threads,
+    // TM_AMD_GROUP_THREADS): the device then runs one context's list / update kernels and kernel boundaries underneath another's force kernel.  Two
     // DHFR-sized replicas step at 59.5 us each this way against 69.6 us alone (free-energy windows and HREX replicas that share a
     // GPU).  Same trajectories as n_steps of multiple_steps on each: the contexts share nothing.
     // No frames are stored (as multiple_steps with store_x_interval = 0).  The contexts must be distinct objects.

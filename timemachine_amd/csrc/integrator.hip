@@ -657,8 +657,15 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
             owned[k].push_back(ctxts[k]->intg_.get());
             for (auto &m : ctxts[k]->movers_) {
                 owned[k].push_back(m.get());
+                // ... and whatever the mover evaluates on its own: a barostat built on ANOTHER context's bound potentials would
+                // run its energy launches in that context's neighbor list and accumulators, on this context's stream
+                for (auto &bp : m->held_potentials()) {
+                    owned[k].push_back(bp.get());
+                    collect_objects(bp->potential, owned[k]);
+                }
             }
             std::sort(owned[k].begin(), owned[k].end());
+            owned[k].erase(std::unique(owned[k].begin(), owned[k].end()), owned[k].end());
         }
         for (size_t a = 0; a < ctxts.size(); a++) {
             for (size_t b = a + 1; b < ctxts.size(); b++) {
@@ -698,11 +705,18 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
         }
         // Enqueueing a step costs the host 6-10 us (two or three launches and the plan's bookkeeping): plenty of slack against a
         // 55 us DHFR-sized replica-step, but for small systems (8 us per replica-step on the device at 2.2k atoms) one launching
-        // thread is the limit.  So the contexts are dealt to up to TM_AMD_GROUP_THREADS (default 2) host threads, each feeding its own
-        // contexts' streams; the contexts share nothing, so the threads need no coordination beyond the join.
+        // thread is the limit.  So the contexts are dealt to up to TM_AMD_GROUP_THREADS host threads, each feeding its own
+        // contexts' streams; the contexts share nothing, so the threads need no coordination beyond the join.  Default: two
+        // threads while every context is small (<= 5000 atoms), one above -- there the second thread measured nothing (55.0 us per
+        // DHFR-sized replica-step either way) and a multi-GPU node has 2 CPUs per rank to give (16-CPU quota, 8 ranks).
         const auto t_enqueue = std::chrono::steady_clock::now();
         const char *e_threads = std::getenv("TM_AMD_GROUP_THREADS");
-        size_t n_threads = std::min<size_t>(ctxts.size(), static_cast<size_t>(std::max(1, e_threads ? std::atoi(e_threads) : 2)));
+        int largest = 0;
+        for (const Context *c : ctxts) {
+            largest = std::max(largest, c->N_);
+        }
+        const int default_threads = largest <= 5000 ? 2 : 1;
+        size_t n_threads = std::min<size_t>(ctxts.size(), static_cast<size_t>(std::max(1, e_threads ? std::atoi(e_threads) : default_threads)));
         if (Profiler::get().enabled()) {
             n_threads = 1; // the per-launch profiler keeps its events in one unsynchronised table
         }

@@ -205,6 +205,8 @@ __global__ __launch_bounds__(RB_THREADS, (RB_WAVES * RB_WGS_PER_CU) / 4) void k_
     };
     __shared__ Lds lds;
     __shared__ __attribute__((aligned(16))) double s_es_tab[F64 ? ES_TAB_DOUBLES : 2];
+    // two workgroups per CU share its 160 KB; a workgroup's static allocation is what the launch asks for (TM_TIMING adds 48 B)
+    static_assert(sizeof(Lds) + (F64 ? ES_TAB_DOUBLES : 2) * sizeof(double) + 64 <= 64 * 1024, "row-block kernel: static LDS beyond 64 KB (RB_UCAP / RB_MAX_ROW_BLOCKS)");
 
     const int tid = static_cast<int>(threadIdx.x);
     const int lane = tid & 63;
@@ -430,6 +432,9 @@ __global__ __launch_bounds__(RB_THREADS, (RB_WAVES * RB_WGS_PER_CU) / 4) void k_
         // ---- phase 1: the row masks of this wave's slices
         const Real ox = rows.row[0][0], oy = rows.row[1][0], oz = rows.row[2][0];
         const float rext = rows.rext, w0 = rows.w0;
+        // (read while faster waves of this unit may already be OR-ing their slices' bits in, below: which filter form a wave takes
+        // can therefore depend on timing -- but never a result: the flat and the general Gram form are both conservative supersets
+        // of the exact `d2 < cutoff^2` test that phase 2 makes, and a flag only ever switches a wave to the MORE general form)
         const bool rows_flat = (rows.flags & 2u) == 0u;
         float ra_[5], rb_[5]; // rows (lane & 15) and 16 + (lane & 15): x y z w |r|^2
 #pragma unroll

@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include "kernels_nblist.hip.hpp"
+#ifdef TM_ROWBLOCK // the row-block kernel is a test / A-B artefact: built into the variant library libtimemachine_amd_rowblock.so only
 #include "kernels_nonbonded_rowblock.hip.hpp"
+#endif
 #include "profiler.hpp"
 
 #include <rocprim/rocprim.hpp>
@@ -597,16 +599,21 @@ template <typename Real> void NonbondedAllPairs<Real>::allocate() {
 int g_static_list_max_k = std::getenv("TM_AMD_STATIC_LIST_MAX_K") ? std::atoi(std::getenv("TM_AMD_STATIC_LIST_MAX_K")) : TM_STATIC_LIST_MAX_K;
 template <typename Real> int NonbondedAllPairs<Real>::static_list_max_k() { return g_static_list_max_k; }
 // Forces-only launches over at least this many atoms run the row-block kernel (kernels_nonbonded_rowblock.hip.hpp: one workgroup
-// per (row block, <= 1024 listed columns), lane-owned columns regrouped by hit count).  OFF by default (INT_MAX): round 4 built it as
-// the re-decomposition of the tile kernel, it passes the whole GPU suite bit for bit, and it measures 74 us per launch against the
-// item kernel's 55 on the DHFR-shaped box (EXPERIMENTS.md, "row-block kernel": the pair loop of BOTH kernels runs at ~65 % of its
-// VALU bound, the row-block form's trips are 77 % occupied against the queue's 95 %, and its barrier phases and 2.4 units per
-// workgroup cost what its cheaper filter saves).  Kept selectable for A/B runs and as the second, independent implementation the
-// parity tests compare bit for bit.
+// per (row block, <= 1024 listed columns), lane-owned columns regrouped by hit count) -- IN LIBRARIES BUILT WITH -DTM_ROWBLOCK
+// (csrc/build.py builds libtimemachine_amd_rowblock.so; the product library does not carry the kernel: round 4 built it as the
+// re-decomposition of the tile kernel, it passes the whole GPU suite bit for bit and measures 74 us per launch against the item
+// kernel's 55 on the DHFR-shaped box, EXPERIMENTS.md "row-block kernel").  Its value is that of a second, independent
+// implementation the parity tests compare bit for bit (tests/test_gpu_second_binding.py runs them against the variant library).
 #ifndef TM_ROWBLOCK_MIN_K
 #define TM_ROWBLOCK_MIN_K 2147483647
 #endif
+#ifdef TM_ROWBLOCK
+const bool g_rowblock_built = true;
 int g_rowblock_min_k = std::getenv("TM_AMD_ROWBLOCK_MIN_K") ? std::atoi(std::getenv("TM_AMD_ROWBLOCK_MIN_K")) : TM_ROWBLOCK_MIN_K;
+#else
+const bool g_rowblock_built = false;
+int g_rowblock_min_k = TM_ROWBLOCK_MIN_K;
+#endif
 
 template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::vector<int> &atom_idxs) {
     verify_atom_idxs(N_, atom_idxs);
@@ -896,6 +903,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
         // MD: the f64 kernel has a form for cutoffs that do not reach beyond the end of the electrostatic switch (all of the
         // reference's callers: cutoff == 1.2 nm); see INSIDE_SWITCH.
         const bool inside = sizeof(Real) == 8 && cutoff_ <= TM_ES_SWITCH_D;
+#ifdef TM_ROWBLOCK
         if (K_ >= g_rowblock_min_k && nblist_.num_row_blocks() <= RB_MAX_ROW_BLOCKS) {
             // large systems: one workgroup per (row block, column range) unit, see kernels_nonbonded_rowblock.hip.hpp
 #define TM_LAUNCH_ROWBLOCKS(INSIDE)                                                                                    \
@@ -911,7 +919,9 @@ void NonbondedAllPairs<Real>::run_pipeline(
                 TM_LAUNCH_ROWBLOCKS(false);
             }
 #undef TM_LAUNCH_ROWBLOCKS
-        } else if (inside) {
+        } else
+#endif
+        if (inside) {
             if constexpr (sizeof(Real) == 8) {
                 if (split == 4) {
                     TM_LAUNCH_TILES(false, true, false, true, 4);

@@ -10,14 +10,15 @@
 namespace tmamd {
 
 int device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
+    // (a function-local static with an initialiser: C++11 makes the first call thread-safe -- the enqueueing threads of
+    // Context::multiple_steps_group may construct nothing, but nothing here should depend on that)
+    static const int cus = []() {
         int dev = 0;
         HIP_CHECK(hipGetDevice(&dev));
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
     return cus;
 }
 

@@ -1151,6 +1151,11 @@ void declare_functions(py::module &m) {
             return previous;
         },
         py::arg("min_atoms"));
+    m.def("debug_rowblock_available", []() { // does the loaded library carry the row-block kernel (the variant library of the parity tests)?
+        int yes = 0;
+        check(tm_debug_rowblock_available(&yes));
+        return yes != 0;
+    });
     m.def("debug_check_guards", []() { // -DTM_GUARD builds: violated guard zones so far; -1 in product builds
         int n = 0;
         check(tm_debug_check_guards(&n));

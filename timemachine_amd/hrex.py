@@ -105,8 +105,12 @@ def step_replicas(contexts, n_steps: int, group: int = 4):
     `custom_ops.multiple_steps_group` -- their steps interleaved on streams of their own, so that one replica's neighbor-list and
     integrator kernels (a quarter of a step, latency-bound) run underneath another's force kernel: two DHFR-sized replicas step at
     59.5 us each instead of 69.6, four at 55.0.  Trajectories are those of separate `multiple_steps` calls,
-    bit for bit.  The reference steps a device's windows one after the other (fe/free_energy.py:1537-1551)."""
+    bit for bit; a group whose contexts share a potential, integrator or mover object (refused by the grouped call) is stepped
+    one context after the other instead.  The reference steps a device's windows one after the other
+    (fe/free_energy.py:1537-1551)."""
     contexts = list(contexts)
+    if not contexts:
+        return  # a rank that owns no replica (more ranks than windows)
     grouped = getattr(contexts[0], "multiple_steps", None) is not None and group > 1 and len(contexts) > 1
     co = None
     if grouped:
@@ -119,7 +123,16 @@ def step_replicas(contexts, n_steps: int, group: int = 4):
             c.multiple_steps(n_steps, 0)
         return
     for k in range(0, len(contexts), group):
-        co.multiple_steps_group(contexts[k:k + group], n_steps)
+        chunk = contexts[k:k + group]
+        try:
+            co.multiple_steps_group(chunk, n_steps)
+        except RuntimeError as e:
+            # contexts that share device state (the reference's bind-one-potential-many-times pattern, a shared integrator):
+            # the call refuses them BEFORE anything is enqueued -- step them one call after the other, which is always valid
+            if "share a potential, integrator or mover" not in str(e):
+                raise
+            for c in chunk:
+                c.multiple_steps(n_steps, 0)
 
 
 def verify_and_sanitize_potential_matrix(U_kl, replica_idx_by_state, abs_energy_threshold: float = 1e9):

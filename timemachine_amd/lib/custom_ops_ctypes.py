@@ -1060,11 +1060,19 @@ def multiple_steps_group(contexts, n_steps):
 
 
 def debug_set_rowblock_min_k(min_atoms):
-    """A/B aid: forces-only nonbonded launches over at least `min_atoms` atoms run the row-block kernel (0: always); -> the old
-    value.  Results are bit-identical either way."""
+    """A/B aid (variant library libtimemachine_amd_rowblock.so only; the product library refuses anything but INT_MAX): forces-only
+    nonbonded launches over at least `min_atoms` atoms run the row-block kernel (0: always); -> the old value.  Results are
+    bit-identical either way."""
     prev = _c_int(0)
     _check(_lib.tm_debug_set_rowblock_min_k(_c_int(int(min_atoms)), ctypes.byref(prev)))
     return prev.value
+
+
+def debug_rowblock_available():
+    """does the loaded library carry the row-block kernel (libtimemachine_amd_rowblock.so, the parity tests' variant library)?"""
+    yes = _c_int(0)
+    _check(_lib.tm_debug_rowblock_available(ctypes.byref(yes)))
+    return bool(yes.value)
 
 
 def profile_set_enabled(enabled):
