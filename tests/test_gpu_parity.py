@@ -1473,3 +1473,18 @@ def test_group_stepping_refuses_contexts_that_share_device_state(co, P):
     c3, c4 = (co.Context(s.coords, v0, s.box, shared_intg, fresh[k]) for k in range(2))
     with pytest.raises(RuntimeError, match="share a potential, integrator or mover"):
         co.multiple_steps_group([c3, c4], 5)
+    # a barostat evaluates ITS bound potentials: one built on another context's list would run in that context's neighbor list
+    from timemachine_amd.lib import MonteCarloBarostat
+
+    own = [[bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)] for _ in range(2)]
+    foreign_barostat = MonteCarloBarostat(s.num_atoms, 1.0, 300.0, ts.molecule_groups(s), 5, 3).impl(own[1])
+    c5 = co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 4).impl(), own[0], movers=[foreign_barostat])
+    c6 = co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 5).impl(), own[1])
+    with pytest.raises(RuntimeError, match="share a potential, integrator or mover"):
+        co.multiple_steps_group([c5, c6], 5)
+    # hrex.step_replicas falls back to one call after the other for such a group instead of failing
+    from timemachine_amd import hrex
+
+    hrex.step_replicas([c5, c6], 5, group=2)
+    hrex.step_replicas([], 5)
+    assert np.all(np.isfinite(c5.get_x_t())) and np.all(np.isfinite(c6.get_x_t()))

@@ -113,6 +113,16 @@ template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(double
     }
 }
 template <bool SKIP_W = false> __device__ __forceinline__ void lds_wait14(float (&)[7], float (&)[7]) {}
+// experiment (TM_SPLIT_WAIT, flat items): the six coordinate reads are issued first and waited for alone -- LDS returns in order --, so
+// the displacement and d^2 issue while charge, sigma and epsilon are still on their way
+__device__ __forceinline__ void lds_wait_first6_of12(double (&a)[7], double (&b)[7]) {
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+}
+__device__ __forceinline__ void lds_wait_first6_of12(float (&)[7], float (&)[7]) {}
+__device__ __forceinline__ void lds_wait_rest6(float (&)[7], float (&)[7]) {}
+__device__ __forceinline__ void lds_wait_rest6(double (&a)[7], double (&b)[7]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]));
+}
 // branch-probability hint for the block placement of the f64 kernels (measured: +0.5 % there, -2 % on the f32 kernels)
 template <bool ON> __device__ __forceinline__ bool hint(const bool c, const bool expected) {
     if constexpr (ON) {
@@ -1082,6 +1092,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 asm volatile("" : : "v"(d_));
             }
 #endif
+#ifdef TM_SETPRIO
+            __builtin_amdgcn_s_setprio(TM_SETPRIO); // experiment: a wave inside its batch (one long dependent chain) issues ahead of its SIMD neighbours' filter rounds
+#endif
             if (active) {
                 // a queue entry is (round << 11) | column lane: the row slot follows from the round's lane arrangement
                 const unsigned int e = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short *>(static_cast<unsigned long>(entry_addr));
@@ -1094,9 +1107,21 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     // 64 banks).  Left to itself the compiler pairs them into ds_read2_b64, which the LDS serves at half that rate
                     // (MI355X_MICROARCH.md, LDS table: 8 cycles per wave instruction against 2 + 2).
                     // (one base register: the column array's distance from the row array rides in the instructions' offset fields)
+#if defined(TM_ABLATE) && (TM_ABLATE == 10 || TM_ABLATE == 13) // ablation (timing only): operand reads at conflict-free addresses
+                    const unsigned int ra = lds_offset(&s_row[0][0]) + static_cast<unsigned int>(lane & 31) * 8u, ca = lds_offset(&s_row[0][0]) + static_cast<unsigned int>(lane) * 8u;
+#else
                     const unsigned int ra = lds_offset(&s_row[0][0]) + pi * 8u, ca = lds_offset(&s_row[0][0]) + pj * 8u;
+#endif
                     lds_read14<0, TILE * 8, NB_CHUNK * 8, static_cast<int>(offsetof(WaveLds, col) - offsetof(WaveLds, row)), FLAT>(ra, ca, ri, cj);
+#ifdef TM_SPLIT_WAIT
+                    if constexpr (FLAT) {
+                        lds_wait_first6_of12(ri, cj);
+                    } else {
+                        lds_wait14<FLAT>(ri, cj);
+                    }
+#else
                     lds_wait14<FLAT>(ri, cj);
+#endif
                 } else {
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
@@ -1117,6 +1142,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 // (flat items: w_i - w_j == +0 and fma(0, 0, s) == s, so leaving the term out changes no bit)
                 const Real ddw = FLAT ? static_cast<Real>(0) : ri[3] - cj[3];
                 const Real dd2 = FLAT ? fma_real(ddz, ddz, fma_real(ddy, ddy, ddx * ddx)) : pair_d2(ddx, ddy, ddz, ddw);
+#ifdef TM_SPLIT_WAIT
+                if constexpr (sizeof(Real) == 8 && TM_LDS_SINGLE_READS && FLAT) {
+                    lds_wait_rest6(ri, cj);
+                }
+#endif
                 if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
                 const Real qi = ri[4], qj = cj[4];
                 const Real sig_i = ri[5], sig_j = cj[5], eps_i = ri[6], eps_j = cj[6];
@@ -1134,12 +1164,17 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                             pair_force_fixed_slow(p, ddx, ddy, ddz, fx, fy, fz);
                         }
                     }
-                    lds_add(&s_fi[0][pi], fx);
-                    lds_add(&s_fi[1][pi], fy);
-                    lds_add(&s_fi[2][pi], fz);
-                    lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
-                    lds_sub(&s_fj[1][pj], fy);
-                    lds_sub(&s_fj[2][pj], fz);
+#if defined(TM_ABLATE) && (TM_ABLATE == 12 || TM_ABLATE == 13) // ablation (timing only): the six accumulations at conflict-free addresses
+                    const unsigned int api = static_cast<unsigned int>(lane & 31), apj = static_cast<unsigned int>(lane);
+#else
+                    const unsigned int api = pi, apj = pj;
+#endif
+                    lds_add(&s_fi[0][api], fx);
+                    lds_add(&s_fi[1][api], fy);
+                    lds_add(&s_fi[2][api], fz);
+                    lds_sub(&s_fj[0][apj], fx); // FIX(-p d) == -FIX(p d)
+                    lds_sub(&s_fj[1][apj], fy);
+                    lds_sub(&s_fj[2][apj], fz);
                 } else {
                 PairOut<Real> o;
                 nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
@@ -1174,6 +1209,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 } // forces only / everything else
                 } // exact cutoff test
             }
+#ifdef TM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         // ---- one group: four rounds of phase 1, then phase 2 on every full batch of 64 queued pairs (LAST: on everything left).
         // FAST: flat Gram items off the diagonal -- almost every item of a production system.

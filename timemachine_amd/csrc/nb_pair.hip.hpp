@@ -175,6 +175,25 @@ __device__ __attribute__((noinline, cold)) double es_force_factor_below_table(co
     return inv * real_es_factor(beta, d2 * inv, inv, inv * inv, damping);
 }
 
+// the degree-5 polynomial of one table interval at in-interval position t.  ONE definition for every kernel and both tables
+// (excluded pairs cancel bit for bit only if every call site rounds alike).
+__device__ __forceinline__ double es_tab_poly(const double (&c)[ES_TAB_COEFFS], const double t) {
+#ifdef TM_ESTRIN
+    // Estrin: three dependent levels instead of Horner's five (one multiplication more)
+    const double t2 = t * t;
+    const double a = __builtin_fma(c[1], t, c[0]);
+    const double b = __builtin_fma(c[3], t, c[2]);
+    const double e = __builtin_fma(c[5], t, c[4]);
+    return __builtin_fma(__builtin_fma(e, t2, b), t2, a);
+#else
+    double p = __builtin_fma(c[5], t, c[4]);
+    p = __builtin_fma(p, t, c[3]);
+    p = __builtin_fma(p, t, c[2]);
+    p = __builtin_fma(p, t, c[1]);
+    return __builtin_fma(p, t, c[0]);
+#endif
+}
+
 // F(d2) such that the electrostatic force prefactor of a pair is charge_scale * q_i q_j * F(d2): the table part, without a
 // branch.  `below` says that d2 lies under the table (the caller owes the analytic form; the value returned is then 0).
 // INSIDE_SWITCH: the caller knows d2 < TM_ES_SWITCH_D^2 (its cutoff is not beyond the end of the switch): d2 can then only
@@ -189,12 +208,12 @@ template <bool INSIDE_SWITCH = false, typename Tab> __device__ __forceinline__ d
         idx = outside ? 0u : idx;
     }
     double c[ES_TAB_COEFFS];
+#if defined(TM_ABLATE) && (TM_ABLATE == 11 || TM_ABLATE == 13) // ablation (timing only): table reads at conflict-free addresses (16 consecutive intervals per lane group)
+    tab.load(static_cast<unsigned int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) & 15u, c);
+#else
     tab.load(idx, c);
-    double p = __builtin_fma(c[5], t, c[4]);
-    p = __builtin_fma(p, t, c[3]);
-    p = __builtin_fma(p, t, c[2]);
-    p = __builtin_fma(p, t, c[1]);
-    p = __builtin_fma(p, t, c[0]);
+#endif
+    const double p = es_tab_poly(c, t);
     if constexpr (INSIDE_SWITCH) {
         below = outside;
         return p;
@@ -232,11 +251,7 @@ template <typename Tab> __device__ __forceinline__ double es_energy_factor(const
     idx = outside ? 0u : idx;
     double c[ES_TAB_COEFFS];
     tab.load_g(idx, c);
-    double p = __builtin_fma(c[5], t, c[4]);
-    p = __builtin_fma(p, t, c[3]);
-    p = __builtin_fma(p, t, c[2]);
-    p = __builtin_fma(p, t, c[1]);
-    p = __builtin_fma(p, t, c[0]);
+    const double p = es_tab_poly(c, t);
     const double switch_end2 = static_cast<double>(TM_ES_SWITCH_D) * static_cast<double>(TM_ES_SWITCH_D);
     double g = (d2 < switch_end2 && !outside) ? p : 0.0; // beyond the switch the damping function is exactly zero
     const bool below = outside && d2 < static_cast<double>(TM_ES_TAB_S_MIN);
@@ -257,6 +272,29 @@ __device__ __forceinline__ double nb_pair_prefactor_deferred(
     const double charge_scale, const double lj_scale, const double qi, const double qj, const double sig_i, const double sig_j,
     const double eps_i, const double eps_j, const double d2ij, const Tab &tab, bool &below) {
     const double qij = qi * qj;
+#ifdef TM_LJ_EARLY
+    // experiment: the table's LDS reads are ISSUED first, the Lennard-Jones chain (rcp + nine dependent multiplications, written
+    // without a branch) runs underneath their round trip, the polynomial follows; the same operations on the same operands for
+    // the lanes that have an LJ term, a select for the others: same bits
+    if constexpr (INSIDE_SWITCH) {
+        double t;
+        unsigned int idx = es_tab_index(d2ij, t);
+        below = idx >= static_cast<unsigned int>(ES_TAB_INTERVALS);
+        idx = idx < static_cast<unsigned int>(ES_TAB_INTERVALS) ? idx : static_cast<unsigned int>(ES_TAB_INTERVALS - 1);
+        double c[ES_TAB_COEFFS];
+        tab.load(idx, c);
+        const double inv_d2 = tm_rcp_f64(d2ij);
+        const double eps_ij = eps_i * eps_j;
+        const double sig_ij = sig_i + sig_j;
+        const double sig2 = (sig_ij * sig_ij) * inv_d2;
+        const double sig4 = sig2 * sig2;
+        const double sig6 = sig4 * sig2;
+        const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2) * (sig6 * 48 - 24);
+        const bool has_lj = eps_i != 0 && eps_j != 0;
+        const double es_prefactor = charge_scale * qij * es_tab_poly(c, t);
+        return has_lj ? es_prefactor - lj_prefactor : es_prefactor;
+    }
+#endif
     const double es_prefactor = charge_scale * qij * es_force_factor_table<INSIDE_SWITCH>(d2ij, tab, below);
     const double inv_d2ij = tm_rcp_f64(d2ij);
     double prefactor = es_prefactor;
