@@ -203,6 +203,9 @@ int tm_barostat_get_adaptive_scaling(tm_mover_t mover, int *enabled);
 int tm_barostat_set_pressure(tm_mover_t mover, double pressure);
 /* diagnostic (not in the reference surface): acceptance counters since the last adaptive reset */
 int tm_barostat_get_counters(tm_mover_t mover, int *accepted, int *attempted);
+/* diagnostic (not in the reference surface): attempts since construction, and how many of them ran on the nonbonded potential's
+ * current list (csrc/barostat.hip, "the fast path"; tm_debug_set_barostat_fast_path) */
+int tm_barostat_get_attempt_paths(tm_mover_t mover, long long *attempts, long long *fast);
 int tm_context_destroy(tm_context_t ctxt);
 int tm_context_num_atoms(tm_context_t ctxt, int *N);
 int tm_context_step(tm_context_t ctxt);
@@ -285,6 +288,12 @@ int tm_profile_reset(void);
  * (EXPERIMENTS.md, History, item 6).  0 turns that off process-wide (every box change rebuilds, as in the reference);
  * results are bit-identical either way -- the test suite checks exactly that. */
 int tm_debug_set_box_scaling_reuse(int enabled);
+/* debugging / A-B aid: a MonteCarloBarostat attempt inside a Context evaluates both energies on the nonbonded potential's CURRENT
+ * neighbor list and sorted records and commits an accepted proposal into them (four launches + the list launch; csrc/barostat.hip)
+ * whenever the potentials' state allows; 0 = always the reference-shaped attempt (barostat.cu:154-246: copy, centroids, rescale, two
+ * full evaluations, decision).  Process-wide; *previous (may be NULL) receives the old value.  Energies, decisions and trajectories
+ * are bit-identical either way. */
+int tm_debug_set_barostat_fast_path(int enabled, int *previous);
 /* debugging / A-B aid: nonbonded potentials over at most `max_atoms` atoms keep a STATIC, complete interaction list (every column
  * block listed for every row block: nothing can invalidate it, no list kernel runs on MD steps; EXPERIMENTS.md, History, item 11).
  * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.

@@ -247,3 +247,54 @@ def test_box_scaling_keeps_the_neighbor_list_valid(co, relaxed, precision, inter
     assert counters_a == counters_b and counters_a[1] == 600 // interval and counters_a[0] > 0
     assert not np.array_equal(boxes_a[-1], s.box)
     assert builds_a < builds_b, (builds_a, builds_b)
+
+
+@pytest.mark.parametrize("precision", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["listed_2k", "static_2k", "dhfr_shaped", "big_molecule"])
+def test_attempts_on_the_current_list_are_bitwise_the_reference_shaped_attempts(co, relaxed, which, precision):
+    """Inside a Context a barostat attempt runs on the nonbonded potential's CURRENT neighbor list and sorted records whenever the
+    last MD step left them in place (csrc/barostat.hip, "the fast path": proposal + list-validity test in one launch, two energy
+    launches, decision + commit of an accepted proposal into the pre-gathered state).  Energies are the same integers, so every
+    decision, every box and every trajectory must equal the reference-shaped attempt's (barostat.cu:154-246: copy, centroids,
+    rescale, two full evaluations, decision) bit for bit -- on the listed pipeline (rebuilds, re-sorts, proposals that the list must
+    be rebuilt for), on the static complete list of small systems, at the bench workload's size, at high pressure (steady
+    compression: the accumulated box scale runs into its limit and forces rebuilds), and with one molecule larger than the
+    in-thread centroid limit (its centroid comes from the segmented-scan kernel)."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    if which == "dhfr_shaped":
+        s = ts.dhfr_shaped_box()
+        x, v = s.coords.astype(np.float32).astype(np.float64), np.zeros_like(s.coords)
+        groups, n_steps, interval, dt, friction, pressure, padding, static_k = ts.molecule_groups(s), 150, 5, 1.0e-3, 10.0, 1.0, 0.18, 0
+    else:
+        s, groups, x, v = relaxed
+        n_steps, interval, dt, friction, padding = 400, 3, 2.0e-3, 1.0, 0.1
+        pressure = 400.0 if which == "listed_2k" else 1.0
+        static_k = 4608 if which == "static_2k" else 0
+        if which == "big_molecule":  # the first 150 waters as ONE rigid group of 450 atoms (> the in-thread centroid limit)
+            groups = [list(range(450))] + [g for g in groups if g[0] >= 450]
+    N = s.num_atoms
+
+    def run(fast):
+        fast_before = co.debug_set_barostat_fast_path(fast)
+        static_before = co.debug_set_static_list_max_k(static_k)
+        try:
+            bps = [bp.to_gpu(precision).bound_impl for bp in ts.bound_potentials(s, precision, nblist_padding=padding)]
+            baro = MonteCarloBarostat(N, pressure, 300.0, groups, interval, 11).impl(bps)
+            ctxt = co.Context(x, v, s.box, LangevinIntegrator(300.0, dt, friction, s.masses, 9).impl(), bps, movers=[baro])
+            xs, boxes = ctxt.multiple_steps(n_steps, interval)
+            ctxt.multiple_steps(7, 0)  # (a call boundary: the first step of a call gathers for itself; attempts inside take either path)
+            return xs, boxes, ctxt.get_x_t(), ctxt.get_v_t(), ctxt.get_box(), baro.get_counters(), baro.get_volume_scale_factor(), baro.get_attempt_paths()
+        finally:
+            co.debug_set_barostat_fast_path(fast_before)
+            co.debug_set_static_list_max_k(static_before)
+
+    a, b = run(True), run(False)
+    for u, w in zip(a[:5], b[:5]):
+        np.testing.assert_array_equal(u, w)
+    assert a[5] == b[5] and a[6] == b[6]
+    attempts, fast = a[7]
+    assert attempts == (n_steps + 7) // interval and fast >= 0.9 * attempts, a[7]  # all but the attempts that meet a Hilbert re-sort
+    assert b[7] == (attempts, 0)
+    assert not np.array_equal(a[4], s.box)  # moves were accepted

@@ -7,9 +7,11 @@
 // cuRAND batch buffer (statistically equivalent, reproducible per seed on this implementation only).
 #include "engine.hpp"
 #include "fixed_point.hip.hpp"
+#include "nb_snapshot_test.hip.hpp"
 #include "philox.hip.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <iostream>
 #include <set>
 
@@ -175,6 +177,269 @@ __global__ void k_barostat_decide(
     }
 }
 
+// =============================================================================================================
+// The fast path (round 5): both energies of an attempt on the nonbonded potential's CURRENT neighbor list and sorted records.
+//
+// After an MD step the integrator's update kernel has left the nonbonded potential's next gather done (engine.hpp:
+// PregatherTarget): sorted records of x, the rebuild flag, the block bounds.  The reference-shaped attempt above throws that away
+// twice (the proposal's evaluation gathers x' over it, the next MD step gathers x or x' again): fifteen small launches around the
+// two energy launches.  Here the attempt is FOUR launches + the list launch:
+//   k_barostat_propose_probe   the proposal in one pass -- scale, molecule centroids (summed in-thread for molecules of up to
+//                              BAROSTAT_INLINE_MOL atoms), x' in atom order and as a second set of sorted records next to the
+//                              potential's own (ProbeTarget::gathered2), and the list-validity test of x' (raising the flag the list
+//                              launch reads: a proposal the current list cannot vouch for rebuilds it, from x, first)
+//   [k_find_ixns]              the list launch every evaluation makes (exits unless flagged)
+//   k_nonbonded_tiles x 2      energy-only, on (gathered, box) and on (gathered2, box'); the plan's bonded terms and exclusions ride
+//                              along; one partial sum per workgroup
+//   k_barostat_decide_commit   every workgroup adds up the partial sums for itself, makes the Metropolis decision (the arithmetic of
+//                              k_barostat_decide) and, on acceptance, commits the proposal INTO the pre-gathered state: x, box, the
+//                              sorted records, the next call's rebuild flag, the block bounds -- so that the next MD step finds its
+//                              inputs exactly as after an ordinary step (rejected: nothing was touched).
+// Same energies bit for bit (the same per-pair / per-term functions on the same operands, integer sums), hence the same decisions
+// and the same trajectories as the path above (tests/test_gpu_parity.py::test_barostat_follows_model_attempt_by_attempt,
+// tests/test_gpu_barostat_cases.py run on both paths).
+bool g_barostat_fast_path = std::getenv("TM_AMD_BAROSTAT_SLOW_PATH") == nullptr;
+static const int BAROSTAT_INLINE_MOL = 128; // molecules up to this size have their centroid summed by each of their atoms' threads
+
+// what the proposal is, from the attempt's Philox draw and the box: the arithmetic of k_barostat_propose
+template <typename Real> struct Proposal {
+    Real volume, delta, scale, u2;
+};
+template <typename Real>
+__device__ __forceinline__ Proposal<Real> draw_proposal(const int adaptive, const unsigned long long seed, const unsigned long long attempt, const double *__restrict__ box, const double volume_scale_now) {
+    unsigned int r[4];
+    philox4x32_10(static_cast<unsigned int>(attempt), static_cast<unsigned int>(attempt >> 32), 0x4241524fu, 0x53544154u,
+                  static_cast<unsigned int>(seed), static_cast<unsigned int>(seed >> 32), r);
+    const Real u1 = static_cast<Real>((static_cast<double>(r[0]) + 1.0) * (1.0 / 4294967296.0));
+    Proposal<Real> p;
+    p.u2 = static_cast<Real>((static_cast<double>(r[1]) + 1.0) * (1.0 / 4294967296.0));
+    p.volume = static_cast<Real>(box[0] * box[4] * box[8]);
+    const double vs = (adaptive && volume_scale_now == 0.0) ? 0.01 * p.volume : volume_scale_now; // first attempt: 1 % of the box volume
+    p.delta = static_cast<Real>(vs * 2 * (u1 - static_cast<Real>(0.5)));
+    const Real new_volume = p.volume + p.delta;
+    p.scale = cbrt(new_volume / p.volume);
+    return p;
+}
+
+template <typename Real, typename GReal>
+__global__ __launch_bounds__(256) void k_barostat_propose_probe(
+    const int N, const int adaptive, const unsigned long long seed, const unsigned long long attempt, const double *__restrict__ box,
+    double *__restrict__ volume_scale, Real *__restrict__ mv, double *__restrict__ box_proposed, const double *__restrict__ x,
+    double *__restrict__ x_proposed, const int *__restrict__ mol_of_atom, const int *__restrict__ mol_offsets, const int *__restrict__ atom_idxs,
+    const u64 *__restrict__ centroids, // sums of the molecules larger than BAROSTAT_INLINE_MOL (k_barostat_centroids ran first), else unused
+    const ProbeTarget t) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const double vs_now = *volume_scale;
+    const Proposal<Real> p = draw_proposal<Real>(adaptive, seed, attempt, box, vs_now);
+    double bp[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        bp[k] = box[k];
+    }
+    bp[0] *= p.scale;
+    bp[4] *= p.scale;
+    bp[8] *= p.scale;
+    if (a == 0) {
+        if (adaptive && vs_now == 0.0) {
+            *volume_scale = 0.01 * p.volume; // (every thread has formed the same value for itself)
+        }
+        mv[0] = p.volume;
+        mv[1] = p.delta;
+        mv[2] = p.scale;
+        mv[3] = p.u2;
+        for (int k = 0; k < 9; k++) {
+            box_proposed[k] = bp[k];
+        }
+    }
+    if (a >= N) {
+        return;
+    }
+    double xp[3] = {x[a * 3 + 0], x[a * 3 + 1], x[a * 3 + 2]};
+    const int m = mol_of_atom[a];
+    if (m >= 0) {
+        const int first = mol_offsets[m], last = mol_offsets[m + 1];
+        u64 sum[3] = {0, 0, 0};
+        if (last - first <= BAROSTAT_INLINE_MOL) {
+            for (int k = first; k < last; k++) { // integer sums: the bits of k_barostat_centroids in any order
+                const int b = atom_idxs[k];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    sum[d] += float_to_fixed<Real>(static_cast<Real>(x[b * 3 + d]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                sum[d] = centroids[m * 3 + d];
+            }
+        }
+        const Real n_atoms = static_cast<Real>(last - first);
+#pragma unroll
+        for (int d = 0; d < 3; d++) { // the arithmetic of k_barostat_rescale
+            const Real edge = static_cast<Real>(box[d * 4]);
+            const Real centre = edge * static_cast<Real>(0.5);
+            Real c = fixed_to_float<Real>(sum[d]) / n_atoms;
+            const Real displacement = ((c - centre) * p.scale) + centre - c;
+            c += displacement;
+            const Real scaled_edge = edge * p.scale;
+            const Real home = scaled_edge * floor(c / scaled_edge);
+            xp[d] += static_cast<double>(displacement - home);
+        }
+    }
+    x_proposed[a * 3 + 0] = xp[0];
+    x_proposed[a * 3 + 1] = xp[1];
+    x_proposed[a * 3 + 2] = xp[2];
+    // the proposal as the tile kernel reads it: a sorted record next to the current geometry's
+    const int slot = t.slot_of_atom[a];
+    const GReal *g = static_cast<const GReal *>(t.gathered) + static_cast<size_t>(slot) * 8;
+    GReal *g2 = static_cast<GReal *>(t.gathered2) + static_cast<size_t>(slot) * 8;
+    g2[0] = static_cast<GReal>(xp[0]);
+    g2[1] = static_cast<GReal>(xp[1]);
+    g2[2] = static_cast<GReal>(xp[2]);
+    g2[3] = g[3];
+    g2[4] = g[4];
+    g2[5] = g[5];
+    g2[6] = g[6];
+    g2[7] = 0;
+    if (a < 8) {
+        static_cast<GReal *>(t.gathered2)[static_cast<size_t>(t.n) * 8 + a] = 0; // the sentinel record padded list slots point at
+    }
+    // can the current list vouch for the proposal?  If not, the list launch that follows rebuilds it -- from the CURRENT geometry,
+    // whose records, block bounds and snapshot source are all in place -- and the proposal then sits a proposal's displacement
+    // from a fresh snapshot.
+    if (t.scale_aware && snapshot_calls_for_rebuild(xp[0], xp[1], xp[2], t.snap_x + a * 3, bp, t.snap_box, t.threshold2)) {
+        if (atomicExch(t.flag_probe, 1) == 0) { // the first to raise it resets the counters the build accumulates into (PregatherTarget)
+            t.nbl_counters[0] = 0;
+            t.nbl_counters[1] = 0;
+            t.nbl_counters[2] = 0;
+            for (int k = NB_COUNTER_CLASS0; k < NB_NUM_COUNTERS; k++) {
+                t.nbl_counters[k] = 0;
+            }
+        }
+    }
+}
+
+// The decision of k_barostat_decide on energies that arrive as per-workgroup partial sums, and the commit of an accepted proposal
+// into the potential's pre-gathered state.  One thread per sorted SLOT, 64-thread workgroups (two 32-atom blocks per wave: their
+// bounds fall out of shuffles, as in the integrator's sorted update kernel).
+template <typename Real, typename GReal>
+__global__ __launch_bounds__(64) void k_barostat_decide_commit(
+    const int N, const int adaptive, const int num_molecules, const double kT, const double pressure, const Real *__restrict__ mv,
+    double *__restrict__ volume_scale, const i128 *__restrict__ u_init_partials, const int n_init, const i128 *__restrict__ u_final_partials,
+    const int n_final, double *__restrict__ box, const double *__restrict__ box_proposed, double *__restrict__ x,
+    const double *__restrict__ x_proposed, int *__restrict__ counters, u64 *__restrict__ centroids, const int n_centroids, const ProbeTarget t) {
+    const int lane = threadIdx.x;
+    i128 e0 = 0, e1 = 0;
+    for (int k = lane; k < n_init; k += 64) {
+        e0 += u_init_partials[k];
+    }
+    for (int k = lane; k < n_final; k += 64) {
+        e1 += u_final_partials[k];
+    }
+    // (sums in every lane: butterfly instead of wave_sum_i128's lane-0 total)
+    e0 = wave_sum_i128(e0);
+    e1 = wave_sum_i128(e1);
+    u64 lo0 = static_cast<u64>(e0), lo1 = static_cast<u64>(e1);
+    long long hi0 = static_cast<long long>(e0 >> 64), hi1 = static_cast<long long>(e1 >> 64);
+    lo0 = __shfl(lo0, 0, 64);
+    hi0 = __shfl(hi0, 0, 64);
+    lo1 = __shfl(lo1, 0, 64);
+    hi1 = __shfl(hi1, 0, 64);
+    const i128 u_init = (static_cast<i128>(hi0) << 64) | static_cast<i128>(lo0);
+    const i128 u_final = (static_cast<i128>(hi1) << 64) | static_cast<i128>(lo1);
+    const Real volume = mv[0], delta = mv[1], u2 = mv[3];
+    const Real new_volume = volume + delta;
+    Real energy_delta = INFINITY;
+    if (!energy_overflowed(u_final) && !energy_overflowed(u_init)) {
+        energy_delta = static_cast<Real>(static_cast<double>(static_cast<long long>(u_final - u_init)) / static_cast<double>(TM_FIXED_EXPONENT));
+    }
+    const Real w = static_cast<Real>(energy_delta + pressure * delta - num_molecules * kT * log(new_volume / volume));
+    const bool rejected = w > 0 && u2 > static_cast<Real>(exp(-w / kT));
+    const int slot = blockIdx.x * 64 + lane;
+    if (slot == 0) {
+        if (!rejected) {
+            counters[0]++;
+        }
+        counters[1]++;
+        if (adaptive && counters[1] >= 10) {
+            if (counters[0] < 0.25 * counters[1]) {
+                volume_scale[0] /= 1.1;
+                counters[0] = 0;
+                counters[1] = 0;
+            } else if (counters[0] > 0.75 * counters[1]) {
+                volume_scale[0] = fmin(volume_scale[0] * 1.1, static_cast<double>(volume) * 0.3);
+                counters[0] = 0;
+                counters[1] = 0;
+            }
+        }
+        *t.flag_probe = 0; // consumed by the probe's list launch; the next call but one reads it again (the update kernel's flag_clear)
+    }
+    for (int k = slot; k < n_centroids; k += gridDim.x * 64) {
+        centroids[k] = 0; // for the next attempt's k_barostat_centroids (molecules beyond BAROSTAT_INLINE_MOL)
+    }
+    if (rejected) {
+        return; // (uniform across the launch) x, box, the sorted records, the flags, the bounds: all as the last MD step left them
+    }
+    const bool valid = slot < N;
+    GReal p[3] = {0, 0, 0};
+    if (valid) {
+        const int a = static_cast<int>(t.perm[slot]);
+        const double xp[3] = {x_proposed[a * 3 + 0], x_proposed[a * 3 + 1], x_proposed[a * 3 + 2]};
+        x[a * 3 + 0] = xp[0];
+        x[a * 3 + 1] = xp[1];
+        x[a * 3 + 2] = xp[2];
+        const GReal *g2 = static_cast<const GReal *>(t.gathered2) + static_cast<size_t>(slot) * 8;
+        GReal *g = static_cast<GReal *>(t.gathered) + static_cast<size_t>(slot) * 8;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            p[d] = g2[d];
+            g[d] = p[d];
+        }
+        // the committed geometry against the list's snapshot as it is NOW (the probe's list launch may have rebuilt it)
+        if (t.scale_aware && snapshot_calls_for_rebuild(xp[0], xp[1], xp[2], t.snap_x + a * 3, box_proposed, t.snap_box, t.threshold2)) {
+            if (atomicExch(t.flag_next, 1) == 0) {
+                t.nbl_counters[0] = 0;
+                t.nbl_counters[1] = 0;
+                t.nbl_counters[2] = 0;
+                for (int k = NB_COUNTER_CLASS0; k < NB_NUM_COUNTERS; k++) {
+                    t.nbl_counters[k] = 0;
+                }
+            }
+        }
+    }
+    // the new box (every thread reads box_proposed, never box: thread 0 rewrites it here)
+    if (slot < 9) {
+        box[slot] = box_proposed[slot];
+    }
+    // bounding boxes of the wave's two 32-slot blocks in the NEW box (the arithmetic of k_update_forward_baoab_sorted / k_block_bounds)
+    const GReal half = static_cast<GReal>(0.5);
+    const int first = lane & 32;
+    GReal lo[3], hi[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const GReal b = static_cast<GReal>(box_proposed[d * 4]);
+        const GReal ib = 1 / b;
+        const GReal p0 = __shfl(p[d], first, 64);
+        const GReal img = valid ? p[d] - b * nearbyint((p[d] - p0) * ib) : p0;
+        GReal l = img, h = img;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            l = min(l, __shfl_xor(l, o, 64));
+            h = max(h, __shfl_xor(h, o, 64));
+        }
+        lo[d] = l;
+        hi[d] = h;
+    }
+    const int sub = lane & 31;
+    if (sub < 3 && (slot - sub) < N) {
+        const int blk = slot >> 5;
+        const GReal l = sub == 0 ? lo[0] : (sub == 1 ? lo[1] : lo[2]);
+        const GReal h = sub == 0 ? hi[0] : (sub == 1 ? hi[1] : hi[2]);
+        static_cast<GReal *>(t.blk_ctr)[blk * 3 + sub] = half * (h + l);
+        static_cast<GReal *>(t.blk_ext)[blk * 3 + sub] = half * (h - l);
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 static void verify_group_idxs(const int N, const std::vector<std::vector<int>> &group_idxs) { // mol_utils.cpp:8-27
     size_t n = 0;
@@ -254,6 +519,82 @@ MonteCarloBarostat<Real>::MonteCarloBarostat(
     d_mol_offsets_.copy_from(mol_offsets.data());
     d_counters_.realloc(2);
     this->reset_counters();
+    // the fast path's view of the groups: the molecule of every atom
+    std::vector<int> mol_of_atom(static_cast<size_t>(N_), -1);
+    for (int m = 0; m < num_mols_; m++) {
+        max_mol_size_ = std::max(max_mol_size_, mol_offsets[m + 1] - mol_offsets[m]);
+        for (int k = mol_offsets[m]; k < mol_offsets[m + 1]; k++) {
+            mol_of_atom[atom_idxs[k]] = m;
+        }
+    }
+    d_mol_of_atom_.realloc(std::max(N_, 1));
+    if (N_ > 0) {
+        d_mol_of_atom_.copy_from(mol_of_atom.data());
+    }
+}
+
+// One attempt on the nonbonded potential's current list (see the comment above k_barostat_propose_probe).  false: the state is
+// not the one the fast path needs (nothing has been launched or changed: the caller runs the reference-shaped attempt).
+template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(double *d_x, double *d_box, hipStream_t stream) {
+    if (!g_barostat_fast_path) { // A/B switch (tm_debug_set_barostat_fast_path, TM_AMD_BAROSTAT_SLOW_PATH): always the reference-shaped attempt
+        return false;
+    }
+    const int n_bps = static_cast<int>(bps_.size());
+    plan_.clear();
+    for (int i = 0; i < n_bps; i++) {
+        bps_[i]->potential->plan_forces(N_, bps_[i]->size, bps_[i]->size > 0 ? bps_[i]->d_p.data : nullptr, plan_);
+    }
+    // exactly one potential with a kernel of its own -- an all-pairs nonbonded potential whose sorted pre-gathered state describes
+    // (d_x, d_box) -- and everything else in the plan's table, in that potential's precision
+    if (plan_.rest().size() != 1) {
+        return false;
+    }
+    const ForcePlan::Rest carrier = plan_.rest()[0];
+    NonbondedAllPairsBase *nb = dynamic_cast<NonbondedAllPairsBase *>(carrier.pot);
+    if (nb == nullptr || !nb->probe_ready(N_, carrier.P, d_x, carrier.d_p, d_box)) {
+        return false;
+    }
+    const FusedTable *tables[2];
+    int blocks[2];
+    plan_.prepare_tables(N_, stream, tables, blocks);
+    const int prec = nb->precision_bytes() == 8 ? 1 : 0;
+    if (tables[prec ^ 1] != nullptr) {
+        return false; // terms of the other precision: nobody to carry their table
+    }
+    const ProbeTarget t = nb->probe_begin();
+    const int tpb = DEFAULT_TPB;
+    if (max_mol_size_ > BAROSTAT_INLINE_MOL) { // large molecules (a protein): their centroid sums by the segmented-scan kernel, first
+        if (!centroids_clean_) {
+            HIP_CHECK(hipMemsetAsync(d_centroids_.data, 0, d_centroids_.size(), stream));
+        }
+        k_barostat_centroids<Real><<<ceil_divide(num_grouped_atoms_, tpb), tpb, 0, stream>>>(num_grouped_atoms_, d_x, d_atom_idxs_.data, d_mol_idxs_.data, d_centroids_.data);
+        HIP_CHECK(hipGetLastError());
+    }
+    const double pressure = static_cast<double>(pressure_) * AVOGADRO * 1e-25; // bar -> kJ/mol/nm^3
+    const double kT = BOLTZ_KJ * static_cast<double>(temperature_);
+    const i128 *p0 = nullptr, *p1 = nullptr;
+    int n0 = 0, n1 = 0;
+#define TM_BAROSTAT_FAST(GREAL)                                                                                        \
+    k_barostat_propose_probe<Real, GREAL><<<ceil_divide(std::max(N_, 1), 256), 256, 0, stream>>>(                        \
+        N_, adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data, d_x, d_x_proposed_.data, \
+        d_mol_of_atom_.data, d_mol_offsets_.data, d_atom_idxs_.data, d_centroids_.data, t);                              \
+    HIP_CHECK(hipGetLastError());                                                                                      \
+    nb->probe_energy(0, d_box, tables[prec], blocks[prec], d_x, stream, p0, n0);                                       \
+    nb->probe_energy(1, d_box_proposed_.data, tables[prec], blocks[prec], d_x_proposed_.data, stream, p1, n1);         \
+    k_barostat_decide_commit<Real, GREAL><<<ceil_divide(std::max(N_, 9), 64), 64, 0, stream>>>(                        \
+        N_, adaptive_ ? 1 : 0, num_mols_, kT, pressure, d_move_.data, d_volume_scale_.data, p0, n0, p1, n1, d_box, d_box_proposed_.data, \
+        d_x, d_x_proposed_.data, d_counters_.data, d_centroids_.data, num_mols_ * 3, t);                                \
+    HIP_CHECK(hipGetLastError())
+    if (t.real_bytes == 8) {
+        TM_BAROSTAT_FAST(double);
+    } else {
+        TM_BAROSTAT_FAST(float);
+    }
+#undef TM_BAROSTAT_FAST
+    attempt_++;
+    fast_attempts_++;
+    centroids_clean_ = true;
+    return true;
 }
 
 template <typename Real> void MonteCarloBarostat<Real>::reset_counters() { HIP_CHECK(hipMemset(d_counters_.data, 0, 2 * sizeof(int))); }
@@ -290,9 +631,15 @@ template <typename Real> void MonteCarloBarostat<Real>::move(const int N, double
     }
     this->step_++;
     this->acted_ = this->step_ % this->interval_ == 0;
+    this->kept_inputs_ = false;
     if (!this->acted_) {
         return;
     }
+    if (this->move_on_current_list(d_x, d_box, stream)) {
+        this->kept_inputs_ = true; // accepted or not, the potentials' pre-gathered inputs describe (d_x, d_box)
+        return;
+    }
+    centroids_clean_ = false; // (this path's centroid sums stay in the buffer)
     const int tpb = DEFAULT_TPB;
     const int n_prep = std::max(N_, num_mols_) * 3;
     k_barostat_propose<Real><<<ceil_divide(std::max(n_prep, 1), tpb), tpb, 0, stream>>>(

@@ -24,7 +24,7 @@ BINDING = os.path.join(os.path.dirname(HERE), "lib", "custom_ops" + (sysconfig.g
 CXX = os.environ.get("CXX", "g++")
 SOURCES = ["nonbonded.hip", "bonded.hip", "fused.hip", "barostat.hip", "integrator.hip", "local_md.hip", "potential.hip", "c_api.cpp"]
 HEADERS = [
-    "common.hpp", "engine.hpp", "fixed_point.hip.hpp", "nb_pair.hip.hpp", "kernels_nonbonded.hip.hpp", "kernels_nonbonded_rowblock.hip.hpp", "kernels_nblist.hip.hpp", "kernels_bonded.hip.hpp", "philox.hip.hpp", "nb_math.hip.hpp", "nb_math_coeffs.h", "nb_es_table.hip.hpp",
+    "common.hpp", "engine.hpp", "fixed_point.hip.hpp", "nb_pair.hip.hpp", "kernels_nonbonded.hip.hpp", "kernels_nonbonded_rowblock.hip.hpp", "kernels_nblist.hip.hpp", "kernels_bonded.hip.hpp", "philox.hip.hpp", "nb_math.hip.hpp", "nb_math_coeffs.h", "nb_es_table.hip.hpp", "nb_snapshot_test.hip.hpp",
     "profiler.hpp", "../../include/timemachine_amd.h",
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -606,6 +606,17 @@ int tm_barostat_get_counters(tm_mover_t m, int *accepted, int *attempted) {
     as_barostat(m).get_counters(accepted, attempted);
     TM_CATCH
 }
+int tm_barostat_get_attempt_paths(tm_mover_t m, long long *attempts, long long *fast) {
+    TM_TRY
+    if (auto b = std::dynamic_pointer_cast<MonteCarloBarostat<float>>(m->p)) {
+        b->get_attempt_paths(attempts, fast);
+    } else if (auto c = std::dynamic_pointer_cast<MonteCarloBarostat<double>>(m->p)) {
+        c->get_attempt_paths(attempts, fast);
+    } else {
+        throw std::runtime_error("not a MonteCarloBarostat");
+    }
+    TM_CATCH
+}
 
 int tm_context_destroy(tm_context_t ctxt) {
     TM_TRY
@@ -882,6 +893,14 @@ int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
     require(g_rowblock_built || min_atoms == std::numeric_limits<int>::max(),
             "the row-block kernel is not built into this library (load the variant libtimemachine_amd_rowblock.so: TM_AMD_LIB)");
     g_rowblock_min_k = min_atoms;
+    TM_CATCH
+}
+int tm_debug_set_barostat_fast_path(int enabled, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_barostat_fast_path ? 1 : 0;
+    }
+    g_barostat_fast_path = enabled != 0;
     TM_CATCH
 }
 int tm_debug_rowblock_available(int *available) {

@@ -80,6 +80,9 @@ struct PregatherTarget {
     int real_bytes = 0;       // sizeof(Real) of the producer: 4 or 8
     const double *snap_x = nullptr; // coordinates at the last list build, atom order
     double pad2_quarter = 0;        // (padding / 2)^2
+    // != nullptr: the producer follows small box changes without rebuilding (a barostat is at work): the test is the scale-aware
+    // one (nb_snapshot_test.hip.hpp) of the new position in `cur_box` against the snapshot in `snap_box`, and pad2_quarter is its D^2
+    const double *snap_box = nullptr, *cur_box = nullptr;
     int *flag_set = nullptr;        // rebuild flag of the producer's next call
     int *flag_clear = nullptr;      // flag of the call that has just been consumed
     u64 *g_du_dx = nullptr;         // the accumulator handed over in DeferredForces (to be zeroed slot by slot)
@@ -132,6 +135,10 @@ public:
     // after run(): did anything go to d_du_dx_cm?  (false when every table rode on a potential that took it into its own
     // accumulator: the consumer can skip reading and re-zeroing the array)
     bool cm_written() const { return cm_written_; }
+    // what was planned (a mover's fast path inspects it): the potentials that launch their own kernels, and -- after
+    // prepare_tables() -- the uploaded table of each precision (nullptr: none planned)
+    const std::vector<Rest> &rest() const { return rest_; }
+    void prepare_tables(const int N, hipStream_t stream, const FusedTable *d_tables[2], int blocks[2]);
 
 private:
     FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
@@ -506,14 +513,47 @@ private:
 
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
+extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
 extern int g_rowblock_min_k;     // forces-only launches over at least this many atoms run the row-block kernel (tm_debug_set_rowblock_min_k)
 extern const bool g_rowblock_built; // ... which only libraries built with -DTM_ROWBLOCK carry (the variant library of the parity tests)
 extern int g_static_list_max_k;  // potentials over at most this many atoms keep a static, complete list (tm_debug_set_static_list_max_k)
 
+// What a mover that proposes a SECOND geometry (the barostat: x', box') needs from the nonbonded potential whose sorted
+// pre-gathered state describes the current one (x, box), so that both energies can be evaluated on the potential's CURRENT list
+// without giving that state up, and an accepted proposal can be committed in place (MonteCarloBarostat's fast path,
+// barostat.hip).  Plain device pointers: passed to kernels by value.
+struct ProbeTarget {
+    void *gathered = nullptr;  // Real[K + 1][8] sorted records of the current geometry (left by the integrator's update kernel)
+    void *gathered2 = nullptr; // the same for the proposal: filled by the mover (x y z; w q sig eps copied from `gathered`)
+    int real_bytes = 0;        // sizeof(Real) of the potential
+    int n = 0;                 // atoms (== slots: the potential covers every atom)
+    const int *slot_of_atom = nullptr;
+    const unsigned int *perm = nullptr;
+    double *snap_x = nullptr;   // coordinates at the last list build, atom order (re-based by the commit)
+    double *snap_box = nullptr; // [0..8] the box the snapshot is expressed in, [9..11] accumulated scale since the build
+    double threshold2 = 0;      // squared displacement (against the scaled snapshot) beyond which the list is rebuilt
+    int scale_aware = 0;        // the potential follows small box changes without rebuilding (else: any box change rebuilds)
+    int *flag_probe = nullptr;  // the rebuild flag the probe's list launch reads (raised when the PROPOSAL fails the test)
+    int *flag_next = nullptr;   // the flag of the force call after the probe (raised by the commit's own test)
+    unsigned int *nbl_counters = nullptr; // reset by whoever raises a flag (sorted hand-over: no bounds kernel does it)
+    void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(n / 32)][3]: block bounds, recomputed by the commit
+};
+
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
 class NonbondedAllPairsBase : public Potential {
 public:
+    // ---- probing a second geometry on the current list (see ProbeTarget) ----
+    // true iff the sorted pre-gathered state the last MD step left describes exactly these inputs and nothing (re-sort, forced
+    // rebuild, atom subset, interaction group) stands in the way
+    virtual bool probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) { return false; }
+    // begins a probe: the call counts as one evaluation (launch parity, sort cadence); the pre-gathered state stays valid
+    virtual ProbeTarget probe_begin() { return ProbeTarget{}; }
+    // energy-only tile launch on geometry `which` (0: gathered / d_box, preceded by the flag-driven list launch; 1: gathered2 /
+    // d_box2) that leaves per-workgroup partial sums; `table` (may be nullptr): a ForcePlan table of this precision whose
+    // energies, evaluated on `coords`, ride along
+    virtual void probe_energy(const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords,
+                              hipStream_t stream, const i128 *&partials, int &count) {}
     virtual double get_cutoff() const = 0;
     virtual double get_nblist_padding() const = 0;
     virtual double get_beta() const = 0;
@@ -548,6 +588,9 @@ public:
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
+    bool probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) override;
+    ProbeTarget probe_begin() override;
+    void probe_energy(const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords, hipStream_t stream, const i128 *&partials, int &count) override;
     void invalidate_cached_inputs() override { pre_valid_ = false; }
     void expect_box_scaling() override { box_scales_ = true; }
     double get_cutoff() const override { return cutoff_; }
@@ -586,6 +629,9 @@ protected:
     DeviceBuffer<double> d_snap_x_, d_snap_box_;
     DeviceBuffer<int> d_flags_;
     DeviceBuffer<i128> d_u_partials_;
+    DeviceBuffer<Real> d_gathered2_;    // a probe's second geometry (ProbeTarget::gathered2), allocated on first use
+    DeviceBuffer<i128> d_u_partials2_;  // ... and its partial sums
+    const double *probe_d_box_ = nullptr; // the box pointer of the probe in flight (geometry 0)
     DeviceBuffer<long long> d_timing_; // per-wave cycle counters, filled only by -DTM_TIMING builds
     DeviceBuffer<int> d_slot_of_atom_;            // [N]: position of each atom in the sorted order, -1 = not one of ours
     void check_sizes(const int N, const int P) const;
@@ -775,6 +821,10 @@ public:
     // false only when the last move() call provably left coordinates and box untouched (off-interval call); the
     // Context drops the potentials' pre-gathered inputs otherwise
     bool acted_last_call() const { return acted_; }
+    // true when the last move() call changed coordinates / box (or not) but left the potentials' pre-gathered inputs describing the
+    // result (the barostat's fast path commits an accepted proposal into them): the Context then only drops the integrator's
+    // slot-ordered copies of x / v
+    bool kept_potential_inputs() const { return kept_inputs_; }
     // the bound potentials this mover evaluates on its own (a barostat's energy evaluations run in THEIR neighbor lists and
     // accumulators): Context::multiple_steps_group counts them as device state of the mover's context
     virtual std::vector<std::shared_ptr<BoundPotential>> held_potentials() const { return {}; }
@@ -783,6 +833,7 @@ protected:
     int interval_;
     int step_;
     bool acted_ = true;
+    bool kept_inputs_ = false;
 };
 
 // reference: cpp/src/barostat.{hpp,cu}, kernels/k_barostat.cuh.  Molecular-scaling Monte Carlo barostat: every
@@ -801,6 +852,11 @@ public:
     void set_pressure(const double pressure);
     // diagnostics used by the parity tests: (accepted, attempted) counters and the uniforms of attempt k
     void get_counters(int *accepted, int *attempted);
+    // diagnostic: attempts since construction, and how many of them ran on the potential's current list (the fast path)
+    void get_attempt_paths(long long *attempts, long long *fast) const {
+        *attempts = static_cast<long long>(attempt_);
+        *fast = fast_attempts_;
+    }
 private:
     const int N_;
     bool adaptive_;
@@ -816,6 +872,12 @@ private:
     DeviceBuffer<int> d_atom_idxs_, d_mol_idxs_, d_mol_offsets_, d_counters_;
     ForcePlan plan_; // the two energy evaluations of an attempt
     void reset_counters();
+    // ---- fast path (barostat.hip: move_on_current_list): both energies on the nonbonded potential's current list ----
+    DeviceBuffer<int> d_mol_of_atom_;   // [N]: molecule of each atom, -1 = not grouped
+    int max_mol_size_ = 0;
+    long long fast_attempts_ = 0;
+    bool centroids_clean_ = false; // d_centroids_ is all zero (left so by the last fast-path attempt)
+    bool move_on_current_list(double *d_x, double *d_box, hipStream_t stream);
 };
 
 // reference: cpp/src/local_md_potentials.{hpp,cu}, local_md_utils.cu, kernels/k_local_md.cuh.

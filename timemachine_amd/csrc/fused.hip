@@ -110,6 +110,16 @@ void ForcePlan::upload_tables(bool pending[2], hipStream_t stream) {
     }
 }
 
+void ForcePlan::prepare_tables(const int N, hipStream_t stream, const FusedTable *d_tables[2], int blocks[2]) {
+    host_[0].num_atoms = host_[1].num_atoms = N;
+    bool pending[2];
+    this->upload_tables(pending, stream);
+    for (int prec = 0; prec < 2; prec++) {
+        d_tables[prec] = pending[prec] ? d_table_[prec].data : nullptr;
+        blocks[prec] = pending[prec] ? host_[prec].block_end[host_[prec].n - 1] : 0;
+    }
+}
+
 void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, i128 *d_u, hipStream_t stream) {
     host_[0].num_atoms = host_[1].num_atoms = N;
     bool pending[2];

@@ -10,6 +10,7 @@
 //  * BOLTZ is the C++ value (cpp/src/constants.hpp:5), not the python one (timemachine/constants.py:5-8).
 #include "engine.hpp"
 #include "fixed_point.hip.hpp"
+#include "nb_snapshot_test.hip.hpp"
 #include "philox.hip.hpp"
 #include "profiler.hpp"
 
@@ -80,11 +81,17 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
     g[0] = gx;
     g[1] = gy;
     g[2] = gz;
-    const GReal dx = static_cast<GReal>(t.snap_x[atom * 3 + 0]) - gx;
-    const GReal dy = static_cast<GReal>(t.snap_x[atom * 3 + 1]) - gy;
-    const GReal dz = static_cast<GReal>(t.snap_x[atom * 3 + 2]) - gz;
-    const GReal d2 = dx * dx + dy * dy + dz * dz;
-    if (static_cast<double>(d2) > t.pad2_quarter) {
+    bool rebuild;
+    if (t.snap_box != nullptr) { // wave-uniform: a barostat works on the producer
+        rebuild = snapshot_calls_for_rebuild(xn, yn, zn, t.snap_x + atom * 3, t.cur_box, t.snap_box, t.pad2_quarter);
+    } else {
+        const GReal dx = static_cast<GReal>(t.snap_x[atom * 3 + 0]) - gx;
+        const GReal dy = static_cast<GReal>(t.snap_x[atom * 3 + 1]) - gy;
+        const GReal dz = static_cast<GReal>(t.snap_x[atom * 3 + 2]) - gz;
+        const GReal d2 = dx * dx + dy * dy + dz * dz;
+        rebuild = static_cast<double>(d2) > t.pad2_quarter;
+    }
+    if (rebuild) {
         if (t.nbl_counters == nullptr) {
             *t.flag_set = 1; // benign race: every writer stores the same value
         } else if (atomicExch(t.flag_set, 1) == 0) {
@@ -556,7 +563,13 @@ void Context::_step(hipStream_t stream) {
     for (auto &mover : movers_) {
         mover->move(N_, d_x_t_.data, d_box_t_.data, stream);
         if (mover->acted_last_call()) {
-            this->invalidate_potential_inputs(); // coordinates / box may have changed behind the same pointers
+            if (mover->kept_potential_inputs()) {
+                // (the barostat's fast path: an accepted proposal was committed INTO the potentials' pre-gathered state; only the
+                // integrator's own slot-ordered copies of x are behind)
+                intg_->invalidate_state_cache();
+            } else {
+                this->invalidate_potential_inputs(); // coordinates / box may have changed behind the same pointers
+            }
         }
     }
     step_ += 1;

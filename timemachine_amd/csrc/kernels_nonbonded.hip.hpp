@@ -668,6 +668,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     };
     __shared__ WaveLds s_wave[WAVES];
     __shared__ unsigned int s_ticket; // next position of this workgroup's pool
+    __shared__ i128 s_energy[COMPUTE_U ? WAVES : 1]; // energy launches: the waves' sums, added up by thread 0 at the end
     // f64: the workgroup's copy of the electrostatic force-factor table (12 KB, read-only after the barrier below)
     // (energy launches keep the energy-factor table behind it; the du/dp variants, whose per-wave LDS is the largest, read
     // that one from global memory)
@@ -1406,9 +1407,21 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #endif
 
     if constexpr (COMPUTE_U) {
+        // one partial sum per WORKGROUP (round 5; one per wave before): whoever adds them up -- k_reduce_i128[_sources], the
+        // barostat's decision kernel, which every one of its workgroups does for itself -- reads 256-512 values, not 4096.
+        // (every wave of the workgroup gets here: the item loop has no early exit)
         const i128 total = wave_sum_i128(energy);
         if (lane == 0) {
-            u_partials[global_wave] = total;
+            s_energy[wave] = total;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            i128 sum = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) {
+                sum += s_energy[w];
+            }
+            u_partials[blockIdx.x] = sum;
         }
     }
 }

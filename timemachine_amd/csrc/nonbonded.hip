@@ -703,6 +703,8 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     out.next.real_bytes = static_cast<int>(sizeof(Real));
     out.next.snap_x = d_snap_x_.data;
     out.next.pad2_quarter = rebuild_threshold2();
+    out.next.snap_box = scale_aware() && !static_list() ? d_snap_box_.data : nullptr; // (an accepted barostat move may leave the box ahead of the snapshot's)
+    out.next.cur_box = d_box;
     out.next.flag_set = d_flags_.data + parity_; // run_pipeline has already advanced parity_: the NEXT call's pair
     out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
     out.next.g_du_dx = d_g_du_dx_.data;
@@ -768,6 +770,87 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
     partials = d_u_partials_.data;
     count = u_partials_count_;
     return true;
+}
+
+// item-splitting thresholds of the tile launches (run_pipeline has the measurements)
+#ifndef TM_SPLIT4_MAX_K
+#define TM_SPLIT4_MAX_K 1536
+#define TM_SPLIT2_MAX_K_F32 7168
+#define TM_SPLIT2_MAX_K_F64 4608
+#endif
+// ---- probing a second geometry on the current list (engine.hpp: ProbeTarget; the barostat's fast path) --------------------
+template <typename Real>
+bool NonbondedAllPairs<Real>::probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) {
+    if (N != N_ || P != N_ * PARAMS_PER_ATOM || empty_) {
+        return false;
+    }
+    sync_list_mode();
+    return pre_valid_ && pre_sorted_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
+           calls_since_sort_ % steps_per_sort_ != 0 && K_ == N_ && group_rows_ == 0 && nblist_.upper_triangular() &&
+           (static_list() || scale_aware()) && piggyback_table_ == nullptr && piggyback_energy_table_ == nullptr;
+}
+
+template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
+    d_gathered2_.reserve(static_cast<size_t>(N_ + 1) * 8);
+    d_u_partials2_.reserve(grid_);
+    ProbeTarget t;
+    t.gathered = d_gathered_.data;
+    t.gathered2 = d_gathered2_.data;
+    t.real_bytes = static_cast<int>(sizeof(Real));
+    t.n = K_;
+    t.slot_of_atom = d_slot_of_atom_.data;
+    t.perm = d_perm_.data;
+    t.snap_x = d_snap_x_.data;
+    t.snap_box = d_snap_box_.data;
+    t.threshold2 = rebuild_threshold2();
+    t.scale_aware = (scale_aware() && !static_list()) ? 1 : 0; // (a static complete list has no snapshot to test against and no counters to reset)
+    // the probe is one evaluation as far as the flag pair and the sort cadence go: its list launch consumes the flag the last
+    // update kernel may have raised, the force call after it reads the other one (which the commit may raise)
+    t.flag_probe = d_flags_.data + parity_;
+    parity_ ^= 1;
+    t.flag_next = d_flags_.data + parity_;
+    calls_since_sort_++;
+    t.nbl_counters = nblist_.d_counters_rw();
+    t.blk_ctr = nblist_.d_col_ctr();
+    t.blk_ext = nblist_.d_col_ext();
+    probe_d_box_ = pre_box_;
+    return t; // pre_valid_ / pre_sorted_ stay: the sorted records still describe (x, box), or -- after the commit -- (x', box')
+}
+
+template <typename Real>
+void NonbondedAllPairs<Real>::probe_energy(
+    const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords, hipStream_t stream,
+    const i128 *&partials, int &count) {
+    if (which == 0 && !(static_list() && static_list_built_)) {
+        // the list launch an ordinary evaluation would make: rebuilds iff the update kernel -- or the proposal's own test, made by the
+        // mover -- raised the flag; block bounds and counters are the sorted hand-over's (bounds_done)
+        int *flag = d_flags_.data + (parity_ ^ 1); // (probe_begin has already advanced parity_)
+        const int prof_list = Profiler::get().begin("nblist_build", stream);
+        nblist_.build_device(d_gathered_.data, probe_d_box_, cutoff_ + list_padding(), cutoff_, flag, 0, N_ * 3, pre_x_, d_snap_x_.data, d_snap_box_.data, stream, true, false);
+        Profiler::get().end("nblist_build", prof_list, stream);
+    }
+    const Real *gathered = which == 0 ? d_gathered_.data : d_gathered2_.data;
+    i128 *out = which == 0 ? d_u_partials_.data : d_u_partials2_.data;
+    const int n_cus = grid_ / (4 * TileWaves<Real>::value);
+    const int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
+#define TM_LAUNCH_PROBE(...)                                                                                            \
+    k_nonbonded_tiles<Real, true, false, false, ##__VA_ARGS__><<<n_cus * TileShape<Real, false>::wgs_per_cu, 64 * TileShape<Real, false>::waves, 0, stream>>>( \
+        K_, nblist_.get_num_row_idxs(), 1, nullptr, nblist_.d_counters() + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), \
+        nblist_.d_col_atoms(), gathered, d_box_which, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, out, table, \
+        table_blocks, coords, nullptr, 3, 1, nullptr, d_timing_.data)
+    const int prof = Profiler::get().begin("nonbonded_tiles", stream);
+    if (split == 4) {
+        TM_LAUNCH_PROBE(false, 4);
+    } else if (split == 2) {
+        TM_LAUNCH_PROBE(false, 2);
+    } else {
+        TM_LAUNCH_PROBE();
+    }
+#undef TM_LAUNCH_PROBE
+    Profiler::get().end("nonbonded_tiles", prof, stream);
+    HIP_CHECK(hipGetLastError());
+    partials = out;
+    count = n_cus * TileShape<Real, false>::wgs_per_cu;
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, const int P) const {
@@ -849,14 +932,14 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
 #define TM_LAUNCH_TILES(U, X, PP, ...)                                                                                 \
-    launched_waves = n_cus * TileShape<Real, PP>::waves_per_cu;                                                        \
+    launched_waves = n_cus * TileShape<Real, PP>::wgs_per_cu; /* energy launches leave one partial sum per WORKGROUP */   \
     k_nonbonded_tiles<Real, U, X, PP, ##__VA_ARGS__><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
         d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, pig_acc, pig_atom_stride, pig_comp_stride, pig_remap, \
         d_timing_.data)
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
-    int launched_waves = 0; // waves of this launch = energy partials it writes
+    int launched_waves = 0; // workgroups of this launch = energy partials it writes (the name dates from one partial per wave)
     const int sel = (d_u ? 4 : 0) | (d_du_dx ? 2 : 0) | (d_du_dp ? 1 : 0);
     // a ForcePlan table offered through piggyback_forces() rides on the forces-only launch; any other call drops it
     // back to its owner's stand-alone path by never having accepted it (the plan only offers it for forces-only calls)
@@ -885,11 +968,6 @@ void NonbondedAllPairs<Real>::run_pipeline(
     //   K = 256: 29.8 / 22.2 / 18.1 (f32), 28.9 / 22.5 / 19.0 (f64);  900: 29.9 / 22.9 / 19.9, 29.8 / 23.8 / 21.7;
     //   2243: 33.9 / 27.1 / 29.7, 33.7 / 29.1 / 31.7;  3600: 35.7 / 32.0 / 35.1, 36.1 / 31.2 / 37.0;
     //   6318: 38.7 / 35.8 / 45.7, 40.1 / 42.0 / 48.4;  9000: 40.8 / 42.5 / 56.1, 44.4 / 49.5 / 61.5
-#ifndef TM_SPLIT4_MAX_K
-#define TM_SPLIT4_MAX_K 1536
-#define TM_SPLIT2_MAX_K_F32 7168
-#define TM_SPLIT2_MAX_K_F64 4608
-#endif
     int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
 #ifdef TM_SPLIT_ENV
     if (const char *e = getenv("TM_AMD_SPLIT")) {

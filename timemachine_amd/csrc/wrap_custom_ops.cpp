@@ -775,6 +775,11 @@ void declare_integrators_and_movers(py::module &m) {
             int acc = 0, att = 0;
             check(tm_barostat_get_counters(b.h, &acc, &att));
             return py::make_tuple(acc, att);
+        })
+        .def("get_attempt_paths", [](PyBarostat &b) { // diagnostic: (attempts since construction, of which on the potential's current list)
+            long long att = 0, fast = 0;
+            check(tm_barostat_get_attempt_paths(b.h, &att, &fast));
+            return py::make_tuple(att, fast);
         });
 }
 
@@ -1151,6 +1156,14 @@ void declare_functions(py::module &m) {
             return previous;
         },
         py::arg("min_atoms"));
+    m.def(
+        "debug_set_barostat_fast_path",
+        [](const bool enabled) { // A/B aid: barostat attempts on the potential's current list (true) or reference-shaped (false); -> the old value
+            int previous = 0;
+            check(tm_debug_set_barostat_fast_path(enabled ? 1 : 0, &previous));
+            return previous != 0;
+        },
+        py::arg("enabled"));
     m.def("debug_rowblock_available", []() { // does the loaded library carry the row-block kernel (the variant library of the parity tests)?
         int yes = 0;
         check(tm_debug_rowblock_available(&yes));

@@ -719,6 +719,12 @@ class MonteCarloBarostat(Mover):
         _check(_lib.tm_barostat_get_counters(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def get_attempt_paths(self):
+        """(attempts since construction, of which on the nonbonded potential's current list) -- diagnostic"""
+        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        _check(_lib.tm_barostat_get_attempt_paths(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
 
 class Context:
     """Context(x0, v0, box, integrator, bps, movers=None); wrap_kernels.cpp:296-689."""
@@ -1066,6 +1072,14 @@ def debug_set_rowblock_min_k(min_atoms):
     prev = _c_int(0)
     _check(_lib.tm_debug_set_rowblock_min_k(_c_int(int(min_atoms)), ctypes.byref(prev)))
     return prev.value
+
+
+def debug_set_barostat_fast_path(enabled):
+    """A/B aid: MonteCarloBarostat attempts on the nonbonded potential's current list (True) or reference-shaped (False); -> the old
+    value.  Bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_barostat_fast_path(_c_int(1 if enabled else 0), ctypes.byref(prev)))
+    return bool(prev.value)
 
 
 def debug_rowblock_available():
