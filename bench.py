@@ -100,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--equil-scale", type=float, default=1.0, help="scale the untimed equilibration (profiling runs)")
     ap.add_argument("--equil-precision", choices=["f64", "f32"], default="f32")
     ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto")
+    ap.add_argument("--barostat-interval", type=int, default=0, help="hrex: a MonteCarloBarostat every this many steps in every window's context (0: NVT); "
+                    "the default f64 NVT line carries an f32 / interval-25 leg (production_shape) unless --no-npt")
     ap.add_argument("--replica-group", type=int, default=4,
                     help="replicas of one rank stepped together on its GPU (custom_ops.multiple_steps_group): hrex mode's MD phase, and the "
                          "replicas_per_gpu legs of md mode; 1 = one after the other, as the reference does")
@@ -576,7 +578,9 @@ def run_md(args, rank, local_rank, world, backend):
     rank_ms_per_step = []  # one entry per run() call; [0] is the headline run
     rank_cpu_us_per_step = []  # process CPU time of the timed multiple_steps call / steps, same indexing
 
-    def run(prec, steps, warmup, profile_steps, barostat_interval=0, cutoff=None):
+    def run(prec, steps, warmup, profile_steps, barostat_interval=0, cutoff=None, start=None, final=None):
+        # start: (x, v, box) to begin from instead of the equilibrated frame; final: a dict that receives the run's last (x, v, box)
+        x_s, v_s, box_s = start if start is not None else ((None, None, None) if args.stub else (x, v, system.box))
         if args.stub:
             bps, ctxt = None, StubContext(N)
         else:
@@ -587,7 +591,7 @@ def run_md(args, rank, local_rank, world, backend):
                 from timemachine_amd.lib import MonteCarloBarostat
 
                 movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, ts.molecule_groups(system), barostat_interval, seed).impl(bps)]
-            ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps, movers=movers)
+            ctxt = co.Context(x_s, v_s, box_s, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed).impl(), bps, movers=movers)
         device_sync(co)  # the first call initialises torch's HIP context (seconds): do it here, not in front of the clock
         ctxt.multiple_steps(SETTLE_STEPS, 0)  # untimed, whatever --warmup says (see the module docstring)
         if warmup > 0:
@@ -606,6 +610,8 @@ def run_md(args, rank, local_rank, world, backend):
         dev_s, host_s = parallel.max_over_ranks(dev_s), parallel.max_over_ranks(host_s)
         xf = ctxt.get_x_t()
         assert np.all(np.isfinite(xf)), "trajectory diverged"
+        if final is not None and not args.stub:
+            final.update(x=xf, v=ctxt.get_v_t(), box=ctxt.get_box())
         prof = None
         if profile_steps > 0 and not args.stub:
             nb = find_all_pairs(bps)
@@ -842,10 +848,20 @@ def run_md(args, rank, local_rank, world, backend):
             if args.no_npt:
                 raise KeyboardInterrupt
             n_npt = n_sec
-            d3, _, _, _, _ = run(precision, n_npt, w_sec, 0, barostat_interval=25)
+            end = {}
+            d3, _, _, _, _ = run(precision, n_npt, w_sec, 0, barostat_interval=25, final=end)
             out["npt"] = {"barostat_interval": 25, "pressure_bar": 1.0, "ns_day": n_npt / d3 * 86400.0 * DT * 1e-3,
                           "ms_per_step": 1e3 * d3 / n_npt, "dtype": args.precision,
-                          "note": "reference: tests/test_benchmark.py:517-518 (dhfr-apo-barostat-interval-25); two energy-only evaluations per attempt"}
+                          "note": "reference: tests/test_benchmark.py:517-518 (dhfr-apo-barostat-interval-25); every attempt evaluates both energies "
+                                  "in ONE tile launch on the nonbonded potential's current list (csrc/barostat.hip, the fast path)"}
+            # At 1 bar this synthetic box contracts (6.223 -> ~6.14 nm: its water model's equilibrium density is not real water's), so
+            # the NPT steps do ~4 % more pair work than `value`'s at the DHFR box.  What the BAROSTAT costs is the ratio against an NVT
+            # run of the same state -- the NPT run's last frame, box and velocities, the same number of steps:
+            d5, _, _, _, _ = run(precision, n_npt, 0, 0, start=(end["x"], end["v"], end["box"]))
+            out["npt"]["box_nm_at_end"] = float(end["box"][0, 0])
+            out["npt"]["nvt_at_npt_box_ns_day"] = n_npt / d5 * 86400.0 * DT * 1e-3
+            out["npt"]["ratio_to_nvt_at_npt_box"] = d5 / d3
+            out["npt"]["ratio_to_value"] = (n_npt / d3) / (args.steps / dev_s)
         except KeyboardInterrupt:
             pass
         except Exception as exc:  # pragma: no cover
@@ -866,16 +882,22 @@ def run_md(args, rank, local_rank, world, backend):
                     co.multiple_steps_group(group, SETTLE_STEPS)
                     device_sync(co)
                     t0 = time.perf_counter()
+                    c0 = time.process_time()
                     co.multiple_steps_group(group, n_sec)
                     wall = time.perf_counter() - t0
+                    cpu_s = time.process_time() - c0
                     assert all(np.all(np.isfinite(c.get_x_t())) for c in group), "trajectory diverged"
                     out["replicas_per_gpu"][key] = {
                         "replicas": n_rep, "aggregate_ns_day": n_rep * n_sec / wall * 86400.0 * DT * 1e-3, "us_per_replica_step": 1e6 * wall / (n_sec * n_rep),
                         "device_ms_per_step_each": [c.last_multiple_steps_ms() / n_sec for c in group],
-                        "dtype": "f64" if leg_prec == np.float64 else "f32", "cutoff": args.cutoff if leg_cutoff is None else leg_cutoff}
+                        "dtype": "f64" if leg_prec == np.float64 else "f32", "cutoff": args.cutoff if leg_cutoff is None else leg_cutoff,
+                        # the host side of the grouped call: process CPU time per replica-step, CPUs busy during the call (hold n_gpus
+                        # times this against cpu_quota), the enqueueing threads and the hardware queues the runtime was given
+                        "host_cpu_us_per_step": 1e6 * cpu_s / (n_sec * n_rep), "host_cpu_load": cpu_s / wall,
+                        "enqueue_threads": _group_threads(N), "gpu_max_hw_queues": _runtime_env("GPU_MAX_HW_QUEUES")}
                     del group
                 out["replicas_per_gpu"]["note"] = (
-                    "independent replicas of the same box stepped together on one GPU by one host thread (custom_ops.multiple_steps_group: steps "
+                    "independent replicas of the same box stepped together on one GPU (custom_ops.multiple_steps_group: one enqueueing host thread at this size; steps "
                     "interleaved on the contexts' own streams; one replica's list / update kernels run underneath another's force kernel); "
                     "host wall clock of the call; trajectories bit-identical to stepping alone (tests/test_gpu_parity.py)")
             except Exception as exc:  # pragma: no cover
@@ -897,25 +919,40 @@ def run_md(args, rank, local_rank, world, backend):
 # ---------------------------------------------------------------------------------------------------------------------
 # --mode hrex
 # ---------------------------------------------------------------------------------------------------------------------
+def _runtime_env(name):
+    """an environment variable as the C runtime sees it (the native library exports GPU_MAX_HW_QUEUES with setenv when it is loaded:
+    os.environ, a copy made at interpreter start, does not show that)"""
+    import ctypes
+
+    try:
+        libc = ctypes.CDLL(None)
+        libc.getenv.restype = ctypes.c_char_p
+        v = libc.getenv(name.encode())
+        return v.decode() if v is not None else None
+    except (OSError, AttributeError):  # pragma: no cover
+        return os.environ.get(name)
+
+
+def _group_threads(n_atoms):
+    """the enqueueing host threads Context::multiple_steps_group uses for contexts of this size (csrc/integrator.hip)"""
+    e = os.environ.get("TM_AMD_GROUP_THREADS")
+    return max(1, int(e)) if e else (2 if n_atoms <= 5000 else 1)
+
+
 def run_hrex(args, rank, local_rank, world, backend):
     from timemachine_amd import hrex, parallel
 
     n_states = args.windows or 24
     steps_per_frame = args.steps_per_frame
-    n_frames = max(args.steps // steps_per_frame, 1)
-    warm_frames = max(args.warmup // steps_per_frame, 1)
-    dh = hrex.DistributedHREX(n_states, TEMPERATURE, max_delta_states=args.max_delta_states, world_size=world, rank=rank)
-    mine = dh.local_replicas
     co = None
     if not args.stub:
         from timemachine_amd import potentials as P
         from timemachine_amd import testsystems as ts
-        from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+        from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat, custom_ops as co
 
         if co.device_count() < 1:
             raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
         co.set_device(local_rank)
-        prec = np.float64 if args.precision == "f64" else np.float32
         system = ts.config5_complex_sized(0.0)
         N = system.num_atoms
         lig = np.arange(system.num_water_atoms, N)
@@ -929,79 +966,128 @@ def run_hrex(args, rank, local_rank, world, backend):
             return [bp.to_gpu(p).bound_impl for bp in ts.bound_potentials(system, p, nblist_padding=args.padding)]
 
         x0, v0 = equilibrate(co, LangevinIntegrator, system, make_bps, 99, args.equil_scale, np.float32)
-        unbound = P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff).to_gpu(prec).unbound_impl
-        ctxts, bound_nb = [], []
-        for r in mine:
-            bps = make_bps(prec)
-            bps[-1].set_params(params_by_state[r].reshape(-1))
-            ctxts.append(co.Context(x0, v0, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, 500 + r).impl(), bps))
-            bound_nb.append(bps[-1])
-        boxes = np.stack([system.box] * len(mine))
     else:
         N = 31000
-        ctxts = [StubContext(N) for _ in mine]
 
-    timers = {"md": 0.0, "matrix": 0.0, "exchange": 0.0, "rebind": 0.0}
-
-    def frame(it, timed):
-        t0 = time.perf_counter()
-        hrex.step_replicas(ctxts, steps_per_frame, group=args.replica_group)  # the rank's replicas, `group` at a time on one GPU
-        device_sync(co)
-        t1 = time.perf_counter()
-        if args.stub:
-            state = dh.state_of_replica()
-            rows = np.full((len(mine), n_states), np.inf)
-            for i, r in enumerate(mine):
-                lo, hi = max(0, state[r] - args.max_delta_states), min(n_states - 1, state[r] + args.max_delta_states)
-                rows[i, lo : hi + 1] = 0.1 * np.abs(np.arange(lo, hi + 1) - r)
-        else:
-            coords = np.stack([c.get_x_t() for c in ctxts])
-            rows = hrex.compute_potential_matrix(unbound, coords, boxes, params_by_state, dh.replica_idx_by_state, args.max_delta_states, replicas=mine)
-        t2 = time.perf_counter()
-        new_states = dh.exchange(rows, seed=1000 + it)  # collective: one all_gather + the identical swap chain everywhere
-        t3 = time.perf_counter()
+    def measure(precision_name, barostat_interval, n_frames, warm_frames):
+        """one HREX measurement: this rank's resident replicas built afresh, warm-up frames, n_frames timed; -> (record fields, per_rank)"""
+        dh = hrex.DistributedHREX(n_states, TEMPERATURE, max_delta_states=args.max_delta_states, world_size=world, rank=rank)
+        mine = dh.local_replicas
         if not args.stub:
-            for i in range(len(mine)):
-                bound_nb[i].set_params(params_by_state[new_states[i]].reshape(-1))
-        t4 = time.perf_counter()
-        if timed:
-            timers["md"] += t1 - t0
-            timers["matrix"] += t2 - t1
-            timers["exchange"] += t3 - t2
-            timers["rebind"] += t4 - t3
+            prec = np.float64 if precision_name == "f64" else np.float32
+            unbound = P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff).to_gpu(prec).unbound_impl
+            ctxts, bound_nb = [], []
+            for r in mine:
+                bps = make_bps(prec)
+                bps[-1].set_params(params_by_state[r].reshape(-1))
+                # the production shape (fe/rbfe.py:113-121,191-192; fe/free_energy.py:695-708): a barostat in every window's context
+                movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, ts.molecule_groups(system), barostat_interval, 700 + r).impl(bps)] if barostat_interval > 0 else []
+                ctxts.append(co.Context(x0, v0, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, 500 + r).impl(), bps, movers=movers))
+                bound_nb.append(bps[-1])
+        else:
+            ctxts = [StubContext(N) for _ in mine]
+        timers = {"md": 0.0, "matrix": 0.0, "exchange": 0.0, "rebind": 0.0}
 
-    for it in range(warm_frames):
-        frame(it, False)
-    parallel.barrier()
-    device_sync(co)
-    t0 = time.perf_counter()
-    for it in range(n_frames):
-        frame(warm_frames + it, True)
-    device_sync(co)
-    parallel.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
-    for c in ctxts:
-        assert np.all(np.isfinite(c.get_x_t())), "trajectory diverged"
-    t_max = {k: parallel.max_over_ranks(v) for k, v in timers.items()}
-    md_steps = n_frames * steps_per_frame
-    # who holds what: every rank's resident replicas (windows), its own MD time per frame, device and bus id
-    per_rank = parallel.gather_objects({
-        "rank": rank, "local_rank": local_rank, "resident_replicas": [int(r) for r in mine], "md_ms_per_frame": 1e3 * timers["md"] / n_frames,
-        "ms_per_step": 1e3 * timers["md"] / max(n_frames * steps_per_frame * max(len(mine), 1), 1),
-        "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
-    })
+        def frame(it, timed):
+            t0 = time.perf_counter()
+            hrex.step_replicas(ctxts, steps_per_frame, group=args.replica_group)  # the rank's replicas, `group` at a time on one GPU
+            device_sync(co)
+            t1 = time.perf_counter()
+            if args.stub:
+                state = dh.state_of_replica()
+                rows = np.full((len(mine), n_states), np.inf)
+                for i, r in enumerate(mine):
+                    lo, hi = max(0, state[r] - args.max_delta_states), min(n_states - 1, state[r] + args.max_delta_states)
+                    rows[i, lo : hi + 1] = 0.1 * np.abs(np.arange(lo, hi + 1) - r)
+            else:
+                coords = np.stack([c.get_x_t() for c in ctxts])
+                boxes = np.stack([c.get_box() for c in ctxts])  # (every window has its own box once a barostat is at work)
+                rows = hrex.compute_potential_matrix(unbound, coords, boxes, params_by_state, dh.replica_idx_by_state, args.max_delta_states, replicas=mine)
+            t2 = time.perf_counter()
+            new_states = dh.exchange(rows, seed=1000 + it)  # collective: one all_gather + the identical swap chain everywhere
+            t3 = time.perf_counter()
+            if not args.stub:
+                for i in range(len(mine)):
+                    bound_nb[i].set_params(params_by_state[new_states[i]].reshape(-1))
+            t4 = time.perf_counter()
+            if timed:
+                timers["md"] += t1 - t0
+                timers["matrix"] += t2 - t1
+                timers["exchange"] += t3 - t2
+                timers["rebind"] += t4 - t3
+
+        for it in range(warm_frames):
+            frame(it, False)
+        parallel.barrier()
+        device_sync(co)
+        t0 = time.perf_counter()
+        c0 = time.process_time()  # user + system CPU time of this process, all threads (enqueue threads and the HIP runtime's included)
+        for it in range(n_frames):
+            frame(warm_frames + it, True)
+        device_sync(co)
+        cpu_s = time.process_time() - c0
+        parallel.barrier()
+        elapsed_rank = time.perf_counter() - t0
+        elapsed = parallel.max_over_ranks(elapsed_rank)
+        for c in ctxts:
+            assert np.all(np.isfinite(c.get_x_t())), "trajectory diverged"
+        t_max = {k: parallel.max_over_ranks(v) for k, v in timers.items()}
+        md_steps = n_frames * steps_per_frame
+        replica_steps = max(md_steps * max(len(mine), 1), 1)
+        # who holds what: every rank's resident replicas (windows), its own MD time per frame, its host CPU, device and bus id
+        per_rank = parallel.gather_objects({
+            "rank": rank, "local_rank": local_rank, "resident_replicas": [int(r) for r in mine], "md_ms_per_frame": 1e3 * timers["md"] / n_frames,
+            "ms_per_step": 1e3 * timers["md"] / replica_steps,
+            "host_cpu_us_per_step": 1e6 * cpu_s / replica_steps, "host_cpu_load": cpu_s / max(elapsed_rank, 1e-9), "cpus": len(PINNED_CPUS) if PINNED_CPUS else None,
+            "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
+        })
+        if rank != 0:
+            return None, None
+        accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
+        proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
+        fields = {
+            "value": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3,
+            "steps": md_steps,
+            "warmup": warm_frames * steps_per_frame,
+            "ms_per_step": 1e3 * elapsed / md_steps,
+            "dtype": precision_name,
+            "barostat_interval": barostat_interval,
+            "frames": n_frames,
+            "frames_per_s": n_frames / elapsed,
+            "per_frame_ms": {k: 1e3 * v / n_frames for k, v in t_max.items()},
+            "exchange_latency_ms": 1e3 * (t_max["matrix"] + t_max["exchange"] + t_max["rebind"]) / n_frames,
+            "swap_acceptance": accepted / max(proposed, 1),
+            "value_per_gpu": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3 / world,
+            # what the host spends: process CPU time per replica-step (max over ranks) and CPUs busy over the whole job, to be held
+            # against cpu_quota (the job's, taken before the ranks pinned themselves); how the grouped call was fed
+            "host_cpu_us_per_step": max(r["host_cpu_us_per_step"] for r in per_rank),
+            "host_cpu_load": sum(r["host_cpu_load"] for r in per_rank),
+            "cpu_quota": JOB_CPU_QUOTA if JOB_CPU_QUOTA is not None else _cpu_quota(),
+            "replica_group": args.replica_group,
+            "enqueue_threads": _group_threads(N),
+            "gpu_max_hw_queues": None if args.stub else _runtime_env("GPU_MAX_HW_QUEUES"),
+            "resident_replicas_rank0": len(mine),
+        }
+        return fields, per_rank
+
+    n_frames = max(args.steps // steps_per_frame, 1)
+    warm_frames = max(args.warmup // steps_per_frame, 1)
+    main_fields, per_rank = measure(args.precision, args.barostat_interval, n_frames, warm_frames)
+    # the reference's PRODUCTION shape as a leg of the default line: f32 potentials, a Monte Carlo barostat every 25 steps in every
+    # window (examples/run_rbfe_legs.py -> fe/rbfe.py:113-121,191-192; fe/free_energy.py:695-708), fewer frames
+    production = None
+    if args.precision == "f64" and args.barostat_interval == 0 and not args.no_npt:
+        production, _ = measure("f32", 25, max(n_frames // 2, 1), 1)
     if rank != 0:
         return
-    accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
-    proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
-    emit_json({
+    record = {
         "metric": "ns/day aggregate over all lambda windows, HREX (BASELINE config 5 shape)",
-        "value": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3,
+        "value": main_fields["value"],
         "unit": "ns/day",
         "n_gpus": world,
-        "steps": md_steps,
-        "warmup": warm_frames * steps_per_frame,
-        "ms_per_step": 1e3 * elapsed / md_steps,
+        "steps": main_fields["steps"],
+        "warmup": main_fields["warmup"],
+        "ms_per_step": main_fields["ms_per_step"],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -1009,22 +1095,26 @@ def run_hrex(args, rank, local_rank, world, backend):
         "data": "synthetic",
         "config": {
             "workload": f"configs[4] (zero-based; BASELINE's fifth) shape: {n_states} lambda windows of a {N}-atom solvated-ligand state, round-robin over {world} GPU(s) "
-            f"({len(mine)} resident replicas on rank 0), {steps_per_frame} steps per frame, neighbour exchange with max_delta_states {args.max_delta_states}, "
-            f"{n_states}^3 swap attempts per frame; ms_per_step is wall time per MD step of ONE window slot (all windows of a rank run back to back)",
-            "atoms": N, "windows": n_states, "frames": n_frames, "nblist_padding": args.padding,
+            f"({main_fields['resident_replicas_rank0']} resident replicas on rank 0, stepped {args.replica_group} at a time), {steps_per_frame} steps per frame, neighbour exchange with max_delta_states {args.max_delta_states}, "
+            f"{n_states}^3 swap attempts per frame; ms_per_step is wall time per MD step of ONE window slot (all windows of a rank run back to back)"
+            + (f"; Monte Carlo barostat every {args.barostat_interval} steps in every window" if args.barostat_interval else ""),
+            "atoms": N, "windows": n_states, "frames": main_fields["frames"], "nblist_padding": args.padding, "barostat_interval": args.barostat_interval,
         },
-        "frames_per_s": n_frames / elapsed,
-        "per_frame_ms": {k: 1e3 * v / n_frames for k, v in t_max.items()},
-        "exchange_latency_ms": 1e3 * (t_max["matrix"] + t_max["exchange"] + t_max["rebind"]) / n_frames,
-        "swap_acceptance": accepted / max(proposed, 1),
         "world_size": world,
         "backend": backend,
-        "value_per_gpu": n_states * md_steps / elapsed * 86400.0 * DT * 1e-3 / world,
         "rccl_ranks": collective_ranks(backend),
         "per_rank": per_rank,
         "binding": "stub" if args.stub else co.BINDING,
         "device": "stub" if args.stub else co.device_name(),
-    })
+    }
+    for k in ("frames_per_s", "per_frame_ms", "exchange_latency_ms", "swap_acceptance", "value_per_gpu", "host_cpu_us_per_step", "host_cpu_load", "cpu_quota",
+              "replica_group", "enqueue_threads", "gpu_max_hw_queues"):
+        record[k] = main_fields[k]
+    if production is not None:
+        production["note"] = ("the reference's production shape (examples/run_rbfe_legs.py: fe/rbfe.py:113-121,191-192, fe/free_energy.py:695-708): f32 potentials, a Monte "
+                              "Carlo barostat every 25 steps in every window, replicas stepped together; same windows, half the frames")
+        record["production_shape"] = production
+    emit_json(record)
 
 
 def main(argv=None):

@@ -34,6 +34,18 @@ if len(idx)>=3:
     # the attempt itself: launches from the first barostat kernel before decision b to b, in order
     j=b
     while j>a and not ('barostat' in rows[j]['Kernel_Name'].lower() and 'decide' not in rows[j]['Kernel_Name'].lower() and 'propose' in rows[j]['Kernel_Name'].lower()): j-=1
+    # every attempt of the run: its launches from the proposal kernel to the decision, and how often the list was rebuilt inside it
+    props=[i for i,r in enumerate(rows) if 'barostat' in r['Kernel_Name'].lower() and 'propose' in r['Kernel_Name'].lower()]
+    durs=[]; rebuilds=0
+    for p0 in props[5:]:
+        q=p0
+        while q < len(rows) and 'decide' not in rows[q]['Kernel_Name'].lower(): q+=1
+        if q >= len(rows): break
+        durs.append(1e-3*(int(rows[q]['End_Timestamp'])-int(rows[p0]['Start_Timestamp'])))
+        rebuilds += any('find_ixns' in rows[k]['Kernel_Name'] and int(rows[k]['End_Timestamp'])-int(rows[k]['Start_Timestamp']) > 20000 for k in range(p0,q))
+    if durs:
+        import statistics
+        print(f"attempts {len(durs)}: proposal .. decision {statistics.mean(durs):.1f} us mean, {statistics.median(durs):.1f} median; list rebuilt inside {rebuilds} of them")
     print("attempt launches in order:")
     tA=int(rows[j]['Start_Timestamp'])
     for r in rows[j:b+4]:

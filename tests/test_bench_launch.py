@@ -70,6 +70,21 @@ def test_bench_hrex_mode_two_ranks():
     # resident replicas per rank: round-robin placement (parallel.windows_for_rank), every window exactly once
     assert [r["resident_replicas"] for r in out["per_rank"]] == [[0, 2, 4], [1, 3, 5]]
     assert out["value_per_gpu"] == pytest.approx(out["value"] / 2) and out["rccl_ranks"] is None
+    # the host in the record: CPU time per replica-step, CPUs busy over the job against the job's quota, how the grouped call was fed
+    assert out["host_cpu_us_per_step"] > 0 and out["host_cpu_load"] > 0 and out["cpu_quota"] >= 1
+    assert out["replica_group"] == 4 and out["enqueue_threads"] == 1 and "gpu_max_hw_queues" in out
+    for p in out["per_rank"]:
+        assert p["host_cpu_us_per_step"] > 0 and p["host_cpu_load"] > 0
+    # the production-shape leg of the default line (f32 potentials, barostat every 25 steps in every window)
+    prod = out["production_shape"]
+    assert prod["dtype"] == "f32" and prod["barostat_interval"] == 25 and prod["value"] > 0 and prod["frames"] == 1
+    assert prod["host_cpu_us_per_step"] > 0 and "fe/rbfe.py" in prod["note"]
+    assert out["config"]["barostat_interval"] == 0
+
+
+def test_bench_hrex_mode_with_a_barostat_is_one_line_without_the_extra_leg():
+    out = _line(_run("--gpus", "1", "--mode", "hrex", "--windows", "4", "--steps", "400", "--warmup", "400", "--precision", "f32", "--barostat-interval", "25"))
+    assert out["dtype"] == "f32" and out["config"]["barostat_interval"] == 25 and "production_shape" not in out
 
 
 def test_cpu_baseline_times_whole_force_evaluations():

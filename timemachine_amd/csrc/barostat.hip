@@ -184,8 +184,9 @@ __global__ void k_barostat_decide(
 // PregatherTarget): sorted records of x, the rebuild flag, the block bounds.  The reference-shaped attempt above throws that away
 // twice (the proposal's evaluation gathers x' over it, the next MD step gathers x or x' again): fifteen small launches around the
 // two energy launches.  Here the attempt is FOUR launches + the list launch:
-//   k_barostat_propose_probe   the proposal in one pass -- scale, molecule centroids (summed in-thread for molecules of up to
-//                              BAROSTAT_INLINE_MOL atoms), x' in atom order and as a second set of sorted records next to the
+//   [k_barostat_centroids]     only when a molecule has more than BAROSTAT_INLINE_MOL atoms: the centroid sums of the large ones
+//   k_barostat_propose_probe   the proposal in one pass -- scale, molecule centroids (summed in-thread for the small
+//                              molecules), x' in atom order and as a second set of sorted records next to the
 //                              potential's own (ProbeTarget::gathered2), and the list-validity test of x' (raising the flag the list
 //                              launch reads: a proposal the current list cannot vouch for rebuilds it, from x, first)
 //   [k_find_ixns]              the list launch every evaluation makes (exits unless flagged)
@@ -199,7 +200,12 @@ __global__ void k_barostat_decide(
 // and the same trajectories as the path above (tests/test_gpu_parity.py::test_barostat_follows_model_attempt_by_attempt,
 // tests/test_gpu_barostat_cases.py run on both paths).
 bool g_barostat_fast_path = std::getenv("TM_AMD_BAROSTAT_SLOW_PATH") == nullptr;
-static const int BAROSTAT_INLINE_MOL = 128; // molecules up to this size have their centroid summed by each of their atoms' threads
+// both geometries in one tile launch (k_nonbonded_tiles<..., DUAL>) or one launch each (A/B switch, TM_AMD_BAROSTAT_TWO_LAUNCHES)
+static const bool g_barostat_dual_launch = std::getenv("TM_AMD_BAROSTAT_TWO_LAUNCHES") == nullptr;
+// molecules up to this size (waters, ions) have their centroid summed by each of their atoms' threads; larger ones by the
+// segmented-scan kernel in a launch of its own (measured: 83-atom chains summed in-thread made the proposal kernel a 29 us chain of
+// dependent loads and conversions per thread)
+static const int BAROSTAT_INLINE_MOL = 8;
 
 // what the proposal is, from the attempt's Philox draw and the box: the arithmetic of k_barostat_propose
 template <typename Real> struct Proposal {
@@ -227,8 +233,11 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     double *__restrict__ volume_scale, Real *__restrict__ mv, double *__restrict__ box_proposed, const double *__restrict__ x,
     double *__restrict__ x_proposed, const int *__restrict__ mol_of_atom, const int *__restrict__ mol_offsets, const int *__restrict__ atom_idxs,
     const u64 *__restrict__ centroids, // sums of the molecules larger than BAROSTAT_INLINE_MOL (k_barostat_centroids ran first), else unused
+    float *__restrict__ r2_blocks,     // [gridDim.x]: this block's largest |atom - own molecule's centroid|^2 (the DUAL tile launch's filter margin)
     const ProbeTarget t) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_r2[4];
+    float r2_mine = 0.0f;
     const double vs_now = *volume_scale;
     const Proposal<Real> p = draw_proposal<Real>(adaptive, seed, attempt, box, vs_now);
     double bp[9];
@@ -251,9 +260,7 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
             box_proposed[k] = bp[k];
         }
     }
-    if (a >= N) {
-        return;
-    }
+    if (a < N) {
     double xp[3] = {x[a * 3 + 0], x[a * 3 + 1], x[a * 3 + 2]};
     const int m = mol_of_atom[a];
     if (m >= 0) {
@@ -279,12 +286,15 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
             const Real edge = static_cast<Real>(box[d * 4]);
             const Real centre = edge * static_cast<Real>(0.5);
             Real c = fixed_to_float<Real>(sum[d]) / n_atoms;
+            const float off = static_cast<float>(xp[d] - static_cast<double>(c));
+            r2_mine = __builtin_fmaf(off, off, r2_mine);
             const Real displacement = ((c - centre) * p.scale) + centre - c;
             c += displacement;
             const Real scaled_edge = edge * p.scale;
             const Real home = scaled_edge * floor(c / scaled_edge);
             xp[d] += static_cast<double>(displacement - home);
         }
+        r2_mine *= 1.0001f; // (f32 rounding of the three squares)
     }
     x_proposed[a * 3 + 0] = xp[0];
     x_proposed[a * 3 + 1] = xp[1];
@@ -316,6 +326,19 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
                 t.nbl_counters[k] = 0;
             }
         }
+    }
+    } // a < N
+    // the block's largest atom-to-centroid distance (every thread of the block gets here)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r2_mine = fmaxf(r2_mine, __shfl_xor(r2_mine, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r2[threadIdx.x >> 6] = r2_mine;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        r2_blocks[blockIdx.x] = fmaxf(fmaxf(s_r2[0], s_r2[1]), fmaxf(s_r2[2], s_r2[3]));
     }
 }
 
@@ -574,13 +597,20 @@ template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(dou
     const double kT = BOLTZ_KJ * static_cast<double>(temperature_);
     const i128 *p0 = nullptr, *p1 = nullptr;
     int n0 = 0, n1 = 0;
+    const int n_prop_blocks = ceil_divide(std::max(N_, 1), 256);
+    d_r2_blocks_.reserve(n_prop_blocks);
 #define TM_BAROSTAT_FAST(GREAL)                                                                                        \
-    k_barostat_propose_probe<Real, GREAL><<<ceil_divide(std::max(N_, 1), 256), 256, 0, stream>>>(                        \
+    k_barostat_propose_probe<Real, GREAL><<<n_prop_blocks, 256, 0, stream>>>(                                            \
         N_, adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data, d_x, d_x_proposed_.data, \
-        d_mol_of_atom_.data, d_mol_offsets_.data, d_atom_idxs_.data, d_centroids_.data, t);                              \
+        d_mol_of_atom_.data, d_mol_offsets_.data, d_atom_idxs_.data, d_centroids_.data, d_r2_blocks_.data, t);           \
     HIP_CHECK(hipGetLastError());                                                                                      \
-    nb->probe_energy(0, d_box, tables[prec], blocks[prec], d_x, stream, p0, n0);                                       \
-    nb->probe_energy(1, d_box_proposed_.data, tables[prec], blocks[prec], d_x_proposed_.data, stream, p1, n1);         \
+    if (g_barostat_dual_launch) {                                                                                      \
+        nb->probe_energy_dual(d_box_proposed_.data, tables[prec], blocks[prec], d_x, d_x_proposed_.data, d_r2_blocks_.data, n_prop_blocks, stream, p0, p1, n0); \
+        n1 = n0;                                                                                                       \
+    } else {                                                                                                           \
+        nb->probe_energy(0, d_box, tables[prec], blocks[prec], d_x, stream, p0, n0);                                   \
+        nb->probe_energy(1, d_box_proposed_.data, tables[prec], blocks[prec], d_x_proposed_.data, stream, p1, n1);     \
+    }                                                                                                                  \
     k_barostat_decide_commit<Real, GREAL><<<ceil_divide(std::max(N_, 9), 64), 64, 0, stream>>>(                        \
         N_, adaptive_ ? 1 : 0, num_mols_, kT, pressure, d_move_.data, d_volume_scale_.data, p0, n0, p1, n1, d_box, d_box_proposed_.data, \
         d_x, d_x_proposed_.data, d_counters_.data, d_centroids_.data, num_mols_ * 3, t);                                \

@@ -554,6 +554,10 @@ public:
     // energies, evaluated on `coords`, ride along
     virtual void probe_energy(const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords,
                               hipStream_t stream, const i128 *&partials, int &count) {}
+    // both geometries in ONE tile launch (k_nonbonded_tiles<..., DUAL>), preceded by the list launch: `r2_blocks` = n_r2 per-block
+    // maxima of |atom - own molecule's centroid|^2 (what bounds the change of a pair distance between the two geometries)
+    virtual void probe_energy_dual(const double *d_box2, const FusedTable *table, const int table_blocks, const double *coords, const double *coords2,
+                                   const float *r2_blocks, const int n_r2, hipStream_t stream, const i128 *&partials, const i128 *&partials2, int &count) {}
     virtual double get_cutoff() const = 0;
     virtual double get_nblist_padding() const = 0;
     virtual double get_beta() const = 0;
@@ -591,6 +595,8 @@ public:
     bool probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) override;
     ProbeTarget probe_begin() override;
     void probe_energy(const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords, hipStream_t stream, const i128 *&partials, int &count) override;
+    void probe_energy_dual(const double *d_box2, const FusedTable *table, const int table_blocks, const double *coords, const double *coords2, const float *r2_blocks, const int n_r2, hipStream_t stream, const i128 *&partials, const i128 *&partials2, int &count) override;
+    void probe_list_launch(hipStream_t stream);
     void invalidate_cached_inputs() override { pre_valid_ = false; }
     void expect_box_scaling() override { box_scales_ = true; }
     double get_cutoff() const override { return cutoff_; }
@@ -874,6 +880,7 @@ private:
     void reset_counters();
     // ---- fast path (barostat.hip: move_on_current_list): both energies on the nonbonded potential's current list ----
     DeviceBuffer<int> d_mol_of_atom_;   // [N]: molecule of each atom, -1 = not grouped
+    DeviceBuffer<float> d_r2_blocks_;   // per block of the proposal kernel: max |atom - own centroid|^2 (the DUAL tile launch's filter margin)
     int max_mol_size_ = 0;
     long long fast_attempts_ = 0;
     bool centroids_clean_ = false; // d_centroids_ is all zero (left so by the last fast-path attempt)

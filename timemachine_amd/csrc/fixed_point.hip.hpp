@@ -65,6 +65,22 @@ template <typename Real> __device__ __forceinline__ i128 float_to_fixed_energy(R
     return static_cast<i128>(r);
 }
 
+// The same value for a caller inside a hot loop (the tile kernel's energy launches): the common case -- |u 2^36| < 2^51, i.e. a pair
+// energy below 32 768 kJ/mol -- is one multiply, the magic add and an integer subtract; everything else (large, infinite, NaN)
+// takes float_to_fixed_energy() behind ONE wave-uniform branch (left to itself the compiler if-converts the general function:
+// both conversions and the range logic, ~20 instructions, issue for every pair).  Same integers.
+template <typename Real> __device__ __forceinline__ i128 float_to_fixed_energy_hot(Real u_orig) {
+    const double u = static_cast<double>(u_orig * static_cast<Real>(TM_FIXED_EXPONENT)); // (the scaling in Real, as the reference forms it; widening is exact)
+    long long r = real_to_int64_fast(u);
+    const bool rare = !(__builtin_fabs(u) < TM_FIXED_FAST_LIMIT); // (true for NaN)
+    if (__ballot(rare) != 0ull) {
+        if (rare) {
+            return float_to_fixed_energy<Real>(u_orig);
+        }
+    }
+    return static_cast<i128>(r);
+}
+
 __host__ __device__ __forceinline__ bool fixed_point_overflow(i128 v) {
     return v >= static_cast<i128>(LLONG_MAX) || v <= static_cast<i128>(LLONG_MIN);
 }

@@ -72,6 +72,18 @@ template <typename Real, bool DU_DP> struct TileShape {
 #endif
     static const int waves_per_cu = waves * wgs_per_cu;
 };
+// Which launches take the "wide" shape (f64: 3 waves per SIMD = 168 registers; f32: one 16-wave workgroup): the du/dp variants, whose
+// per-wave LDS is 1.5x; DUAL energy launches (two geometries' operands and two pair evaluations per batch: 128 registers spill);
+// and, when TM_ENERGY_WIDE is set, f64 energy-only launches (their 128-register form carries 400 bytes of scratch).
+#ifndef TM_ENERGY_WIDE
+#define TM_ENERGY_WIDE 0
+#endif
+#ifndef TM_DUAL_WIDE
+#define TM_DUAL_WIDE 1
+#endif
+template <typename Real, bool U, bool X, bool PP, bool DUAL> constexpr bool tile_wide() {
+    return PP || (DUAL && TM_DUAL_WIDE && sizeof(Real) == 8) || (TM_ENERGY_WIDE && sizeof(Real) == 8 && U && !X && !PP);
+}
 // LDS traffic of the tile kernel is private to a wave: program order plus a compiler fence is all the synchronisation
 // there is (LDS serves one wave's requests in order).  Never a workgroup barrier -- the waves of a workgroup are at
 // unrelated points of unrelated items.
@@ -626,6 +638,7 @@ template <typename Real> struct TileRegs {
     Real cj[7];       // column atom record
     Real rr[7];       // lanes 0-31: row atom record
     Real ox, oy, oz;  // tile origin (first row atom)
+    Real cj2[3], rr2[3]; // DUAL launches: the same atoms' positions in the second geometry
 };
 
 // INSIDE_SWITCH (f64 forces-only launches): the host vouches for cutoff <= TM_ES_SWITCH_D -- every caller the reference has --
@@ -636,8 +649,14 @@ template <typename Real> struct TileRegs {
 // 16 us of a lone wave's exposed latencies for a full 32 x 64 tile -- and the launch lasts as long as its heaviest item;
 // split, the same work is SPLIT independent chains on different SIMDs.  (Large systems keep SPLIT = 1: several items per
 // wave, and every ticket repeats the item's fetch, its LDS staging and its flush.)
-template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP, bool INSIDE_SWITCH = false, int SPLIT = 1>
-__global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (TileShape<Real, COMPUTE_DU_DP>::min_waves)) void k_nonbonded_tiles(
+// DUAL (energy-only launches; the barostat's fast path, barostat.hip): TWO geometries of the same atoms on the same list in one
+// launch -- the current one (gathered, box) and a proposal (gathered2, box2: every molecule moved rigidly with a box scaled by a
+// fraction of a percent).  The filter runs on the current geometry with a cutoff widened by what a pair distance can change
+// (|s - 1| (|v| + 2 R), R = the largest atom-to-own-centroid distance, handed over in r2_blocks), phase 2 fetches both positions
+// of a pair's atoms and evaluates each geometry's energy behind its own exact cutoff test: the same per-pair function on the same
+// operands as two separate launches, hence the same two integer sums, for the filter, the staging and the queue of one.
+template <typename Real, bool COMPUTE_U, bool COMPUTE_DU_DX, bool COMPUTE_DU_DP, bool INSIDE_SWITCH = false, int SPLIT = 1, bool DUAL = false>
+__global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, COMPUTE_DU_DX, COMPUTE_DU_DP, DUAL>()>::waves), (TileShape<Real, tile_wide<Real, COMPUTE_U, COMPUTE_DU_DX, COMPUTE_DU_DP, DUAL>()>::min_waves)) void k_nonbonded_tiles(
     const int K,                               // atoms in `gathered` (record K is an all-zero sentinel)
     const int NR,                              // number of row atoms
     const int upper_triangular,                // rows == cols == all: keep only row < col
@@ -652,9 +671,14 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     // bonded terms / pair lists before their first tile, adding into out_du_dx (the caller's atom order)
     const FusedTable *__restrict__ fused, const int fused_blocks, const double *__restrict__ coords, u64 *__restrict__ out_du_dx,
     const int out_atom_stride, const int out_comp_stride, const int *__restrict__ out_remap, // layout of out_du_dx (ForceLayout)
-    long long *__restrict__ timing) { // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
+    long long *__restrict__ timing, // timing: debug builds (-DTM_TIMING) only, 8 cycle counters per wave
+    // DUAL launches only (nullptr / 0 otherwise): the second geometry's sorted records, box, atom-order coordinates (for the
+    // piggy-backed table) and partial sums; per-block maxima of |atom - own centroid|^2 from the kernel that made the proposal
+    const Real *__restrict__ gathered2 = nullptr, const double *__restrict__ box2 = nullptr, const double *__restrict__ coords2 = nullptr,
+    i128 *__restrict__ u_partials2 = nullptr, const float *__restrict__ r2_blocks = nullptr, const int n_r2_blocks = 0) {
+    static_assert(!DUAL || (COMPUTE_U && !COMPUTE_DU_DX && !COMPUTE_DU_DP), "DUAL is an energy-only form");
 
-    constexpr int WAVES = TileShape<Real, COMPUTE_DU_DP>::waves;
+    constexpr int WAVES = TileShape<Real, tile_wide<Real, COMPUTE_U, COMPUTE_DU_DX, COMPUTE_DU_DP, DUAL>()>::waves;
     struct WaveLds { // one wave's private scratch
         Real row[7][TILE];
         Real col[7][NB_CHUNK];
@@ -662,6 +686,8 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
         u64 fj[COMPUTE_DU_DX ? 3 : 1][COMPUTE_DU_DX ? NB_CHUNK : 1];
         u64 pi[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? TILE : 1];
         u64 pj[COMPUTE_DU_DP ? 4 : 1][COMPUTE_DU_DP ? NB_CHUNK : 1];
+        Real row2[DUAL ? 3 : 1][DUAL ? TILE : 1];     // DUAL: x y z of the rows / columns in the second geometry
+        Real col2[DUAL ? 3 : 1][DUAL ? NB_CHUNK : 1];
         unsigned int rowatom[TILE];
         float rowflt[5][TILE]; // the rows as the f32 filter sees them: x, y, z relative to the tile origin, w, |r|^2
         unsigned short queue[2 * NB_CHUNK + 4 * NB_CHUNK]; // <= 63 left over in either queue + up to 4 rounds appended between drains
@@ -669,6 +695,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     __shared__ WaveLds s_wave[WAVES];
     __shared__ unsigned int s_ticket; // next position of this workgroup's pool
     __shared__ i128 s_energy[COMPUTE_U ? WAVES : 1]; // energy launches: the waves' sums, added up by thread 0 at the end
+    __shared__ i128 s_energy2[DUAL ? WAVES : 1];
     // f64: the workgroup's copy of the electrostatic force-factor table (12 KB, read-only after the barrier below)
     // (energy launches keep the energy-factor table behind it; the du/dp variants, whose per-wave LDS is the largest, read
     // that one from global memory)
@@ -724,11 +751,28 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
     [[maybe_unused]] const double ps_limit = TM_FIXED_FAST_LIMIT / cutoff_d * 0.999999; // (/ 2^36: the same bound on the prefactor itself)
     const Real beta = static_cast<Real>(beta_d);
     i128 energy = 0;
+    [[maybe_unused]] i128 energy2 = 0;
+    [[maybe_unused]] NbBox<Real> bx2 = bx;
+    double filter_cutoff = cutoff_d;
+    if constexpr (DUAL) {
+        bx2 = load_box<Real>(box2);
+        // the cutoff the filter needs so that a pair inside the cutoff in EITHER geometry passes: |v| <= (|v'| + 2 R |s - 1|) / (1 - |s - 1|)
+        float r2 = 0.0f;
+        for (int k = lane; k < n_r2_blocks; k += 64) {
+            r2 = fmaxf(r2, r2_blocks[k]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            r2 = fmaxf(r2, __shfl_xor(r2, o, 64));
+        }
+        const double ds = fmax(fabs(box2[0] / box[0] - 1.0), fmax(fabs(box2[4] / box[4] - 1.0), fabs(box2[8] / box[8] - 1.0)));
+        filter_cutoff = (cutoff_d + 2.0 * sqrt(static_cast<double>(r2)) * ds * 1.001) / (1.0 - ds) + 1e-6;
+    }
     // phase-1 filter in f32: box, and a cutoff^2 padded far beyond the rounding error of the filter arithmetic
     const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
     const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
     const float fmaxb = fmaxf(fbx, fmaxf(fby, fbz));
-    const float fcut2 = static_cast<float>(cutoff_d * cutoff_d) + 1e-5f * (1.0f + fmaxb) * (1.0f + static_cast<float>(cutoff_d));
+    const float fcut2 = static_cast<float>(filter_cutoff * filter_cutoff) + 1e-5f * (1.0f + fmaxb) * (1.0f + static_cast<float>(filter_cutoff));
     // 1 / the largest |row component| + |column component| (relative to the tile origin) the Gram form of the filter is used for
     const float fex = 1.0f / fminf(0.49f * fbx, TM_GRAM_MAX_EXTENT), fey = 1.0f / fminf(0.49f * fby, TM_GRAM_MAX_EXTENT);
     const float fez = 1.0f / fminf(0.49f * fbz, TM_GRAM_MAX_EXTENT), few = 1.0f / TM_GRAM_MAX_EXTENT;
@@ -849,6 +893,18 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 r.rr[c] = gathered[static_cast<size_t>(r.ra) * 8 + c];
             }
         }
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                r.cj2[c] = gathered2[static_cast<size_t>(r.ja) * 8 + c];
+            }
+            if (lane < TILE) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    r.rr2[c] = gathered2[static_cast<size_t>(r.ra) * 8 + c];
+                }
+            }
+        }
     };
 
 #ifdef TM_TIMING
@@ -911,6 +967,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
             // the energy twin: the plan's bonded terms and pair lists add their energies to this wave's partial sum
             for (int t = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); t < fused_blocks * 4; t += static_cast<int>(total_waves)) {
                 energy += fused_dispatch_energy<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords, box);
+                if constexpr (DUAL) {
+                    energy2 += fused_dispatch_energy<Real>(fused, t >> 2, (t & 3) * 64 + lane, coords2, box2);
+                }
             }
         }
     }
@@ -975,6 +1034,15 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
 #pragma unroll
         for (int c = 0; c < 7; c++) {
             s_col[c][lane] = cur.cj[c];
+        }
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                lds.col2[c][lane] = cur.cj2[c];
+                if (lane < TILE) {
+                    lds.row2[c][lane] = cur.rr2[c];
+                }
+            }
         }
         const bool col_live = ja < uK;
         const float cfx = image(cur.cj[0] - cur.ox, bx.x, bx.inv_x, col_live);
@@ -1143,6 +1211,18 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 // (flat items: w_i - w_j == +0 and fma(0, 0, s) == s, so leaving the term out changes no bit)
                 const Real ddw = FLAT ? static_cast<Real>(0) : ri[3] - cj[3];
                 const Real dd2 = FLAT ? fma_real(ddz, ddz, fma_real(ddy, ddy, ddx * ddx)) : pair_d2(ddx, ddy, ddz, ddw);
+                [[maybe_unused]] Real dd2b = cutoff2; // DUAL: the pair's squared distance in the second geometry
+                if constexpr (DUAL) {
+                    const Real ex = min_image(lds.row2[0][pi] - lds.col2[0][pj], bx2.x, bx2.inv_x);
+                    const Real ey = min_image(lds.row2[1][pi] - lds.col2[1][pj], bx2.y, bx2.inv_y);
+                    const Real ez = min_image(lds.row2[2][pi] - lds.col2[2][pj], bx2.z, bx2.inv_z);
+                    dd2b = FLAT ? fma_real(ez, ez, fma_real(ey, ey, ex * ex)) : pair_d2(ex, ey, ez, ddw);
+                    if (dd2b < cutoff2) {
+                        PairOut<Real> o2;
+                        nb_pair<true>(static_cast<Real>(1), static_cast<Real>(1), ri[4], cj[4], ri[5], cj[5], ri[6], cj[6], dd2b, beta, o2, es_tab);
+                        energy2 += float_to_fixed_energy_hot<Real>(o2.u);
+                    }
+                }
 #ifdef TM_SPLIT_WAIT
                 if constexpr (sizeof(Real) == 8 && TM_LDS_SINGLE_READS && FLAT) {
                     lds_wait_rest6(ri, cj);
@@ -1205,7 +1285,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                     lds_sub(&s_pj[3][pj], gw);
                 }
                 if constexpr (COMPUTE_U) {
-                    energy += float_to_fixed_energy<Real>(o.u);
+                    energy += float_to_fixed_energy_hot<Real>(o.u);
                 }
                 } // forces only / everything else
                 } // exact cutoff test
@@ -1422,6 +1502,21 @@ __global__ __launch_bounds__((64 * TileShape<Real, COMPUTE_DU_DP>::waves), (Tile
                 sum += s_energy[w];
             }
             u_partials[blockIdx.x] = sum;
+        }
+        if constexpr (DUAL) {
+            const i128 total2 = wave_sum_i128(energy2);
+            if (lane == 0) {
+                s_energy2[wave] = total2;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                i128 sum = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) {
+                    sum += s_energy2[w];
+                }
+                u_partials2[blockIdx.x] = sum;
+            }
         }
     }
 }

@@ -821,20 +821,16 @@ template <typename Real>
 void NonbondedAllPairs<Real>::probe_energy(
     const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords, hipStream_t stream,
     const i128 *&partials, int &count) {
-    if (which == 0 && !(static_list() && static_list_built_)) {
-        // the list launch an ordinary evaluation would make: rebuilds iff the update kernel -- or the proposal's own test, made by the
-        // mover -- raised the flag; block bounds and counters are the sorted hand-over's (bounds_done)
-        int *flag = d_flags_.data + (parity_ ^ 1); // (probe_begin has already advanced parity_)
-        const int prof_list = Profiler::get().begin("nblist_build", stream);
-        nblist_.build_device(d_gathered_.data, probe_d_box_, cutoff_ + list_padding(), cutoff_, flag, 0, N_ * 3, pre_x_, d_snap_x_.data, d_snap_box_.data, stream, true, false);
-        Profiler::get().end("nblist_build", prof_list, stream);
+    if (which == 0) {
+        this->probe_list_launch(stream);
     }
     const Real *gathered = which == 0 ? d_gathered_.data : d_gathered2_.data;
     i128 *out = which == 0 ? d_u_partials_.data : d_u_partials2_.data;
     const int n_cus = grid_ / (4 * TileWaves<Real>::value);
     const int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
+    using ProbeShape = TileShape<Real, tile_wide<Real, true, false, false, false>()>;
 #define TM_LAUNCH_PROBE(...)                                                                                            \
-    k_nonbonded_tiles<Real, true, false, false, ##__VA_ARGS__><<<n_cus * TileShape<Real, false>::wgs_per_cu, 64 * TileShape<Real, false>::waves, 0, stream>>>( \
+    k_nonbonded_tiles<Real, true, false, false, ##__VA_ARGS__><<<n_cus * ProbeShape::wgs_per_cu, 64 * ProbeShape::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), 1, nullptr, nblist_.d_counters() + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), \
         nblist_.d_col_atoms(), gathered, d_box_which, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, out, table, \
         table_blocks, coords, nullptr, 3, 1, nullptr, d_timing_.data)
@@ -850,7 +846,49 @@ void NonbondedAllPairs<Real>::probe_energy(
     Profiler::get().end("nonbonded_tiles", prof, stream);
     HIP_CHECK(hipGetLastError());
     partials = out;
-    count = n_cus * TileShape<Real, false>::wgs_per_cu;
+    count = n_cus * ProbeShape::wgs_per_cu;
+}
+
+template <typename Real> void NonbondedAllPairs<Real>::probe_list_launch(hipStream_t stream) {
+    if (static_list() && static_list_built_) {
+        return;
+    }
+    // the list launch an ordinary evaluation would make: rebuilds iff the update kernel -- or the proposal's own test, made by the
+    // mover -- raised the flag; block bounds and counters are the sorted hand-over's (bounds_done)
+    int *flag = d_flags_.data + (parity_ ^ 1); // (probe_begin has already advanced parity_)
+    const int prof_list = Profiler::get().begin("nblist_build", stream);
+    nblist_.build_device(d_gathered_.data, probe_d_box_, cutoff_ + list_padding(), cutoff_, flag, 0, N_ * 3, pre_x_, d_snap_x_.data, d_snap_box_.data, stream, true, false);
+    Profiler::get().end("nblist_build", prof_list, stream);
+}
+
+template <typename Real>
+void NonbondedAllPairs<Real>::probe_energy_dual(
+    const double *d_box2, const FusedTable *table, const int table_blocks, const double *coords, const double *coords2, const float *r2_blocks,
+    const int n_r2, hipStream_t stream, const i128 *&partials, const i128 *&partials2, int &count) {
+    this->probe_list_launch(stream);
+    const int n_cus = grid_ / (4 * TileWaves<Real>::value);
+    const int split = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
+    using DualShape = TileShape<Real, tile_wide<Real, true, false, false, true>()>;
+#define TM_LAUNCH_DUAL(SPLIT)                                                                                           \
+    k_nonbonded_tiles<Real, true, false, false, false, SPLIT, true><<<n_cus * DualShape::wgs_per_cu, 64 * DualShape::waves, 0, stream>>>( \
+        K_, nblist_.get_num_row_idxs(), 1, nullptr, nblist_.d_counters() + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), \
+        nblist_.d_col_atoms(), d_gathered_.data, probe_d_box_, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, \
+        d_u_partials_.data, table, table_blocks, coords, nullptr, 3, 1, nullptr, d_timing_.data, d_gathered2_.data, d_box2, coords2,   \
+        d_u_partials2_.data, r2_blocks, n_r2)
+    const int prof = Profiler::get().begin("nonbonded_tiles", stream);
+    if (split == 4) {
+        TM_LAUNCH_DUAL(4);
+    } else if (split == 2) {
+        TM_LAUNCH_DUAL(2);
+    } else {
+        TM_LAUNCH_DUAL(1);
+    }
+#undef TM_LAUNCH_DUAL
+    Profiler::get().end("nonbonded_tiles", prof, stream);
+    HIP_CHECK(hipGetLastError());
+    partials = d_u_partials_.data;
+    partials2 = d_u_partials2_.data;
+    count = n_cus * DualShape::wgs_per_cu;
 }
 
 template <typename Real> void NonbondedAllPairs<Real>::check_sizes(const int N, const int P) const {
@@ -932,8 +970,8 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (d) K4: tile kernel
     const unsigned int *d_counters = nblist_.d_counters();
 #define TM_LAUNCH_TILES(U, X, PP, ...)                                                                                 \
-    launched_waves = n_cus * TileShape<Real, PP>::wgs_per_cu; /* energy launches leave one partial sum per WORKGROUP */   \
-    k_nonbonded_tiles<Real, U, X, PP, ##__VA_ARGS__><<<n_cus * TileShape<Real, PP>::wgs_per_cu, 64 * TileShape<Real, PP>::waves, 0, stream>>>( \
+    launched_waves = n_cus * TileShape<Real, tile_wide<Real, U, X, PP, false>()>::wgs_per_cu; /* energy launches leave one partial sum per WORKGROUP */   \
+    k_nonbonded_tiles<Real, U, X, PP, ##__VA_ARGS__><<<n_cus * TileShape<Real, tile_wide<Real, U, X, PP, false>()>::wgs_per_cu, 64 * TileShape<Real, tile_wide<Real, U, X, PP, false>()>::waves, 0, stream>>>( \
         K_, nblist_.get_num_row_idxs(), nblist_.upper_triangular() ? 1 : 0, nblist_.row_idxs_or_null(),               \
         d_counters + NB_COUNTER_CLASS0, nblist_.items_cap(), nblist_.d_items(), nblist_.d_col_atoms(), d_gathered_.data,   \
         d_box, beta_, cutoff_, d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, d_u_partials_.data, pig_table, pig_blocks, d_x, pig_acc, pig_atom_stride, pig_comp_stride, pig_remap, \
