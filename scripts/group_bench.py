@@ -22,6 +22,10 @@ for dt, friction, n in ((0.1e-3, 100.0, 300), (0.5e-3, 50.0, 300), (1.0e-3, 10.0
     c = co.Context(x, v, s.box, LangevinIntegrator(300.0, dt, friction, s.masses, 1).impl(), make(np.float32))
     c.multiple_steps(n, 0)
     x, v = c.get_x_t(), c.get_v_t()
+import ctypes  # what the HIP runtime was told about hardware queues: exported by the native library itself when it is loaded (c_api.cpp)
+_libc = ctypes.CDLL(None)
+_libc.getenv.restype = ctypes.c_char_p
+print("binding", getattr(co, "BINDING", "?"), "| GPU_MAX_HW_QUEUES as the runtime sees it:", _libc.getenv(b"GPU_MAX_HW_QUEUES"), "| in os.environ at start:", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
 for n_rep in counts:
     ctxts = [co.Context(x, v, s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, 100 + k).impl(), make(prec)) for k in range(n_rep)]
     co.multiple_steps_group(ctxts, 500)

@@ -231,7 +231,8 @@ template <typename Real, typename GReal>
 __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     const int N, const int adaptive, const unsigned long long seed, const unsigned long long attempt, const double *__restrict__ box,
     double *__restrict__ volume_scale, Real *__restrict__ mv, double *__restrict__ box_proposed, const double *__restrict__ x,
-    double *__restrict__ x_proposed, const int *__restrict__ mol_of_atom, const int *__restrict__ mol_offsets, const int *__restrict__ atom_idxs,
+    double *__restrict__ x_proposed, const int4 *__restrict__ mol_of_atom, // per atom {molecule or -1, its first entry in atom_idxs, its size, its first atom if its atoms are consecutive else -1}
+    const int *__restrict__ atom_idxs,
     const u64 *__restrict__ centroids, // sums of the molecules larger than BAROSTAT_INLINE_MOL (k_barostat_centroids ran first), else unused
     float *__restrict__ r2_blocks,     // [gridDim.x]: this block's largest |atom - own molecule's centroid|^2 (the DUAL tile launch's filter margin)
     const ProbeTarget t) {
@@ -262,13 +263,14 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     }
     if (a < N) {
     double xp[3] = {x[a * 3 + 0], x[a * 3 + 1], x[a * 3 + 2]};
-    const int m = mol_of_atom[a];
+    const int4 info = mol_of_atom[a]; // (one load: the molecule's extent arrives with its number)
+    const int m = info.x;
     if (m >= 0) {
-        const int first = mol_offsets[m], last = mol_offsets[m + 1];
+        const int first = info.y, last = info.y + info.z;
         u64 sum[3] = {0, 0, 0};
         if (last - first <= BAROSTAT_INLINE_MOL) {
             for (int k = first; k < last; k++) { // integer sums: the bits of k_barostat_centroids in any order
-                const int b = atom_idxs[k];
+                const int b = info.w >= 0 ? info.w + (k - first) : atom_idxs[k];
 #pragma unroll
                 for (int d = 0; d < 3; d++) {
                     sum[d] += float_to_fixed<Real>(static_cast<Real>(x[b * 3 + d]));
@@ -543,11 +545,16 @@ MonteCarloBarostat<Real>::MonteCarloBarostat(
     d_counters_.realloc(2);
     this->reset_counters();
     // the fast path's view of the groups: the molecule of every atom
-    std::vector<int> mol_of_atom(static_cast<size_t>(N_), -1);
+    std::vector<int4> mol_of_atom(static_cast<size_t>(N_), make_int4(-1, 0, 0, -1));
     for (int m = 0; m < num_mols_; m++) {
-        max_mol_size_ = std::max(max_mol_size_, mol_offsets[m + 1] - mol_offsets[m]);
-        for (int k = mol_offsets[m]; k < mol_offsets[m + 1]; k++) {
-            mol_of_atom[atom_idxs[k]] = m;
+        const int first = mol_offsets[m], size = mol_offsets[m + 1] - mol_offsets[m];
+        max_mol_size_ = std::max(max_mol_size_, size);
+        bool consecutive = true; // (atom_idxs is sorted within a molecule)
+        for (int k = first + 1; k < first + size; k++) {
+            consecutive = consecutive && atom_idxs[k] == atom_idxs[k - 1] + 1;
+        }
+        for (int k = first; k < first + size; k++) {
+            mol_of_atom[atom_idxs[k]] = make_int4(m, first, size, consecutive ? atom_idxs[first] : -1);
         }
     }
     d_mol_of_atom_.realloc(std::max(N_, 1));
@@ -602,7 +609,7 @@ template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(dou
 #define TM_BAROSTAT_FAST(GREAL)                                                                                        \
     k_barostat_propose_probe<Real, GREAL><<<n_prop_blocks, 256, 0, stream>>>(                                            \
         N_, adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data, d_x, d_x_proposed_.data, \
-        d_mol_of_atom_.data, d_mol_offsets_.data, d_atom_idxs_.data, d_centroids_.data, d_r2_blocks_.data, t);           \
+        d_mol_of_atom_.data, d_atom_idxs_.data, d_centroids_.data, d_r2_blocks_.data, t);                                \
     HIP_CHECK(hipGetLastError());                                                                                      \
     if (g_barostat_dual_launch) {                                                                                      \
         nb->probe_energy_dual(d_box_proposed_.data, tables[prec], blocks[prec], d_x, d_x_proposed_.data, d_r2_blocks_.data, n_prop_blocks, stream, p0, p1, n0); \

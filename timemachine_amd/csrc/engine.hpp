@@ -879,7 +879,7 @@ private:
     ForcePlan plan_; // the two energy evaluations of an attempt
     void reset_counters();
     // ---- fast path (barostat.hip: move_on_current_list): both energies on the nonbonded potential's current list ----
-    DeviceBuffer<int> d_mol_of_atom_;   // [N]: molecule of each atom, -1 = not grouped
+    DeviceBuffer<int4> d_mol_of_atom_;  // [N]: {molecule of the atom (-1: not grouped), its first entry in atom_idxs, its size, its first atom if consecutive else -1}
     DeviceBuffer<float> d_r2_blocks_;   // per block of the proposal kernel: max |atom - own centroid|^2 (the DUAL tile launch's filter margin)
     int max_mol_size_ = 0;
     long long fast_attempts_ = 0;

@@ -907,6 +907,20 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
         }
     };
 
+#ifdef TM_TIMING_BATCH
+    // the per-batch timeline: wall cycles of one wave between stamps inside the batch body, each stamp behind a
+    // wait for the wave's own outstanding LDS operations; sums over the wave's batches (wave-uniform: scalar registers)
+    long long tm_tb[7] = {0, 0, 0, 0, 0, 0, 0}, tm_tb_last = 0, tm_tb_n = 0;
+#define TM_TB(k)                                                                                                       \
+    {                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        const long long n_ = clock64();                                                                                \
+        tm_tb[k] += n_ - tm_tb_last;                                                                                   \
+        tm_tb_last = n_;                                                                                               \
+    }
+#else
+#define TM_TB(k)
+#endif
 #ifdef TM_TIMING
     long long tm_setup = 0, tm_p1 = 0, tm_p2 = 0, tm_flush = 0, tm_items = 0, tm_batches = 0, tm_bc = 0, tm_stage_a = 0;
     const long long tm_begin = clock64();
@@ -1164,12 +1178,17 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
 #ifdef TM_SETPRIO
             __builtin_amdgcn_s_setprio(TM_SETPRIO); // experiment: a wave inside its batch (one long dependent chain) issues ahead of its SIMD neighbours' filter rounds
 #endif
+#ifdef TM_TIMING_BATCH
+            tm_tb_last = clock64();
+            tm_tb_n++;
+#endif
             if (active) {
                 // a queue entry is (round << 11) | column lane: the row slot follows from the round's lane arrangement
                 const unsigned int e = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short *>(static_cast<unsigned long>(entry_addr));
                 const unsigned int pj = e & 0xffu;
                 const unsigned int rnd = e >> 11;
                 const unsigned int pi = ((pj - rnd) & 15u) | (((pj >> 1) ^ rnd) & 16u);
+                TM_TB(0); // queue entry fetched and decoded
                 Real ri[7], cj[7]; // x, y, z, w, q, sig, eps of the pair's row / column atom
                 if constexpr (sizeof(Real) == 8 && TM_LDS_SINGLE_READS) {
                     // fourteen (flat items: twelve) single ds_read_b64 (2 LDS cycles each; row reads are conflict free: 32 rows =
@@ -1202,6 +1221,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                         cj[c] = s_col[c][pj];
                     }
                 }
+                TM_TB(1); // twelve / fourteen operands fetched
                 Real ddx = ri[0] - cj[0], ddy = ri[1] - cj[1], ddz = ri[2] - cj[2];
                 if (hint<F64>(!raw_compact, false)) { // wave-uniform; for a compact tile the three rint / fma pairs are exact no-ops
                     ddx = min_image(ddx, bx.x, bx.inv_x);
@@ -1228,6 +1248,14 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     lds_wait_rest6(ri, cj);
                 }
 #endif
+#ifdef TM_TIMING_BATCH
+                asm volatile("" : "+v"(ddx), "+v"(ddy), "+v"(ddz)); // (the stamp must not be hoisted over the arithmetic)
+                {
+                    Real pin = dd2;
+                    asm volatile("" : "+v"(pin));
+                    TM_TB(2); // displacement, d^2
+                }
+#endif
                 if (dd2 < cutoff2) { // the exact, strict test: atoms with w == cutoff never interact
                 const Real qi = ri[4], qj = cj[4];
                 const Real sig_i = ri[5], sig_j = cj[5], eps_i = ri[6], eps_j = cj[6];
@@ -1235,9 +1263,17 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     // MD: the prefactor only, and ONE wave-uniform escape for both rare cases -- d2 under the table
                     // (clashing atoms: analytic electrostatics) and a product beyond the fast conversion's range
                     bool below, big;
-                    const double prefactor = nb_pair_prefactor_deferred<INSIDE_SWITCH>(1.0, 1.0, qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, es_tab, below);
+                    double prefactor = nb_pair_prefactor_deferred<INSIDE_SWITCH>(1.0, 1.0, qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, es_tab, below);
+#ifdef TM_TIMING_BATCH
+                    asm volatile("" : "+v"(prefactor));
+                    TM_TB(3); // table index, table fetch, polynomial, Lennard-Jones, prefactor
+#endif
                     u64 fx, fy, fz;
                     pair_force_fixed_fast_bounded(prefactor, ddx, ddy, ddz, ps_limit, fx, fy, fz, big);
+#ifdef TM_TIMING_BATCH
+                    asm volatile("" : "+v"(fx), "+v"(fy), "+v"(fz));
+                    TM_TB(4); // three products, magic-add conversions
+#endif
                     const bool rare = below || big;
                     if (__builtin_expect(__ballot(rare) != 0ull, 0)) {
                         if (rare) {
@@ -1256,6 +1292,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     lds_sub(&s_fj[0][apj], fx); // FIX(-p d) == -FIX(p d)
                     lds_sub(&s_fj[1][apj], fy);
                     lds_sub(&s_fj[2][apj], fz);
+                    TM_TB(5); // six LDS atomics issued and acknowledged
                 } else {
                 PairOut<Real> o;
                 nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
@@ -1467,7 +1504,16 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
         item = item_next;
         sub_cur = sub_next;
     }
-#ifdef TM_TIMING
+#ifdef TM_TIMING_BATCH
+    if (lane == 0 && timing) { // (a TM_TIMING_BATCH build reports the batch timeline INSTEAD of the phase counters)
+        long long *t = timing + static_cast<size_t>(global_wave) * 8;
+        for (int k = 0; k < 6; k++) {
+            t[k] = tm_tb[k];
+        }
+        t[6] = 1; // (marks the record as filled: the readers test column 6)
+        t[7] = tm_tb_n;
+    }
+#elif defined(TM_TIMING)
     if (lane == 0 && timing) {
         long long *t = timing + static_cast<size_t>(global_wave) * 8;
 #ifdef TM_TIMING_PRO

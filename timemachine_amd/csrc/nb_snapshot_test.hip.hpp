@@ -24,7 +24,6 @@ __device__ __forceinline__ bool snapshot_calls_for_rebuild(
     const double x, const double y, const double z, const double *__restrict__ snap, const double *__restrict__ box,
     const double *__restrict__ snap_box, const double threshold2) {
     bool same = true, scalable = true;
-    double rho[3], b[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
 #pragma unroll
@@ -35,21 +34,27 @@ __device__ __forceinline__ bool snapshot_calls_for_rebuild(
                 scalable = scalable && now == then; // off-diagonal entries (zeros) must not have changed
             }
         }
-        b[d] = box[d * 4];
-        rho[d] = b[d] / snap_box[d * 4];
-        scalable = scalable && fabs(rho[d] * snap_box[9 + d] - 1.0) <= NB_SCALE_MAX; // (false for NaN / inf: an uninitialised snapshot)
     }
     double ex = x - snap[0], ey = y - snap[1], ez = z - snap[2];
-    if (!same) {
+    if (!same) { // (wave-uniform: the box is the launch's)
+        // hardware reciprocals (1 ulp) instead of six f64 divisions per atom: this test decides WHEN a list is rebuilt, never a
+        // result, and both the scale bound and the threshold carry orders of magnitude more slack than 1e-16 relative
+        double e[3];
+        const double xyz[3] = {x, y, z};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double b = box[d * 4];
+            const double rho = b * __builtin_amdgcn_rcp(snap_box[d * 4]);
+            scalable = scalable && fabs(rho * snap_box[9 + d] - 1.0) <= NB_SCALE_MAX; // (false for NaN / inf: an uninitialised snapshot)
+            e[d] = xyz[d] - rho * snap[d];
+            e[d] -= b * rint(e[d] * __builtin_amdgcn_rcp(b));
+        }
         if (!scalable) {
             return true;
         }
-        ex = x - rho[0] * snap[0];
-        ey = y - rho[1] * snap[1];
-        ez = z - rho[2] * snap[2];
-        ex -= b[0] * rint(ex / b[0]);
-        ey -= b[1] * rint(ey / b[1]);
-        ez -= b[2] * rint(ez / b[2]);
+        ex = e[0];
+        ey = e[1];
+        ez = e[2];
     }
     return ex * ex + ey * ey + ez * ez > threshold2;
 }
