@@ -21,7 +21,21 @@ __device__ __forceinline__ void grid_barrier(unsigned int *counter, const unsign
     __syncthreads();
 }
 
-template <int MODE> // 0: atomic load / store of the data; 1: plain accesses + fences; 2: barriers only (no data)
+// the barrier of MODE 3: no cache maintenance at all -- a workgroup-scope release (the wave's own memory operations have completed) and a
+// RELAXED spin (an acquire load at agent scope invalidates the whole L2 of its XCD on every iteration)
+__device__ __forceinline__ void grid_barrier_light(unsigned int *counter, const unsigned int target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+template <int MODE> // 0: atomic load / store of the data; 1: plain accesses + fences; 2: barriers only (no data); 3: plain accesses to UNCACHED memory, light barrier
 __global__ __launch_bounds__(256) void k_persistent(const int steps, unsigned int *counter, double *data, unsigned int *errors) {
     const unsigned int G = gridDim.x, tid = blockIdx.x * 256 + threadIdx.x, n = G * 256;
     unsigned int bad = 0;
@@ -32,8 +46,14 @@ __global__ __launch_bounds__(256) void k_persistent(const int steps, unsigned in
         } else if (MODE == 1) {
             data[tid] = v + tid;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        } else if (MODE == 3) {
+            data[tid] = v + tid;
         }
-        grid_barrier(counter, (2u * s + 1u) * G);
+        if (MODE == 3) {
+            grid_barrier_light(counter, (2u * s + 1u) * G);
+        } else {
+            grid_barrier(counter, (2u * s + 1u) * G);
+        }
         const unsigned int src = (tid + 256u * (1u + (G > 8 ? 8u : 0u) / 2u) + 77u) % n; // another workgroup's slot (another XCD when G > 8)
         double got = 0;
         if (MODE == 0) {
@@ -41,9 +61,15 @@ __global__ __launch_bounds__(256) void k_persistent(const int steps, unsigned in
         } else if (MODE == 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             got = data[src];
+        } else if (MODE == 3) {
+            got = *const_cast<volatile double *>(data + src);
         }
         bad += (MODE != 2 && got != v + src) ? 1u : 0u;
-        grid_barrier(counter, (2u * s + 2u) * G);
+        if (MODE == 3) {
+            grid_barrier_light(counter, (2u * s + 2u) * G);
+        } else {
+            grid_barrier(counter, (2u * s + 2u) * G);
+        }
     }
     if (bad) {
         atomicAdd(errors, bad);
@@ -78,8 +104,11 @@ int main() {
     CHECK(hipMalloc(&d_counter, 4));
     CHECK(hipMalloc(&d_err, 4));
     CHECK(hipMalloc(&d_data, 256 * 256 * sizeof(double)));
+    double *d_uncached;
+    CHECK(hipExtMallocWithFlags(reinterpret_cast<void **>(&d_uncached), 256 * 256 * sizeof(double), hipDeviceMallocUncached));
     const int steps = 2000;
-    for (int G : {8, 32, 64, 128, 256}) {
+    for (int G : {4, 8, 16, 32, 64, 128, 256}) {
+        if (run<3>("plain accesses to UNCACHED memory, light barrier", G, steps, d_counter, d_uncached, d_err)) return 1;
         if (run<2>("barriers only", G, steps, d_counter, d_data, d_err)) return 1;
         if (run<0>("agent-scope atomic load / store of the data", G, steps, d_counter, d_data, d_err)) return 1;
         if (run<1>("plain accesses + agent release / acquire fences", G, steps, d_counter, d_data, d_err)) return 1;

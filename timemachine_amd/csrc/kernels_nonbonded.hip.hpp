@@ -740,7 +740,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
     using TileTab = std::conditional_t<sizeof(Real) == 8, EsTableLds, EsTableNone>;
     TileTab es_tab{};
     if constexpr (sizeof(Real) == 8) {
+#ifdef TM_TABLE_L1 // experiment (round 5): the force-factor table read through the vector L1 (global loads) instead of its LDS copy -- the LDS pipe is the busiest unit of the kernel (per-batch timeline).  Measured: 55.3-55.8 us against 55.0-55.7: no difference
+        es_tab.tab = (!COMPUTE_U && COMPUTE_DU_DX && !COMPUTE_DU_DP) ? es_table : s_es_tab;
+#else
         es_tab.tab = s_es_tab;
+#endif
         es_tab.gtab = G_IN_LDS ? s_es_tab + ES_TAB_DOUBLES : es_table + ES_TAB_DOUBLES;
     }
     constexpr bool F64 = sizeof(Real) == 8; // (hints for the f32 kernels too: re-measured at the end of round 2, +0.1 %, not applied)
