@@ -506,6 +506,36 @@ void VelocityVerletIntegrator::finalize(
 template class LangevinIntegrator<float>;
 template class LangevinIntegrator<double>;
 
+// Waiting for a long MD call without burning a CPU: hipStreamSynchronize spins (the runtime's default wait policy), so a rank whose
+// host thread has enqueued its 2 000 steps in 16 ms then keeps one CPU at 100 % for the 140 ms the device needs -- eight ranks: eight
+// of the sixteen CPUs a GPU box grants.  Instead: an event behind the enqueued work, polled with short sleeps (the first polls come
+// quickly so that short calls -- single steps, tests -- do not wait a sleep's length for nothing).  TM_AMD_SPIN_WAIT=1 restores the
+// runtime's own wait.
+static void wait_for_stream(hipStream_t stream) {
+    static const bool spin = std::getenv("TM_AMD_SPIN_WAIT") != nullptr;
+    if (spin) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
+    static thread_local hipEvent_t ev = nullptr;
+    if (ev == nullptr) {
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(ev, stream));
+    for (int polls = 0;; polls++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) {
+            return;
+        }
+        if (e != hipErrorNotReady) {
+            HIP_CHECK(e);
+        }
+        if (polls >= 200) { // ~ the first 100-200 us are polled back to back; after that the call is a long one
+            std::this_thread::sleep_for(std::chrono::microseconds(30));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 Context::Context(
     int N, const double *x_0, const double *v_0, const double *box_0, std::shared_ptr<Integrator> intg,
@@ -609,6 +639,9 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
         if (i % store_x_interval == 0) {
             double *box_ptr = h_box + static_cast<size_t>(i / store_x_interval - 1) * 9;
             double *coord_ptr = h_x + static_cast<size_t>(i / store_x_interval - 1) * N_ * 3;
+            // (a device-to-host copy into the caller's pageable array blocks the host -- spinning -- until everything enqueued before it
+            // has run: wait for that politely first, then the copy is a matter of microseconds)
+            wait_for_stream(stream);
             HIP_CHECK(hipMemcpyAsync(coord_ptr, d_x_t_.data, static_cast<size_t>(N_) * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipMemcpyAsync(box_ptr, d_box_t_.data, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
@@ -616,7 +649,7 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
         }
     }
     intg_->finalize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
-    HIP_CHECK(hipStreamSynchronize(stream));
+    wait_for_stream(stream);
 }
 
 // The streams a group of contexts is stepped on: created once, one after the other, so that the runtime hands them distinct
@@ -790,7 +823,7 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
         throw;
     }
     for (hipStream_t q : st) {
-        HIP_CHECK(hipStreamSynchronize(q));
+        wait_for_stream(q);
     }
 }
 
@@ -846,6 +879,7 @@ void Context::_run_local_steps(const int n_steps, const int n_samples, double *h
             if (i % store_x_interval == 0) {
                 double *box_ptr = h_box + static_cast<size_t>(i / store_x_interval - 1) * 9;
                 double *coord_ptr = h_x + static_cast<size_t>(i / store_x_interval - 1) * N_ * 3;
+                wait_for_stream(stream); // (see Context::multiple_steps)
                 HIP_CHECK(hipMemcpyAsync(coord_ptr, d_x_t_.data, static_cast<size_t>(N_) * 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipMemcpyAsync(box_ptr, d_box_t_.data, 9 * sizeof(double), hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
