@@ -10,7 +10,7 @@ from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 co.set_device(0)
-s = ts.dhfr_shaped_box()
+s = {"dhfr": ts.dhfr_shaped_box, "water": ts.dhfr_sized_water_box, "config2": ts.small_solvated_ligand, "water900": lambda: ts.build_water_box(300, 3.0)}[os.environ.get("SYSTEM", "dhfr")]()
 def make(p):
     bps = ts.bound_potentials(s, p, nblist_padding=0.18)
     summed = P.SummedPotential([bp.potential for bp in bps], [bp.params for bp in bps])

@@ -31,11 +31,16 @@ for name, s in systems:
     ctxt = co.Context(eq.get_x_t(), eq.get_v_t(), s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, 5).impl(), make(prec))
     ctxt.multiple_steps(1000, 0)
     import time
+    import psutil
+    _proc = psutil.Process()
+    th0 = {t.id: t.user_time + t.system_time for t in _proc.threads()}
     c0, w0 = time.process_time(), time.perf_counter()
     ctxt.multiple_steps(4000, 0)
+    th1 = {t.id: t.user_time + t.system_time for t in _proc.threads()}
+    busiest = sorted(((th1[k] - th0.get(k, 0.0)) / (time.perf_counter() - w0) for k in th1), reverse=True)[:3]
     ms = ctxt.last_multiple_steps_ms()
     ctxt.get_x_t()  # (waits for the device)
     cpu_us, wall_us = 1e6 * (time.process_time() - c0) / 4000, 1e6 * (time.perf_counter() - w0) / 4000
     # host columns: wall clock of the call per step (== the device's when the host keeps up) and process CPU time per step (launch
     # thread + HIP runtime helpers): a step whose host cost exceeds its device time is HOST-bound
-    print(f"{name:14s} N={s.num_atoms:6d}  {1e3 * ms / 4000:7.2f} us/step  {4000 / (1e-3 * ms) * 86400 * 2.5e-6:9.1f} ns/day   host: wall {wall_us:6.2f} us/step, cpu {cpu_us:6.2f} us/step", flush=True)
+    print(f"{name:14s} N={s.num_atoms:6d}  {1e3 * ms / 4000:7.2f} us/step  {4000 / (1e-3 * ms) * 86400 * 2.5e-6:9.1f} ns/day   host: wall {wall_us:6.2f} us/step, cpu {cpu_us:6.2f} us/step, busiest threads {[round(b, 2) for b in busiest]}", flush=True)
