@@ -170,8 +170,14 @@ def test_committed_bench_lines_follow_the_contract():
         for k in d["kernels"]:
             for key in ("us_per_step", "launches_per_step", "us_per_launch", "algorithmic_bytes_per_step", "frac_of_hbm_peak", "share_of_step"):
                 assert key in k and k[key] >= 0, (k["name"], key)
-        # three kernels make the step: together they account for (nearly) all of it
-        assert 0.9 < sum(k["share_of_step"] for k in d["kernels"]) < 1.3
+        # three kernels make the step.  Up to round 4 the shares were us of the PROFILED run over the TIMED step (they summed to
+        # 1.12); from round 5 on both come from the profiled run -- one clock -- and the rest of that step is the profiler's own
+        # event records between the launches: the shares sum to less than one
+        total = sum(k["share_of_step"] for k in d["kernels"])
+        if os.path.basename(paths[-1]) >= "r05":
+            assert 0.7 < total <= 1.0 and d["kernels_profiled_us_per_step"] > 1e3 * d["ms_per_step"]
+        else:
+            assert 0.9 < total < 1.3
         for key in ("host_cpu_us_per_step", "cpu_quota", "host_cpu_load"):
             assert key in d and d[key] > 0, key
         for key in ("traffic_build_stamp", "library_build_stamp", "traffic_stale"):
