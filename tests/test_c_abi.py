@@ -228,3 +228,29 @@ def test_es_force_table_matches_the_analytic_function():
         G = e * S / d
         assert np.all(np.abs(p - G) < 3e-11 * np.abs(G) + 1e-11)
         assert np.max(np.abs(p - G)[s < 1.0] / np.abs(G)[s < 1.0]) < (6e-12 if beta == 2.0 else 3e-11)
+
+
+def test_loading_the_library_exports_the_hardware_queue_count():
+    """Streams of contexts stepped together (tm_context_multiple_steps_group) need hardware queues of their own; the HIP runtime reads
+    GPU_MAX_HW_QUEUES when it first touches the device.  The LIBRARY exports 8 from a constructor when it is loaded -- a C-ABI consumer
+    that never imports the Python package gets it too (include/timemachine_amd.h) -- and leaves a value the user chose alone."""
+    import subprocess
+    import sys
+
+    probe = (
+        "import ctypes, sys\n"
+        "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+        "before = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+        f"ctypes.CDLL({LIB!r})\n"
+        "after = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+        "print(before, after)\n"
+    )
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["None", "b'8'"], out.stdout
+    out = subprocess.run([sys.executable, "-c", probe], env=dict(env, GPU_MAX_HW_QUEUES="3"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["b'3'", "b'3'"], (out.stdout, out.stderr[-500:])
+    # ... and the Python package itself does not touch the environment any more
+    text = open(os.path.join(REPO, "timemachine_amd", "__init__.py")).read()
+    assert "environ" not in text
