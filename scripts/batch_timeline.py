@@ -14,9 +14,9 @@ from timemachine_amd.lib import custom_ops as co  # noqa: E402
 co.set_device(0)
 s = ts.dhfr_shaped_box()
 x = np.load(os.environ.get("FRAME", "/tmp/tile_ablate_frame.npz"))["x"]
-names = ["queue entry read + decode", "operand fetch (12 ds_read_b64 + wait)", "displacement, d^2", "table index + fetch + polynomial + LJ + prefactor",
+names = ["queue entry read + decode", "operand fetch (12 LDS reads + wait)", "displacement, d^2", "pair function (f64: table index + fetch + polynomial + LJ; f32: analytic erfc / exp / switch + LJ)",
          "3 products + magic-add conversion", "6 LDS atomics (issued + acknowledged)"]
-for prec in (np.float64,):
+for prec in (np.float64, np.float32):
     nb = P.NonbondedAllPairs(s.num_atoms, s.beta, s.cutoff, nblist_padding=0.18).to_gpu(prec).unbound_impl
     for _ in range(5):
         nb.execute(x, s.nb_params, s.box, True, False, False)
@@ -29,5 +29,5 @@ for prec in (np.float64,):
     for k, name in enumerate(names):
         c = t[:, k].sum() / n
         tot += c
-        print(f"  {name:52s} {c:7.0f} cycles")
-    print(f"  {'sum':52s} {tot:7.0f} cycles per batch (stamps serialise the wave's own LDS traffic: an upper bound on the unstamped 1 370)")
+        print(f"  {name:100s} {c:7.0f} cycles")
+    print(f"  {'sum':100s} {tot:7.0f} cycles per batch (stamps serialise the wave's own LDS traffic: an upper bound on the unstamped batch)")

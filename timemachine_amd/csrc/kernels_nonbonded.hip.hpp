@@ -1300,16 +1300,25 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                 } else {
                 PairOut<Real> o;
                 nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
+#ifdef TM_TIMING_BATCH
+                asm volatile("" : "+v"(o.prefactor));
+                TM_TB(3); // (f32: analytic erfc / exp / switch, Lennard-Jones, prefactor)
+#endif
                 if constexpr (COMPUTE_DU_DX) {
                     u64 fx, fy, fz;
                     // (f32: one range test on the prefactor instead of three on the products: 3204 -> 3241 ns/day; same bits)
                     pair_force_fixed_bounded(o.prefactor, ddx, ddy, ddz, static_cast<Real>(ps_limit * (1.0 / 68719476736.0)), fx, fy, fz);
+#ifdef TM_TIMING_BATCH
+                    asm volatile("" : "+v"(fx), "+v"(fy), "+v"(fz));
+                    TM_TB(4);
+#endif
                     lds_add(&s_fi[0][pi], fx);
                     lds_add(&s_fi[1][pi], fy);
                     lds_add(&s_fi[2][pi], fz);
                     lds_sub(&s_fj[0][pj], fx); // FIX(-p d) == -FIX(p d)
                     lds_sub(&s_fj[1][pj], fy);
                     lds_sub(&s_fj[2][pj], fz);
+                    TM_TB(5);
                 }
                 if constexpr (COMPUTE_DU_DP) {
                     lds_add(&s_pi[0][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qj * o.inv_dij * o.ebd));
