@@ -536,6 +536,52 @@ static void wait_for_stream(hipStream_t stream) {
     }
 }
 
+// Bounded run-ahead.  The enqueueing host is several times faster than the device (6-10 us against 70 us per DHFR-sized step), and
+// the HIP runtime lets it run ahead only so far: past a few thousand launches in flight every further launch SPINS inside the runtime
+// until a slot frees up -- measured: a 2 000-step call kept 0.3 CPUs busy, a 4 000-step call 0.9, and every call after it 0.9 as
+// well (scripts/host_cpu_probe2.py).  So the host throttles itself before the runtime does: every RUN_AHEAD_STEPS steps it marks
+// the stream with an event and, before going on, waits -- sleeping -- for the mark of the chunk before the last: at most two
+// chunks (~750 launches) are ever in flight, which is far more than the device needs to stay busy.
+struct RunAhead {
+    static const int RUN_AHEAD_STEPS = 128;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
+    int chunk = 0;
+    ~RunAhead() {
+        for (hipEvent_t e : ev) {
+            if (e) {
+                (void)hipEventDestroy(e);
+            }
+        }
+    }
+    void after_step(const int i, hipStream_t stream) { // i: steps enqueued so far on `stream`
+        static const bool spin = std::getenv("TM_AMD_SPIN_WAIT") != nullptr;
+        if (spin || i % RUN_AHEAD_STEPS != 0) {
+            return;
+        }
+        const int cur = chunk & 1, prev = cur ^ 1;
+        if (ev[cur] == nullptr) {
+            HIP_CHECK(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
+        }
+        HIP_CHECK(hipEventRecord(ev[cur], stream));
+        pending[cur] = true;
+        if (pending[prev]) {
+            for (;;) {
+                const hipError_t e = hipEventQuery(ev[prev]);
+                if (e == hipSuccess) {
+                    break;
+                }
+                if (e != hipErrorNotReady) {
+                    HIP_CHECK(e);
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            pending[prev] = false;
+        }
+        chunk++;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 Context::Context(
     int N, const double *x_0, const double *v_0, const double *box_0, std::shared_ptr<Integrator> intg,
@@ -630,8 +676,10 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     if (n_steps > 0) {
         HIP_CHECK(hipEventRecord(ev_start_, stream));
     }
+    RunAhead run_ahead;
     for (int i = 1; i <= n_steps; i++) {
         this->_step(stream);
+        run_ahead.after_step(i, stream);
         if (i == n_steps) {
             HIP_CHECK(hipEventRecord(ev_stop_, stream));
             ev_valid_ = true;
@@ -770,9 +818,11 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
         n_threads = 1; // (so does the guard-zone allocator of debug builds)
 #endif
         if (n_threads <= 1) {
+            std::vector<RunAhead> run_ahead(ctxts.size());
             for (int i = 1; i <= n_steps; i++) {
                 for (size_t k = 0; k < ctxts.size(); k++) { // one step of every context per round: their launches alternate in the device's queues
                     ctxts[k]->_step(st[k]);
+                    run_ahead[k].after_step(i, st[k]);
                 }
             }
         } else {
@@ -784,9 +834,11 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
                 workers.emplace_back([&, w]() {
                     try {
                         HIP_CHECK(hipSetDevice(dev)); // (the current device is per-thread state)
+                        std::vector<RunAhead> run_ahead(ctxts.size());
                         for (int i = 1; i <= n_steps; i++) {
                             for (size_t k = w; k < ctxts.size(); k += n_threads) {
                                 ctxts[k]->_step(st[k]);
+                                run_ahead[k].after_step(i, st[k]);
                             }
                         }
                     } catch (...) {
