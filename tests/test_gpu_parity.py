@@ -1320,6 +1320,43 @@ def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
 
 
 @pytest.mark.parametrize("threads", ["1", "2"])
+def test_calls_longer_than_the_run_ahead_bound_are_bitwise_short_calls(co, P, threads, monkeypatch):
+    """The stepping loops let the host run at most two chunks of 128 steps ahead of the device (csrc/integrator.hip, RunAhead):
+    a call of 700 steps crosses the bound five times, waits on the chunk before the last each time, and must leave the state that
+    seven calls of 100 steps -- none of which ever waits -- leave, bit for bit; alone (with frames: their copies wait as well)
+    and grouped."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    monkeypatch.setenv("TM_AMD_GROUP_THREADS", threads)
+    s = ts.small_solvated_ligand(lamb=0.3)
+    N = s.num_atoms
+    x0 = s.coords.astype(np.float32).astype(np.float64)
+
+    def contexts(n):
+        out = []
+        for k in range(n):
+            bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s, np.float32)]
+            movers = [MonteCarloBarostat(N, 1.0, 300.0, ts.molecule_groups(s), 25, 9 + k).impl(bps)]
+            out.append(co.Context(x0, np.zeros_like(x0), s.box, LangevinIntegrator(300.0, 1.5e-3, 2.0, s.masses, 70 + k).impl(), bps, movers=movers))
+        return out
+
+    short, long_, grouped = contexts(3), contexts(3), contexts(3)
+    for c in short:
+        for _ in range(7):
+            c.multiple_steps(100, 0)
+    frames = [c.multiple_steps(700, 350) for c in long_]
+    co.multiple_steps_group(grouped, 700)
+    for a, b, g, (xs, boxes) in zip(short, long_, grouped, frames):
+        assert xs.shape[0] == 2
+        np.testing.assert_array_equal(xs[-1], b.get_x_t())
+        for other in (b, g):
+            np.testing.assert_array_equal(a.get_x_t(), other.get_x_t())
+            np.testing.assert_array_equal(a.get_v_t(), other.get_v_t())
+            np.testing.assert_array_equal(a.get_box(), other.get_box())
+
+
+@pytest.mark.parametrize("threads", ["1", "2"])
 @pytest.mark.parametrize("precision", [np.float64, np.float32])
 @pytest.mark.parametrize("which", ["listed_small", "dhfr_shaped"])
 def test_group_stepping_on_the_listed_pipeline_is_bitwise_separate_stepping(co, P, which, precision, threads):
