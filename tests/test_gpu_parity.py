@@ -1321,12 +1321,12 @@ def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
 
 @pytest.mark.parametrize("threads", ["1", "2"])
 def test_calls_longer_than_the_run_ahead_bound_are_bitwise_short_calls(co, P, threads, monkeypatch):
-    """The stepping loops let the host run at most two chunks of 128 steps ahead of the device (csrc/integrator.hip, RunAhead):
-    a call of 700 steps crosses the bound five times, waits on the chunk before the last each time, and must leave the state that
-    seven calls of 100 steps -- none of which ever waits -- leave, bit for bit; alone (with frames: their copies wait as well)
-    and grouped."""
+    """The stepping loops keep the host a bounded number of steps ahead of the device (csrc/integrator.hip, RunAhead: at most 32
+    by the Langevin integrator's progress word; an event every 32 steps for an integrator without one -- VelocityVerlet).  A call of
+    700 steps sleeps on that bound many times and must leave the state that short calls leave, bit for bit: alone (with frames:
+    their copies wait as well), grouped, and under the velocity Verlet integrator."""
     from timemachine_amd import testsystems as ts
-    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat, VelocityVerletIntegrator
 
     monkeypatch.setenv("TM_AMD_GROUP_THREADS", threads)
     s = ts.small_solvated_ligand(lamb=0.3)
@@ -1340,6 +1340,19 @@ def test_calls_longer_than_the_run_ahead_bound_are_bitwise_short_calls(co, P, th
             movers = [MonteCarloBarostat(N, 1.0, 300.0, ts.molecule_groups(s), 25, 9 + k).impl(bps)]
             out.append(co.Context(x0, np.zeros_like(x0), s.box, LangevinIntegrator(300.0, 1.5e-3, 2.0, s.masses, 70 + k).impl(), bps, movers=movers))
         return out
+
+    def verlet():
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s, np.float32)]
+        return co.Context(x0, np.zeros_like(x0), s.box, VelocityVerletIntegrator(0.5e-3, s.masses).impl(), bps)
+
+    vv_short, vv_long = verlet(), verlet()
+    vv_short.initialize()  # (a call per step never meets the bound; initialize / finalize as multiple_steps places them)
+    for _ in range(200):
+        vv_short.step()
+    vv_short.finalize()
+    vv_long.multiple_steps(200, 0)
+    np.testing.assert_array_equal(vv_short.get_x_t(), vv_long.get_x_t())
+    np.testing.assert_array_equal(vv_short.get_v_t(), vv_long.get_v_t())
 
     short, long_, grouped = contexts(3), contexts(3), contexts(3)
     for c in short:

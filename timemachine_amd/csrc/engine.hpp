@@ -747,12 +747,20 @@ public:
     virtual void finalize(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) = 0;
     // coordinates or velocities were changed behind the integrator's back (Context setters, movers): drop derived state
     virtual void invalidate_state_cache() {}
+    // Optional progress word: a 32-bit counter in pinned host memory in which the update kernel of every step leaves the number of
+    // steps this integrator has enqueued so far (progress_enqueued) -- from one thread, as the kernel starts.  The stepping loops
+    // read it to stay a bounded number of steps ahead of the device without a runtime call (integrator.hip, RunAhead).
+    virtual const volatile unsigned int *progress_word() const { return nullptr; }
+    virtual unsigned int progress_enqueued() const { return 0; }
 };
 
 template <typename Real> class LangevinIntegrator : public Integrator {
 public:
     LangevinIntegrator(const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed);
+    ~LangevinIntegrator() override;
     double get_temperature() const { return temperature_; }
+    const volatile unsigned int *progress_word() const override { return h_progress_; }
+    unsigned int progress_enqueued() const override { return enqueued_; }
     void step_fwd(std::vector<std::shared_ptr<BoundPotential>> &bps, double *d_x_t, double *d_v_t, double *d_box_t, unsigned int *d_idxs, hipStream_t stream) override;
     void initialize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
     void finalize(std::vector<std::shared_ptr<BoundPotential>> &, double *, double *, double *, unsigned int *, hipStream_t) override {}
@@ -780,6 +788,8 @@ private:
     DeviceBuffer<u64> d_du_dx_cm_; // component-major [3][cm_stride_]: what the fused table's terms add to
     ForcePlan plan_;
     std::vector<DeferredForces> deferred_;
+    unsigned int *h_progress_ = nullptr; // pinned host memory (progress_word)
+    unsigned int enqueued_ = 0;          // step_fwd calls so far, modulo 2^32
 };
 
 // reference: cpp/src/verlet_integrator.{hpp,cu}; kernels/k_integrator.cuh:64-130.  Arithmetic in double, as the reference

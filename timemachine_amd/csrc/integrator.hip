@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
     const u64 *__restrict__ g0, const int *__restrict__ slot0, const int stride0, const u64 *__restrict__ g1,
     const int *__restrict__ slot1, const int stride1,
     // where to leave the producers' next gather (gathered == nullptr: not wanted)
-    const PregatherTarget pg0, const PregatherTarget pg1) {
+    const PregatherTarget pg0, const PregatherTarget pg1,
+    // the integrator's progress word (pinned host memory; Integrator::progress_word) and what to leave in it
+    unsigned int *__restrict__ progress, const unsigned int progress_value) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (pg0.gathered) {
             *pg0.flag_clear = 0; // the flag of the call just consumed becomes the one after next's
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void k_update_forward_baoab(
         if (pg1.gathered) {
             *pg1.flag_clear = 0;
         }
+        __hip_atomic_store(progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (int kidx = blockIdx.x * blockDim.x + threadIdx.x; kidx < N; kidx += gridDim.x * blockDim.x) {
         const int atom = idxs == nullptr ? kidx : static_cast<int>(idxs[kidx]);
@@ -213,9 +216,10 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
     const unsigned long long step, double *__restrict__ x_t, double *__restrict__ v_t, u64 *__restrict__ du_dx,
     u64 *__restrict__ du_dx_cm, const int cm_stride, const Real dt, const u64 *__restrict__ g0, const int stride0,
     const double *__restrict__ box, const PregatherTarget pg, double *__restrict__ xs, double *__restrict__ vs,
-    Real *__restrict__ cbs_s, Real *__restrict__ ccs_s) {
+    Real *__restrict__ cbs_s, Real *__restrict__ ccs_s, unsigned int *__restrict__ progress, const unsigned int progress_value) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *pg.flag_clear = 0; // the flag of the call just consumed becomes the one after next's
+        __hip_atomic_store(progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (as in k_update_forward_baoab)
     }
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const int lane = threadIdx.x;
@@ -320,6 +324,14 @@ LangevinIntegrator<Real>::LangevinIntegrator(
     d_ccs_.copy_from(h_ccs.data());
     HIP_CHECK(hipMemset(d_du_dx_.data, 0, d_du_dx_.size()));
     HIP_CHECK(hipMemset(d_du_dx_cm_.data, 0, d_du_dx_cm_.size()));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_progress_), 64, hipHostMallocDefault)); // a cache line of its own
+    *h_progress_ = 0;
+}
+
+template <typename Real> LangevinIntegrator<Real>::~LangevinIntegrator() {
+    if (h_progress_ != nullptr) {
+        (void)hipHostFree(h_progress_);
+    }
 }
 
 template <typename Real>
@@ -347,6 +359,7 @@ void LangevinIntegrator<Real>::step_fwd(
     // one producer whose sorted order covers every atom: walk its slots (and leave its block bounds done as well)
     const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n == N_ && df0.next.perm != nullptr;
     const int prof = Profiler::get().begin("integrator_update", stream);
+    enqueued_++; // what the update kernel of this step leaves in the progress word
     if (sorted) {
         u64 *dx = wrote_du_dx ? d_du_dx_.data : nullptr;
         // the slot-ordered copies of x, v, cb, cc are current iff the last launch here wrote them for this producer and these
@@ -356,7 +369,7 @@ void LangevinIntegrator<Real>::step_fwd(
 #define TM_LAUNCH_SORTED(GREAL, CACHE)                                                                                 \
     k_update_forward_baoab_sorted<Real, GREAL, CACHE><<<ceil_divide(N_, 64), 64, 0, stream>>>(                           \
         N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next, \
-        d_xs_.data, d_vs_.data, d_cbs_s_.data, d_ccs_s_.data)
+        d_xs_.data, d_vs_.data, d_cbs_s_.data, d_ccs_s_.data, h_progress_, enqueued_)
         if (df0.next.real_bytes == 8) {
             if (from_cache) {
                 TM_LAUNCH_SORTED(double, true);
@@ -382,7 +395,7 @@ void LangevinIntegrator<Real>::step_fwd(
         state_cache_valid_ = false; // this kernel does not maintain the slot-ordered copies
         k_update_forward_baoab<Real><<<ceil_divide(N_, tpb), tpb, 0, stream>>>(
             N_, ca_, d_idxs, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, wrote_du_dx ? d_du_dx_.data : nullptr, cm, cm_stride_, dt_,
-            df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1);
+            df0.g_du_dx, df0.slot_of_atom, df0.stride, df1.g_du_dx, df1.slot_of_atom, df1.stride, t0, t1, h_progress_, enqueued_);
     }
     Profiler::get().end("integrator_update", prof, stream);
     HIP_CHECK(hipGetLastError());
@@ -536,14 +549,20 @@ static void wait_for_stream(hipStream_t stream) {
     }
 }
 
-// Bounded run-ahead.  The enqueueing host is several times faster than the device (6-10 us against 70 us per DHFR-sized step), and
-// the HIP runtime lets it run ahead only so far: past a few thousand launches in flight every further launch SPINS inside the runtime
-// until a slot frees up -- measured: a 2 000-step call kept 0.3 CPUs busy, a 4 000-step call 0.9, and every call after it 0.9 as
-// well (scripts/host_cpu_probe2.py).  So the host throttles itself before the runtime does: every RUN_AHEAD_STEPS steps it marks
-// the stream with an event and, before going on, waits -- sleeping -- for the mark of the chunk before the last: at most two
-// chunks (~750 launches) are ever in flight, which is far more than the device needs to stay busy.
+// Bounded run-ahead.  The enqueueing host is several times faster than the device (10-12 us against 70 us per DHFR-sized step), and
+// what the HIP runtime does with the lead costs CPU time: past a few thousand launches in flight every further launch SPINS inside
+// the runtime until a slot frees up (a 2 000-step call kept the calling thread 0.15 busy, an 8 000-step call 0.6, every call after it
+// 1.0), and well before that the runtime's own helper thread grows busier with the number of commands in flight (0.05 of a CPU at
+// ~50 of them, 0.2-0.5 at several hundred: scripts/host_cpu_probe3.py).  So the stepping loops keep the host a SMALL number of
+// steps ahead of the device -- a few milliseconds of work, far more than the device needs to stay busy:
+//   * an integrator that keeps a progress word (Integrator::progress_word: the update kernel of every step leaves the count of
+//     steps enqueued so far in pinned host memory) is throttled on that word: no runtime call, no extra packet in the stream; once
+//     the host is more than RUN_AHEAD_HI steps ahead it sleeps until the lead is down to RUN_AHEAD_LO;
+//   * any other integrator: an event every RUN_AHEAD_EVENT_STEPS steps, and a sleeping wait for the event before the last (each
+//     event costs the device ~4 us, hence the larger spacing).
+// The word says "this step's update kernel has started", which is all a throttle needs; completion is wait_for_stream's business.
 struct RunAhead {
-    static const int RUN_AHEAD_STEPS = 128;
+    static const int RUN_AHEAD_HI = 32, RUN_AHEAD_LO = 16, RUN_AHEAD_EVENT_STEPS = 32;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool pending[2] = {false, false};
     int chunk = 0;
@@ -554,9 +573,38 @@ struct RunAhead {
             }
         }
     }
-    void after_step(const int i, hipStream_t stream) { // i: steps enqueued so far on `stream`
+    static void nap() { std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+    void after_step(const int i, hipStream_t stream, const Integrator &intg) { // i: steps enqueued so far by this call on `stream`
         static const bool spin = std::getenv("TM_AMD_SPIN_WAIT") != nullptr;
-        if (spin || i % RUN_AHEAD_STEPS != 0) {
+        if (spin) {
+            return;
+        }
+        if (const volatile unsigned int *word = intg.progress_word()) {
+            const unsigned int enqueued = intg.progress_enqueued();
+            if (static_cast<int>(enqueued - *word) <= RUN_AHEAD_HI) { // (wrapping difference: the counter is 32 bits wide)
+                return;
+            }
+            unsigned int seen = *word;
+            for (int naps = 0; static_cast<int>(enqueued - seen) > RUN_AHEAD_LO; naps++) {
+                nap();
+                const unsigned int now = *word;
+                if (now != seen) {
+                    seen = now;
+                    naps = 0;
+                } else if (naps >= 20000) { // ~2 s without a step: a device error surfaces here; an idle stream means the word is not coming
+                    const hipError_t e = hipStreamQuery(stream);
+                    if (e == hipSuccess) {
+                        return;
+                    }
+                    if (e != hipErrorNotReady) {
+                        HIP_CHECK(e);
+                    }
+                    naps = 0;
+                }
+            }
+            return;
+        }
+        if (i % RUN_AHEAD_EVENT_STEPS != 0) {
             return;
         }
         const int cur = chunk & 1, prev = cur ^ 1;
@@ -574,7 +622,7 @@ struct RunAhead {
                 if (e != hipErrorNotReady) {
                     HIP_CHECK(e);
                 }
-                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                nap();
             }
             pending[prev] = false;
         }
@@ -679,7 +727,7 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     RunAhead run_ahead;
     for (int i = 1; i <= n_steps; i++) {
         this->_step(stream);
-        run_ahead.after_step(i, stream);
+        run_ahead.after_step(i, stream, *intg_);
         if (i == n_steps) {
             HIP_CHECK(hipEventRecord(ev_stop_, stream));
             ev_valid_ = true;
@@ -822,7 +870,7 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
             for (int i = 1; i <= n_steps; i++) {
                 for (size_t k = 0; k < ctxts.size(); k++) { // one step of every context per round: their launches alternate in the device's queues
                     ctxts[k]->_step(st[k]);
-                    run_ahead[k].after_step(i, st[k]);
+                    run_ahead[k].after_step(i, st[k], *ctxts[k]->intg_);
                 }
             }
         } else {
@@ -838,7 +886,7 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
                         for (int i = 1; i <= n_steps; i++) {
                             for (size_t k = w; k < ctxts.size(); k += n_threads) {
                                 ctxts[k]->_step(st[k]);
-                                run_ahead[k].after_step(i, st[k]);
+                                run_ahead[k].after_step(i, st[k], *ctxts[k]->intg_);
                             }
                         }
                     } catch (...) {
