@@ -22,7 +22,7 @@
  *   - loading the library exports GPU_MAX_HW_QUEUES=8 to the process environment unless the variable is already set (see
  *     tm_context_multiple_steps_group); nothing else in the environment is touched.
  *   - a long tm_context_multiple_steps[_group] call does not spin on the host while the device works: the enqueueing thread stays
- *     at most ~32 steps ahead of the device and sleeps in between (it reads a progress word the integrator's kernel leaves in
+ *     at most 64 steps ahead of the device (TM_AMD_RUN_AHEAD_STEPS) and sleeps in between (it reads a progress word the integrator's kernel leaves in
  *     pinned host memory), and the end of the call is awaited by polling an event with short sleeps: ~0.2-0.3 CPUs busy per
  *     process instead of 1.0-1.6.  Results and device time do not depend on it; TM_AMD_SPIN_WAIT=1 in the environment restores
  *     unbounded enqueueing and the runtime's spinning waits (the call then returns ~30 us sooner).

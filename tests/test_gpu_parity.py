@@ -1321,7 +1321,7 @@ def test_group_stepping_is_bitwise_separate_stepping(co, P, precision):
 
 @pytest.mark.parametrize("threads", ["1", "2"])
 def test_calls_longer_than_the_run_ahead_bound_are_bitwise_short_calls(co, P, threads, monkeypatch):
-    """The stepping loops keep the host a bounded number of steps ahead of the device (csrc/integrator.hip, RunAhead: at most 32
+    """The stepping loops keep the host a bounded number of steps ahead of the device (csrc/integrator.hip, RunAhead: at most 64
     by the Langevin integrator's progress word; an event every 32 steps for an integrator without one -- VelocityVerlet).  A call of
     700 steps sleeps on that bound many times and must leave the state that short calls leave, bit for bit: alone (with frames:
     their copies wait as well), grouped, and under the velocity Verlet integrator."""

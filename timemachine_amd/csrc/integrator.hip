@@ -557,12 +557,15 @@ static void wait_for_stream(hipStream_t stream) {
 // steps ahead of the device -- a few milliseconds of work, far more than the device needs to stay busy:
 //   * an integrator that keeps a progress word (Integrator::progress_word: the update kernel of every step leaves the count of
 //     steps enqueued so far in pinned host memory) is throttled on that word: no runtime call, no extra packet in the stream; once
-//     the host is more than RUN_AHEAD_HI steps ahead it sleeps until the lead is down to RUN_AHEAD_LO;
+//     the host is more than RUN_AHEAD_HI steps ahead it sleeps until the lead is down to half of that.  The bound trades the
+//     helper thread's load (0.20-0.26 CPUs busy per process at 32, 0.20-0.33 at 64, 0.22-0.45 at 128, 0.25-0.68 at 256) against the
+//     hiccup of the host that the device rides out without going idle (32 steps: 2.2 ms of DHFR-sized work, 0.5 ms at 256 atoms);
+//     TM_AMD_RUN_AHEAD_STEPS in the environment overrides it;
 //   * any other integrator: an event every RUN_AHEAD_EVENT_STEPS steps, and a sleeping wait for the event before the last (each
 //     event costs the device ~4 us, hence the larger spacing).
 // The word says "this step's update kernel has started", which is all a throttle needs; completion is wait_for_stream's business.
 struct RunAhead {
-    static const int RUN_AHEAD_HI = 32, RUN_AHEAD_LO = 16, RUN_AHEAD_EVENT_STEPS = 32;
+    static const int RUN_AHEAD_HI = 64, RUN_AHEAD_EVENT_STEPS = 32;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool pending[2] = {false, false};
     int chunk = 0;
@@ -580,12 +583,13 @@ struct RunAhead {
             return;
         }
         if (const volatile unsigned int *word = intg.progress_word()) {
+            static const int hi = std::getenv("TM_AMD_RUN_AHEAD_STEPS") ? std::max(2, std::atoi(std::getenv("TM_AMD_RUN_AHEAD_STEPS"))) : RUN_AHEAD_HI;
             const unsigned int enqueued = intg.progress_enqueued();
-            if (static_cast<int>(enqueued - *word) <= RUN_AHEAD_HI) { // (wrapping difference: the counter is 32 bits wide)
+            if (static_cast<int>(enqueued - *word) <= hi) { // (wrapping difference: the counter is 32 bits wide)
                 return;
             }
             unsigned int seen = *word;
-            for (int naps = 0; static_cast<int>(enqueued - seen) > RUN_AHEAD_LO; naps++) {
+            for (int naps = 0; static_cast<int>(enqueued - seen) > hi / 2; naps++) {
                 nap();
                 const unsigned int now = *word;
                 if (now != seen) {
