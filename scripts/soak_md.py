@@ -40,3 +40,31 @@ if co.debug_rowblock_available():  # (variant library libtimemachine_amd_rowbloc
     ctxt.multiple_steps(50000, 0)
     vv = ctxt.get_v_t()
     print("row-block kernel f64, 50k steps: T = %.1f K" % ((s.masses[:, None] * vv * vv).sum() / (3 * s.num_atoms * 0.0083144626)), "finite", bool(np.all(np.isfinite(ctxt.get_x_t()))), "; %.1f us per step" % (1e3 * ctxt.last_multiple_steps_ms() / 50000))
+# round 5: the barostat's attempt on the current list over a long run -- NPT at 1 bar, an attempt every 25
+# steps, 100k steps per precision alone, then the production shape (f32, four windows stepped together, a barostat in each)
+from timemachine_amd.lib import MonteCarloBarostat
+def npt_context(prec, seed):
+    bps = make_bps(prec)
+    baro = MonteCarloBarostat(s.num_atoms, 1.0, 300.0, ts.molecule_groups(s), 25, seed).impl(bps)
+    return co.Context(x, v, s.box, LangevinIntegrator(300.0, 2.5e-3, 1.0, s.masses, seed).impl(), bps, movers=[baro]), baro
+def report(tag, c, baro):
+    vv, box = c.get_v_t(), c.get_box()
+    T = (s.masses[:, None] * vv * vv).sum() / (3 * s.num_atoms * 0.0083144626)
+    accepted, proposed = baro.get_counters()
+    attempts, on_list = baro.get_attempt_paths()
+    print(tag, "T = %.1f K" % T, "box %.4f nm" % box[0, 0], "finite", bool(np.all(np.isfinite(c.get_x_t())) and np.all(np.isfinite(vv))),
+          "attempts %d (on the current list %d), accepted %.2f" % (attempts, on_list, accepted / max(proposed, 1)), flush=True)
+for prec in (np.float64, np.float32):
+    c, baro = npt_context(prec, 11)
+    t0 = time.time()
+    for chunk in range(4):
+        c.multiple_steps(25000, 0)
+        report("%s NPT steps %d" % (prec.__name__, (chunk + 1) * 25000), c, baro)
+    print("  wall %.1f s for 100k steps (%.1f us per step)" % (time.time() - t0, 1e6 * (time.time() - t0) / 1e5))
+group = [npt_context(np.float32, 20 + k) for k in range(4)]
+t0 = time.time()
+for chunk in range(2):
+    co.multiple_steps_group([c for c, _ in group], 25000)
+    for k, (c, baro) in enumerate(group):
+        report("float32 NPT grouped replica %d steps %d" % (k, (chunk + 1) * 25000), c, baro)
+print("  wall %.1f s for 4 x 50k steps (%.1f us per replica-step)" % (time.time() - t0, 1e6 * (time.time() - t0) / 2e5))
