@@ -70,6 +70,7 @@ C_SLOT_FLOPS = 20.0  # per evaluated slot (min-image distance + cutoff test)
 OWN_PAIR_FLOPS = {"f64": 48.0, "f32": 75.0}  # f32: analytic erfc / exp / switch instead of the table (rsq, rcp, exp, sin, cos count 1)
 OWN_SLOT_FLOPS = 6.0
 CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: peak engine clock; used only to turn a kernel time into cycles for valu_busy
+LDS_COUNTER_SATURATED = 1.9  # SQ_ACTIVE_INST_LDS * 4 / (CUs * cycles) of a kernel that keeps every CU's LDS pipe busy (measured: 1.84-1.98)
 METRIC = "ns/day (23k-atom solvated box, 2.5 fs) per GPU"
 
 
@@ -816,6 +817,13 @@ def run_md(args, rank, local_rank, world, backend):
             rv["insts_salu_per_launch"] = sq.get("SQ_INSTS_SALU")
             rv["insts_lds_per_launch"] = sq.get("SQ_INSTS_LDS")
             rv["lds_bank_conflict_cycles"] = sq.get("SQ_LDS_BANK_CONFLICT")
+            if sq.get("SQ_ACTIVE_INST_LDS"):
+                # the CU's ONE LDS pipe: SQ_ACTIVE_INST_LDS in the units a saturated pipe reads -- scripts/microbench/lds_atomics (sixteen
+                # waves per CU issuing nothing but LDS instructions) reads 1.84-1.98 by the valu_busy formula taken per CU
+                # (scripts/gpu_lds_counter_check.sh), i.e. the counter ticks every ~2.1 cycles
+                rv["lds_busy"] = sq["SQ_ACTIVE_INST_LDS"] * 4.0 / (256.0 * kernel_cycles) / LDS_COUNTER_SATURATED
+                rv["lds_busy_note"] = (f"SQ_ACTIVE_INST_LDS * 4 / (256 CUs * kernel cycles) / {LDS_COUNTER_SATURATED} (what a saturated pipe reads: "
+                                       "scripts/gpu_lds_counter_check.sh); bank-conflict cycles of 32-bit atomics are not in the counter, so a lower bound")
             rv["counters_source"] = f"{pmc.get('source')} (separate rocprofv3 --pmc passes of this command; valu_busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * kernel_ms * {CLOCK_GHZ} GHz))"
 
     if world == 1 and not args.stub:
