@@ -133,6 +133,12 @@ int tm_nonbonded_all_pairs_get_atom_idxs(tm_potential_t pot, int32_t *out, int c
 int tm_nonbonded_all_pairs_get_tile_count(tm_potential_t pot, unsigned int *count);
 /* diagnostic: neighbor-list builds since construction (rebuild period of an MD run = calls / builds) */
 int tm_nonbonded_all_pairs_get_build_count(tm_potential_t pot, unsigned int *count);
+/* diagnostic: an all-pairs potential planned next to an interaction group on exactly its atoms (the reference's HostGuestSystem,
+ * fe/system.py:133-146: Nonbonded(atom_idxs=host) + NonbondedInteractionGroup(ligand, host)) evaluates BOTH pair sets in one pipeline
+ * of its own -- one list, one tile launch, one sorted hand-over to the integrator (csrc/engine.hpp: merged carrier;
+ * tm_debug_set_merge_producers).  *calls = force / energy evaluations made that way since construction (0: never merged);
+ * *tiles / *builds = tile count and list builds of that pipeline's list (as the two entry points above report for the potential's own) */
+int tm_nonbonded_all_pairs_get_merged_stats(tm_potential_t pot, long long *calls, unsigned int *tiles, unsigned int *builds);
 /* per-wave cycle counters of the last tile-kernel launch: [waves][8] = {setup, phase1, phase2, flush, items, batches, total, 0};
  * all zero unless the library was built with -DTM_TIMING (development aid, see scripts/ablate.py) */
 int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n);
@@ -299,6 +305,11 @@ int tm_debug_set_box_scaling_reuse(int enabled);
  * full evaluations, decision).  Process-wide; *previous (may be NULL) receives the old value.  Energies, decisions and trajectories
  * are bit-identical either way. */
 int tm_debug_set_barostat_fast_path(int enabled, int *previous);
+/* debugging / A-B aid: forces-only and energy-only plans (MD steps, barostat attempts, Summed / Fanout energy calls) run an all-pairs
+ * potential and an interaction group whose columns are exactly its atoms as ONE pipeline (see tm_nonbonded_all_pairs_get_merged_stats);
+ * 0 = each keeps its own list, launch and hand-over (rounds 1-5).  Process-wide (TM_AMD_NO_MERGE in the environment sets the initial
+ * value to 0); *previous (may be NULL) receives the old value.  Forces, energies and trajectories are bit-identical either way. */
+int tm_debug_set_merge_producers(int enabled, int *previous);
 /* debugging / A-B aid: nonbonded potentials over at most `max_atoms` atoms keep a STATIC, complete interaction list (every column
  * block listed for every row block: nothing can invalidate it, no list kernel runs on MD steps; EXPERIMENTS.md, History, item 11).
  * Process-wide; applies to potentials at their next call; 0 turns it off; *previous (may be NULL) receives the old value.

@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
             box_proposed[k] = bp[k];
         }
     }
+    if (a < 8) {
+        static_cast<GReal *>(t.gathered2)[static_cast<size_t>(t.n) * 8 + a] = 0; // the sentinel record padded list slots point at
+        if (t.second_records != 0) {
+            static_cast<GReal *>(t.gathered2)[static_cast<size_t>(t.second_records + t.n) * 8 + a] = 0;
+        }
+    }
     if (a < N) {
     double xp[3] = {x[a * 3 + 0], x[a * 3 + 1], x[a * 3 + 2]};
     const int4 info = mol_of_atom[a]; // (one load: the molecule's extent arrives with its number)
@@ -313,8 +319,17 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     g2[5] = g[5];
     g2[6] = g[6];
     g2[7] = 0;
-    if (a < 8) {
-        static_cast<GReal *>(t.gathered2)[static_cast<size_t>(t.n) * 8 + a] = 0; // the sentinel record padded list slots point at
+    if (t.second_records != 0) { // merged producers: the atom's second record (the group's parameters) follows the proposal too
+        const GReal *gb = g + static_cast<size_t>(t.second_records) * 8;
+        GReal *g2b = g2 + static_cast<size_t>(t.second_records) * 8;
+        g2b[0] = g2[0];
+        g2b[1] = g2[1];
+        g2b[2] = g2[2];
+        g2b[3] = gb[3];
+        g2b[4] = gb[4];
+        g2b[5] = gb[5];
+        g2b[6] = gb[6];
+        g2b[7] = 0;
     }
     // can the current list vouch for the proposal?  If not, the list launch that follows rebuilds it -- from the CURRENT geometry,
     // whose records, block bounds and snapshot source are all in place -- and the proposal then sits a proposal's displacement
@@ -405,10 +420,11 @@ __global__ __launch_bounds__(64) void k_barostat_decide_commit(
     if (rejected) {
         return; // (uniform across the launch) x, box, the sorted records, the flags, the bounds: all as the last MD step left them
     }
-    const bool valid = slot < N;
+    // (N counts the SLOTS of the potential's order: a merged order has holes, perm == 0xffffffff)
+    const int a = slot < N ? static_cast<int>(t.perm[slot]) : -1;
+    const bool valid = a >= 0;
     GReal p[3] = {0, 0, 0};
     if (valid) {
-        const int a = static_cast<int>(t.perm[slot]);
         const double xp[3] = {x_proposed[a * 3 + 0], x_proposed[a * 3 + 1], x_proposed[a * 3 + 2]};
         x[a * 3 + 0] = xp[0];
         x[a * 3 + 1] = xp[1];
@@ -419,6 +435,13 @@ __global__ __launch_bounds__(64) void k_barostat_decide_commit(
         for (int d = 0; d < 3; d++) {
             p[d] = g2[d];
             g[d] = p[d];
+        }
+        if (t.second_records != 0) { // merged producers: the atom's second record follows
+            GReal *gb = static_cast<GReal *>(t.gathered) + (static_cast<size_t>(t.second_records) + slot) * 8;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                gb[d] = p[d];
+            }
         }
         // the committed geometry against the list's snapshot as it is NOW (the probe's list launch may have rebuilt it)
         if (t.scale_aware && snapshot_calls_for_rebuild(xp[0], xp[1], xp[2], t.snap_x + a * 3, box_proposed, t.snap_box, t.threshold2)) {
@@ -569,13 +592,21 @@ template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(dou
     if (!g_barostat_fast_path) { // A/B switch (tm_debug_set_barostat_fast_path, TM_AMD_BAROSTAT_SLOW_PATH): always the reference-shaped attempt
         return false;
     }
+    // The DUAL launch's filter margin and the scale-aware list test both assume that EVERY atom moves rigidly with its molecule
+    // (|s - 1| (|v| + 2 R) bounds the change of a pair distance).  The reference accepts partial group_idxs (mol_utils.cpp checks
+    // range and uniqueness only): atoms outside every group keep x while the box and their neighbours move -- up to |s - 1| L of
+    // relative displacement.  Those attempts take the reference-shaped path, whose evaluations list x' for themselves.
+    if (num_grouped_atoms_ != N_) {
+        return false;
+    }
     const int n_bps = static_cast<int>(bps_.size());
     plan_.clear();
     for (int i = 0; i < n_bps; i++) {
         bps_[i]->potential->plan_forces(N_, bps_[i]->size, bps_[i]->size > 0 ? bps_[i]->d_p.data : nullptr, plan_);
     }
-    // exactly one potential with a kernel of its own -- an all-pairs nonbonded potential whose sorted pre-gathered state describes
-    // (d_x, d_box) -- and everything else in the plan's table, in that potential's precision
+    plan_.merge_producers(); // an all-pairs potential + an interaction group on its atoms: one carrier (the reference's RBFE states)
+    // exactly one potential with a kernel of its own -- an all-pairs nonbonded potential (or a merged carrier) whose sorted
+    // pre-gathered state describes (d_x, d_box) -- and everything else in the plan's table, in that potential's precision
     if (plan_.rest().size() != 1) {
         return false;
     }
@@ -618,8 +649,8 @@ template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(dou
         nb->probe_energy(0, d_box, tables[prec], blocks[prec], d_x, stream, p0, n0);                                   \
         nb->probe_energy(1, d_box_proposed_.data, tables[prec], blocks[prec], d_x_proposed_.data, stream, p1, n1);     \
     }                                                                                                                  \
-    k_barostat_decide_commit<Real, GREAL><<<ceil_divide(std::max(N_, 9), 64), 64, 0, stream>>>(                        \
-        N_, adaptive_ ? 1 : 0, num_mols_, kT, pressure, d_move_.data, d_volume_scale_.data, p0, n0, p1, n1, d_box, d_box_proposed_.data, \
+    k_barostat_decide_commit<Real, GREAL><<<ceil_divide(std::max(t.n, 9), 64), 64, 0, stream>>>(                       \
+        t.n, adaptive_ ? 1 : 0, num_mols_, kT, pressure, d_move_.data, d_volume_scale_.data, p0, n0, p1, n1, d_box, d_box_proposed_.data, \
         d_x, d_x_proposed_.data, d_counters_.data, d_centroids_.data, num_mols_ * 3, t);                                \
     HIP_CHECK(hipGetLastError())
     if (t.real_bytes == 8) {

@@ -386,6 +386,12 @@ int tm_nonbonded_all_pairs_get_build_count(tm_potential_t pot, unsigned int *cou
     TM_CATCH
 }
 
+int tm_nonbonded_all_pairs_get_merged_stats(tm_potential_t pot, long long *calls, unsigned int *tiles, unsigned int *builds) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { p.merged_stats(calls, tiles, builds); });
+    TM_CATCH
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int tm_potential_execute(
     tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, uint64_t *du_dx, uint64_t *du_dp,
@@ -893,6 +899,14 @@ int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
     require(g_rowblock_built || min_atoms == std::numeric_limits<int>::max(),
             "the row-block kernel is not built into this library (load the variant libtimemachine_amd_rowblock.so: TM_AMD_LIB)");
     g_rowblock_min_k = min_atoms;
+    TM_CATCH
+}
+int tm_debug_set_merge_producers(int enabled, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_merge_producers ? 1 : 0;
+    }
+    g_merge_producers = enabled != 0;
     TM_CATCH
 }
 int tm_debug_set_barostat_fast_path(int enabled, int *previous) {

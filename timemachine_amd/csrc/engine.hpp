@@ -93,9 +93,13 @@ struct PregatherTarget {
     // blocks' bounding boxes, every step (two per wave, a handful of shuffles) -- and resets the neighbor-list counters
     // whenever it raises the rebuild flag.  The producer then launches no bounds kernel at all on MD steps.
     const unsigned int *perm = nullptr;
-    int sorted_n = 0;
+    int sorted_n = 0; // SLOTS of the order: a merged producer's (below) has up to 31 holes, perm[slot] == 0xffffffff
+    int covers_atoms = 0; // atoms that have a slot (the consumer walks the slots iff this is every atom it moves)
     void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(sorted_n / 32)][3]
     unsigned int *nbl_counters = nullptr;        // kernels_nonbonded.hip.hpp: NB_NUM_COUNTERS words
+    // != 0: a MERGED producer (an all-pairs potential carrying an interaction group's pairs in its own pipeline): its all-pairs atoms
+    // have a second record, under the group's parameters, at record index second_records + slot -- positions go there as well
+    int second_records = 0;
 };
 class Potential;
 struct DeferredForces {
@@ -139,6 +143,12 @@ public:
     // prepare_tables() -- the uploaded table of each precision (nullptr: none planned)
     const std::vector<Rest> &rest() const { return rest_; }
     void prepare_tables(const int N, hipStream_t stream, const FusedTable *d_tables[2], int blocks[2]);
+    // Two planned tile producers that read the same coordinates -- an all-pairs potential over the atom set H and an interaction
+    // group (rows R, columns == H): the reference's HostGuestSystem, fe/system.py:133-146 -- become ONE: the all-pairs potential's
+    // merged carrier (NonbondedAllPairsBase::merged_carrier), which lists, evaluates and hands over both pair sets in one
+    // pipeline.  Idempotent; run() and run_energy() call it, a mover that inspects rest() calls it first.  Same bits either way
+    // (the same pair function on the same operands, integer sums).
+    void merge_producers();
 
 private:
     FusedTable host_[2];                  // [0] f32 kernels, [1] f64 kernels
@@ -480,6 +490,11 @@ public:
         // bounds kernel re-expresses the snapshot's box in the current one on its way out
         const bool rebase_box = false);
 
+    // merged orders (NonbondedAllPairs as a carrier): the first `blocks` blocks are `rows` guest atoms padded with holes
+    void set_guest(const int rows, const int blocks) {
+        guest_rows_ = rows;
+        guest_blocks_ = blocks;
+    }
     int get_num_row_idxs() const { return NR_; }
     int num_row_blocks() const { return ceil_divide(NR_, TILE); }
     int num_column_blocks() const { return ceil_divide(NC_, TILE); }
@@ -500,6 +515,7 @@ public:
 private:
     const int max_size_;
     int N_, NC_, NR_;
+    int guest_rows_ = 0, guest_blocks_ = 0;
     DeviceBuffer<Real> d_col_ctr_, d_col_ext_, d_row_ctr_, d_row_ext_;
     DeviceBuffer<unsigned int> d_row_idxs_, d_col_idxs_;
     DeviceBuffer<unsigned int> d_counters_;  // [0] pool cursor, [1] work items, [2] 32-wide tile count, [4..12) items per cost class
@@ -513,6 +529,7 @@ private:
 
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
+extern bool g_merge_producers; // ForcePlan::merge_producers runs all-pairs + interaction group as one pipeline (tm_debug_set_merge_producers)
 extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
 extern int g_rowblock_min_k;     // forces-only launches over at least this many atoms run the row-block kernel (tm_debug_set_rowblock_min_k)
@@ -527,7 +544,7 @@ struct ProbeTarget {
     void *gathered = nullptr;  // Real[K + 1][8] sorted records of the current geometry (left by the integrator's update kernel)
     void *gathered2 = nullptr; // the same for the proposal: filled by the mover (x y z; w q sig eps copied from `gathered`)
     int real_bytes = 0;        // sizeof(Real) of the potential
-    int n = 0;                 // atoms (== slots: the potential covers every atom)
+    int n = 0;                 // SLOTS of the potential's order (every atom has one; a merged order also has holes, perm == 0xffffffff)
     const int *slot_of_atom = nullptr;
     const unsigned int *perm = nullptr;
     double *snap_x = nullptr;   // coordinates at the last list build, atom order (re-based by the commit)
@@ -538,6 +555,7 @@ struct ProbeTarget {
     int *flag_next = nullptr;   // the flag of the force call after the probe (raised by the commit's own test)
     unsigned int *nbl_counters = nullptr; // reset by whoever raises a flag (sorted hand-over: no bounds kernel does it)
     void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(n / 32)][3]: block bounds, recomputed by the commit
+    int second_records = 0; // merged producers (PregatherTarget::second_records): a commit writes the positions there as well
 };
 
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
@@ -563,6 +581,19 @@ public:
     virtual double get_beta() const = 0;
     virtual int precision_bytes() const = 0;
     virtual bool is_interaction_group() const { return false; } // NonbondedInteractionGroup shares the all-pairs pipeline
+    // ---- merging with an interaction group (ForcePlan::merge_producers) ----
+    // all-pairs side: the potential (owned by this one) that evaluates this potential's pairs AND `group`'s in one pipeline, bound
+    // to the group's parameters for the coming call -- or nullptr when the two do not fit (different precision / beta / cutoff,
+    // the group's columns are not exactly this potential's atoms, an empty side, du/dp wanted ...)
+    virtual Potential *merged_carrier(NonbondedAllPairsBase *group, const int P_group, const double *d_p_group) { return nullptr; }
+    // what the all-pairs side needs to know about a candidate group
+    virtual const std::vector<unsigned int> &host_atom_idxs() const = 0; // group: rows (ascending) then columns; all-pairs: its atoms (ascending)
+    virtual int num_group_rows() const { return 0; }
+    virtual unsigned int idxs_version() const = 0;   // bumped by every change of the atom sets
+    virtual unsigned int inputs_epoch() const = 0;   // bumped by invalidate_cached_inputs
+    virtual bool hilbert_disabled() const = 0;
+    virtual bool expects_box_scaling() const = 0;
+    virtual bool is_empty_group() const { return false; }
     // local MD narrows an all-pairs potential to the free atoms for the length of a call and widens it again afterwards
     virtual void narrow_to(const std::vector<int> &atom_idxs) = 0;
     virtual std::vector<int> current_atom_idxs() = 0;
@@ -597,8 +628,28 @@ public:
     void probe_energy(const int which, const double *d_box_which, const FusedTable *table, const int table_blocks, const double *coords, hipStream_t stream, const i128 *&partials, int &count) override;
     void probe_energy_dual(const double *d_box2, const FusedTable *table, const int table_blocks, const double *coords, const double *coords2, const float *r2_blocks, const int n_r2, hipStream_t stream, const i128 *&partials, const i128 *&partials2, int &count) override;
     void probe_list_launch(hipStream_t stream);
-    void invalidate_cached_inputs() override { pre_valid_ = false; }
+    void invalidate_cached_inputs() override {
+        pre_valid_ = false;
+        inputs_epoch_++;
+        if (merged_) {
+            merged_->invalidate_cached_inputs();
+        }
+    }
     void expect_box_scaling() override { box_scales_ = true; }
+    Potential *merged_carrier(NonbondedAllPairsBase *group, const int P_group, const double *d_p_group) override;
+    const std::vector<unsigned int> &host_atom_idxs() const override { return h_atom_idxs_; }
+    int num_group_rows() const override { return group_rows_; }
+    unsigned int idxs_version() const override { return idxs_version_; }
+    unsigned int inputs_epoch() const override { return inputs_epoch_; }
+    bool hilbert_disabled() const override { return disable_hilbert_; }
+    bool expects_box_scaling() const override { return box_scales_; }
+    bool is_empty_group() const override { return empty_; }
+    // diagnostics (tests assert which path ran): force / energy evaluations this potential made as a merged carrier's host
+    void merged_stats(long long *calls, unsigned int *tiles, unsigned int *builds) {
+        *calls = merged_ ? merged_->pipeline_calls_ : 0;
+        *tiles = merged_ ? merged_->num_tile_ixns() : 0;
+        *builds = merged_ ? merged_->num_builds() : 0;
+    }
     double get_cutoff() const override { return cutoff_; }
     double get_nblist_padding() const override { return nblist_padding_; }
     unsigned int num_tile_ixns() { return nblist_.num_tile_ixns(); }
@@ -613,6 +664,30 @@ protected:
     struct GroupTag {};
     NonbondedAllPairs(const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, GroupTag);
     void allocate();
+    // ---- merged carrier (ForcePlan::merge_producers; reference composition: fe/system.py:133-146) ----
+    // A carrier is a NonbondedAllPairs of its own (own list, order, records, accumulators) over the slots
+    //     [ group rows (guest_rows_) | holes up to a block boundary (guest_pad_) | all-pairs atoms ]
+    // The list is the plain upper-triangular one except that the guest row blocks start their columns at block guest_pad_ / 32
+    // (no guest x guest pairs) -- so host x host pairs and guest x host pairs come out of ONE list build, ONE tile launch and ONE
+    // sorted hand-over.  Records: slot s under the parameters of its own potential (guest slots: the group's); the all-pairs
+    // atoms once more under the group's parameters at record K_ + 1 + s, which the guest rows' items read as their columns
+    // (kernels_nonbonded.hip.hpp: load_records).  Forces-only and energy-only evaluation; du/dp stays with the separate potentials.
+    struct MergedTag {};
+    NonbondedAllPairs(const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, MergedTag,
+                      const std::vector<unsigned int> &host_idxs, const std::vector<unsigned int> &guest_idxs);
+    int guest_rows_ = 0, guest_pad_ = 0; // merged carrier: L and L rounded up to 32 (0: not a carrier)
+    int n_atoms_ = 0;                    // atoms that have a slot (K_ counts slots: == n_atoms_ unless merged)
+    const double *guest_p_ = nullptr;    // the group's parameters for the coming call (merged_carrier binds them)
+    bool covers_all() const { return n_atoms_ == N_ && group_rows_ == 0; }
+    int slot_capacity() const { return merged_mode_ ? N_ + TILE : N_; }
+    const bool merged_mode_ = false;
+    std::unique_ptr<NonbondedAllPairs<Real>> merged_; // this potential's carrier, built on first use
+    NonbondedAllPairsBase *merged_group_ = nullptr;   // ... for this group, at these versions of the two atom sets
+    unsigned int merged_versions_[2] = {0, 0}, merged_group_epoch_ = 0;
+    bool merged_refused_ = false;                     // the pair (merged_group_, versions) does not fit: do not ask again
+    std::vector<unsigned int> h_atom_idxs_;           // host copy of d_atom_idxs_ (group: rows then columns)
+    unsigned int idxs_version_ = 1, inputs_epoch_ = 1;
+    long long pipeline_calls_ = 0;
     const char *name_ = "NonbondedAllPairs"; // class name used in error messages
     int steps_per_sort_;
     int group_rows_ = 0;  // > 0: the first group_rows_ entries of d_atom_idxs_ are the row group (sorted separately)
@@ -646,7 +721,7 @@ protected:
     // input pointers, dropped by any other call into the pipeline
     bool pre_valid_ = false;
     bool pre_sorted_ = false; // the consumer also left the block bounds done and resets the list counters with the flag
-    const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr;
+    const double *pre_x_ = nullptr, *pre_p_ = nullptr, *pre_box_ = nullptr, *offer_p_ = nullptr, *pre_guest_p_ = nullptr, *offer_guest_p_ = nullptr;
     const FusedTable *piggyback_table_ = nullptr; // consumed by the next forces-only call
     int piggyback_blocks_ = 0;
     const FusedTable *piggyback_energy_table_ = nullptr; // consumed by the next energy-only partial-sum call

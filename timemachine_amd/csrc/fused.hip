@@ -120,7 +120,38 @@ void ForcePlan::prepare_tables(const int N, hipStream_t stream, const FusedTable
     }
 }
 
+void ForcePlan::merge_producers() {
+    // at most one pairing per plan (the reference's states hold one all-pairs potential and one interaction group); potentials
+    // planned more than once stay as they are (their second call would meet the carrier's state half-way)
+    auto planned_once = [&](const Potential *p) {
+        int n = 0;
+        for (const Rest &q : rest_) {
+            n += q.pot == p ? 1 : 0;
+        }
+        return n == 1;
+    };
+    for (size_t i = 0; i < rest_.size(); i++) {
+        NonbondedAllPairsBase *host = dynamic_cast<NonbondedAllPairsBase *>(rest_[i].pot);
+        if (host == nullptr || host->is_interaction_group() || !planned_once(rest_[i].pot)) {
+            continue;
+        }
+        for (size_t j = 0; j < rest_.size(); j++) {
+            NonbondedAllPairsBase *group = j == i ? nullptr : dynamic_cast<NonbondedAllPairsBase *>(rest_[j].pot);
+            if (group == nullptr || !group->is_interaction_group() || !planned_once(rest_[j].pot)) {
+                continue;
+            }
+            Potential *carrier = host->merged_carrier(group, rest_[j].P, rest_[j].d_p);
+            if (carrier != nullptr) {
+                rest_[i].pot = carrier; // evaluated with the all-pairs potential's own (P, d_p); the group's are bound inside
+                rest_.erase(rest_.begin() + static_cast<long>(j));
+                return;
+            }
+        }
+    }
+}
+
 void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, i128 *d_u, hipStream_t stream) {
+    this->merge_producers();
     host_[0].num_atoms = host_[1].num_atoms = N;
     bool pending[2];
     this->upload_tables(pending, stream);
@@ -219,6 +250,7 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
 bool ForcePlan::run(
     const int N, const double *d_x, const double *d_box, u64 *d_du_dx, hipStream_t stream, std::vector<DeferredForces> *deferred,
     const int max_deferred, u64 *d_du_dx_cm, const int cm_stride) {
+    this->merge_producers();
     bool wrote_du_dx = false; // did anything add to the [N, 3] array?
     // the table's terms go to the caller's component-major accumulator when there is one (lanes working on neighbouring
     // atoms then share cache lines: fewer line requests for the memory-side atomics), to the [N, 3] array otherwise

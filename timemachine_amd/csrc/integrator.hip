@@ -81,6 +81,12 @@ __device__ __forceinline__ void pregather_atom_as(const PregatherTarget &t, cons
     g[0] = gx;
     g[1] = gy;
     g[2] = gz;
+    if (t.second_records != 0) { // (wave-uniform) a merged producer: the atom's second record follows (holes' and guest rows' are never read)
+        GReal *g2 = static_cast<GReal *>(t.gathered) + (static_cast<size_t>(t.second_records) + slot) * 8;
+        g2[0] = gx;
+        g2[1] = gy;
+        g2[2] = gz;
+    }
     bool rebuild;
     if (t.snap_box != nullptr) { // wave-uniform: a barostat works on the producer
         rebuild = snapshot_calls_for_rebuild(xn, yn, zn, t.snap_x + atom * 3, t.cur_box, t.snap_box, t.pad2_quarter);
@@ -223,10 +229,11 @@ __global__ __launch_bounds__(64) void k_update_forward_baoab_sorted(
     }
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const int lane = threadIdx.x;
-    const bool valid = slot < N;
+    // (N counts the SLOTS of the producer's order; a merged order pads its guest rows to a block boundary with holes: perm == 0xffffffff)
+    const int atom = slot < N ? static_cast<int>(pg.perm[slot]) : -1;
+    const bool valid = atom >= 0;
     GReal p[3] = {0, 0, 0}; // the new position as the producer's record stores it
     if (valid) {
-        const int atom = static_cast<int>(pg.perm[slot]);
         Real cb, cc;
         double xo[3], vo[3];
         if constexpr (FROM_CACHE) {
@@ -311,7 +318,7 @@ template <typename Real>
 LangevinIntegrator<Real>::LangevinIntegrator(
     const int N, const double *masses, const double temperature, const double dt, const double friction, const int seed)
     : N_(N), temperature_(temperature), dt_(static_cast<Real>(dt)), friction_(friction), seed_(static_cast<unsigned long long>(static_cast<long long>(seed))),
-      step_(0), d_cbs_(N), d_ccs_(N), d_xs_(static_cast<size_t>(N) * 3), d_vs_(static_cast<size_t>(N) * 3), d_cbs_s_(N), d_ccs_s_(N), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7), d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
+      step_(0), d_cbs_(N), d_ccs_(N), d_xs_(static_cast<size_t>(N + TILE) * 3), d_vs_(static_cast<size_t>(N + TILE) * 3), d_cbs_s_(N + TILE), d_ccs_s_(N + TILE), d_du_dx_(static_cast<size_t>(N) * 3), cm_stride_((N + 7) & ~7), d_du_dx_cm_(static_cast<size_t>((N + 7) & ~7) * 3) {
     ca_ = static_cast<Real>(std::exp(-friction * dt));
     const double kT = BOLTZ * temperature;
     const double ccs_adjustment = std::sqrt(1 - std::exp(-2 * friction * dt));
@@ -357,7 +364,7 @@ void LangevinIntegrator<Real>::step_fwd(
     const PregatherTarget no_target;
     const bool pregather = d_idxs == nullptr;
     // one producer whose sorted order covers every atom: walk its slots (and leave its block bounds done as well)
-    const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n == N_ && df0.next.perm != nullptr;
+    const bool sorted = pregather && deferred_.size() == 1 && df0.next.gathered != nullptr && df0.next.sorted_n > 0 && df0.next.covers_atoms == N_ && df0.next.perm != nullptr;
     const int prof = Profiler::get().begin("integrator_update", stream);
     enqueued_++; // what the update kernel of this step leaves in the progress word
     if (sorted) {
@@ -367,8 +374,8 @@ void LangevinIntegrator<Real>::step_fwd(
         // touched x / v since (invalidate_state_cache)
         const bool from_cache = state_cache_valid_ && df0.consumed_sorted_pregather && cache_owner_ == df0.owner && cache_x_ == d_x_t && cache_v_ == d_v_t;
 #define TM_LAUNCH_SORTED(GREAL, CACHE)                                                                                 \
-    k_update_forward_baoab_sorted<Real, GREAL, CACHE><<<ceil_divide(N_, 64), 64, 0, stream>>>(                           \
-        N_, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next, \
+    k_update_forward_baoab_sorted<Real, GREAL, CACHE><<<ceil_divide(df0.next.sorted_n, 64), 64, 0, stream>>>(            \
+        df0.next.sorted_n, ca_, d_cbs_.data, d_ccs_.data, seed_, step_, d_x_t, d_v_t, dx, cm, cm_stride_, dt_, df0.g_du_dx, df0.stride, d_box_t, df0.next, \
         d_xs_.data, d_vs_.data, d_cbs_s_.data, d_ccs_s_.data, h_progress_, enqueued_)
         if (df0.next.real_bytes == 8) {
             if (from_cache) {

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     unsigned int *__restrict__ counters, // [0]=unused [1]=n_items [2]=tile count [3]=builds so far [4..4+NB_SHARDS*NB_CLASSES)=items per (shard, cost class) bucket
     const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
     const int *__restrict__ flag, const int force,
-    double *__restrict__ rebase_snap_box) { // != nullptr: scale-aware potentials (k_check_gather_scaled ran in front of this launch)
+    double *__restrict__ rebase_snap_box, // != nullptr: scale-aware potentials (k_check_gather_scaled ran in front of this launch)
+    // merged orders (engine.hpp): the first guest_blocks blocks hold guest_rows atoms followed by holes
+    const int guest_rows = 0, const int guest_blocks = 0) {
     if (!force && *flag == 0) {
         if (rebase_snap_box != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
             rebase_snapshot_box(box, rebase_snap_box);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_block_bounds(
         const bool is_row = wblk >= n_col_blocks;
         const int blk = is_row ? wblk - n_col_blocks : wblk;
         const unsigned int *idxs = is_row ? row_idxs : col_idxs;
-        const int count = is_row ? NR : NC;
+        const int count = (!is_row && blk < guest_blocks) ? guest_rows : (is_row ? NR : NC);
         const int first = blk * TILE;
         const int n = (count - first) < TILE ? (count - first) : TILE;
         Real p[3] = {0, 0, 0};
@@ -165,7 +167,12 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     // snap_x != nullptr: no bounds kernel ran in front of this launch (its boxes came with the sorted hand-over, see
     // engine.hpp: PregatherTarget); its other duties on a rebuild fall to this kernel: the coordinate / box snapshot and the
     // build count.  (The counter reset was made by whoever raised the flag.)
-    const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box) {
+    const int n_snap, const double *__restrict__ x, double *__restrict__ snap_x, double *__restrict__ snap_box,
+    // Merged orders (UPPER_TRIANGULAR lists only; engine.hpp: NonbondedAllPairs as the carrier of an interaction group): the first
+    // guest_blocks row blocks are the GROUP's row atoms (guest_rows of them, then holes up to the block boundary).  They see every
+    // column block from guest_blocks on -- the all-pairs atoms -- and none of their own kind; their items carry the sign bit in
+    // their fourth word, which tells the tile kernel to read the columns' records under the group's parameters.
+    const int guest_rows = 0, const int guest_blocks = 0) {
     if (!force && *flag == 0) {
         return;
     }
@@ -208,14 +215,17 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     const NbBox<Real> bx = load_box<Real>(box);
     const Real cutoff = static_cast<Real>(cutoff_d);
     const Real cutoff2 = cutoff * cutoff;
-    const int nrow = (NR - rb * TILE) < TILE ? (NR - rb * TILE) : TILE;
+    const bool guest = UPPER_TRIANGULAR && rb < guest_blocks;
+    const int row_limit = guest ? guest_rows : NR;
+    const int nrow = (row_limit - rb * TILE) < TILE ? (row_limit - rb * TILE) : TILE;
+    const int guest_bit = guest ? static_cast<int>(0x80000000u) : 0;
 
     if (tid == 0) {
         s_count = 0;
     }
     if (tid < TILE) {
         const int ridx = rb * TILE + tid;
-        if (ridx < NR) {
+        if (ridx < row_limit) {
             const unsigned int a = row_idxs ? row_idxs[ridx] : static_cast<unsigned int>(ridx);
             s_rx[tid] = gathered[static_cast<size_t>(a) * 8 + 0];
             s_ry[tid] = gathered[static_cast<size_t>(a) * 8 + 1];
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
 
     const Real rcx = row_ctr[rb * 3 + 0], rcy = row_ctr[rb * 3 + 1], rcz = row_ctr[rb * 3 + 2];
     const Real rex = row_ext[rb * 3 + 0], rey = row_ext[rb * 3 + 1], rez = row_ext[rb * 3 + 2];
-    const int cb_first = UPPER_TRIANGULAR ? rb : 0;
+    const int cb_first = UPPER_TRIANGULAR ? (guest ? guest_blocks : rb) : 0;
 
     // row bbox vs column bbox (k_neighborlist.cuh:296-329)
     auto coarse = [&](int cb) -> bool {
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                 const unsigned int bucket = shard * NB_CLASSES + cls;
                 const unsigned int pos = atomicAdd(&counters[NB_COUNTER_CLASS0 + bucket], 1u);
                 items[static_cast<size_t>(bucket) * items_cap + pos] =
-                    make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
+                    make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
             }
         }
     }
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
         items[static_cast<size_t>(shard * NB_CLASSES + cls) * items_cap + s_base[cls] + pos] =
-            make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total));
+            make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
     }
 #ifdef TM_NBL_TIMING
     TM_NBL_STAMP();

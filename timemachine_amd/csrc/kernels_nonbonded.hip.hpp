@@ -414,6 +414,46 @@ __device__ __forceinline__ void lds_sub(u64 *p, u64 v) {
     __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// A merged order (engine.hpp: NonbondedAllPairs as the carrier of an interaction group) pads the group's row atoms to whole 32-slot
+// blocks with HOLES: perm[slot] == NB_HOLE.  A hole's record carries w = 1e18: as a row of a tile it meets the filters exactly like
+// a row beyond NR (kernels below: s_rowflt[3] = 1e18 for those) and fails the exact test d2 < cutoff^2 in either precision; its
+// position is never looked at by anything that decides something (the list build counts rows by the group's size, not by the block).
+static const unsigned int NB_HOLE = 0xffffffffu;
+template <typename Real>
+__device__ __forceinline__ void write_hole_record(Real *__restrict__ gathered, u64 *__restrict__ g_du_dx, u64 *__restrict__ g_du_dp, const int acc_stride, const int idx) {
+    Real *g = gathered + static_cast<size_t>(idx) * 8;
+    g[0] = 0;
+    g[1] = 0;
+    g[2] = 0;
+    g[3] = static_cast<Real>(1e18);
+    g[4] = 0;
+    g[5] = 0;
+    g[6] = 0;
+    g[7] = 0;
+    if (g_du_dx) {
+        g_du_dx[0 * acc_stride + idx] = 0;
+        g_du_dx[1 * acc_stride + idx] = 0;
+        g_du_dx[2 * acc_stride + idx] = 0;
+    }
+    if (g_du_dp) {
+        g_du_dp[0 * acc_stride + idx] = 0;
+        g_du_dp[1 * acc_stride + idx] = 0;
+        g_du_dp[2 * acc_stride + idx] = 0;
+        g_du_dp[3 * acc_stride + idx] = 0;
+    }
+}
+template <typename Real>
+__device__ __forceinline__ void write_second_record(Real *__restrict__ g, const Real xn, const Real yn, const Real zn, const double *__restrict__ pa) {
+    g[0] = xn;
+    g[1] = yn;
+    g[2] = zn;
+    g[3] = static_cast<Real>(pa[3]); // w
+    g[4] = static_cast<Real>(pa[0]); // q
+    g[5] = static_cast<Real>(pa[1]); // sig
+    g[6] = static_cast<Real>(pa[2]); // eps
+    g[7] = 0;
+}
+
 // ---- K1: rebuild check + gather (+ zero the Hilbert-order accumulators) -------------------------------------
 // reference: k_check_rebuild_coords_and_box_gather + k_gather_coords_and_params (k_nonbonded.cuh:12-84)
 template <typename Real>
@@ -422,13 +462,20 @@ __global__ void k_check_gather(
     const double *__restrict__ box, const double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double pad2_quarter, // 0.25 * padding^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom) {
+    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom,
+    // merged orders (NonbondedAllPairs as the carrier of an interaction group, engine.hpp): slots [0, guest_pad) are the group's row
+    // atoms under ITS parameters p_guest (padded to whole blocks with holes, perm == NB_HOLE), the rest the all-pairs atoms under p;
+    // those get a second record under p_guest at record index K + 1 + slot (what the group's items read as columns)
+    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
     }
     if (idx < 8) {
         gathered[static_cast<size_t>(K) * 8 + idx] = 0; // sentinel record: padded list slots point here
+        if (p_guest != nullptr) {
+            gathered[static_cast<size_t>(2 * K + 1) * 8 + idx] = 0; // ... and the second records' sentinel
+        }
     }
     if (idx < 9) {
         if (snap_box[idx] != box[idx]) {
@@ -439,6 +486,10 @@ __global__ void k_check_gather(
         return;
     }
     const unsigned int a = perm[idx];
+    if (a == NB_HOLE) {
+        write_hole_record(gathered, g_du_dx, g_du_dp, acc_stride, idx);
+        return;
+    }
     slot_of_atom[a] = idx; // inverse of perm (for consumers that pick forces up from the sorted accumulator)
     const double xd = x[a * 3 + 0], yd = x[a * 3 + 1], zd = x[a * 3 + 2];
     Real xo = static_cast<Real>(snap_x[a * 3 + 0]), yo = static_cast<Real>(snap_x[a * 3 + 1]),
@@ -450,14 +501,18 @@ __global__ void k_check_gather(
         *flag_set = 1; // benign race: every writer stores the same value
     }
     Real *g = gathered + static_cast<size_t>(idx) * 8;
+    const double *pa = (p_guest != nullptr && idx < guest_pad) ? p_guest : p;
     g[0] = xn;
     g[1] = yn;
     g[2] = zn;
-    g[3] = static_cast<Real>(p[a * 4 + 3]); // w
-    g[4] = static_cast<Real>(p[a * 4 + 0]); // q
-    g[5] = static_cast<Real>(p[a * 4 + 1]); // sig
-    g[6] = static_cast<Real>(p[a * 4 + 2]); // eps
+    g[3] = static_cast<Real>(pa[a * 4 + 3]); // w
+    g[4] = static_cast<Real>(pa[a * 4 + 0]); // q
+    g[5] = static_cast<Real>(pa[a * 4 + 1]); // sig
+    g[6] = static_cast<Real>(pa[a * 4 + 2]); // eps
     g[7] = 0;
+    if (p_guest != nullptr && idx >= guest_pad) {
+        write_second_record(gathered + static_cast<size_t>(K + 1 + idx) * 8, xn, yn, zn, p_guest + a * 4);
+    }
     // sorted accumulators are component-major (component c of slot i at [c * acc_stride + i]): see the flush of the tile kernel
     if (g_du_dx) {
         g_du_dx[0 * acc_stride + idx] = 0;
@@ -492,13 +547,17 @@ __global__ void k_check_gather_scaled(
     const double *__restrict__ box, double *__restrict__ snap_x, const double *__restrict__ snap_box,
     const double threshold2, // D^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
-    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom) {
+    u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom,
+    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0) { // merged orders: see k_check_gather
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0;
     }
     if (idx < 8) {
         gathered[static_cast<size_t>(K) * 8 + idx] = 0;
+        if (p_guest != nullptr) {
+            gathered[static_cast<size_t>(2 * K + 1) * 8 + idx] = 0;
+        }
     }
     // wave-uniform: what happened to the box since the snapshot was last expressed in it
     bool same = true, scalable = true;
@@ -525,6 +584,10 @@ __global__ void k_check_gather_scaled(
         return;
     }
     const unsigned int a = perm[idx];
+    if (a == NB_HOLE) {
+        write_hole_record(gathered, g_du_dx, g_du_dp, acc_stride, idx);
+        return;
+    }
     slot_of_atom[a] = idx;
     const double xd = x[a * 3 + 0], yd = x[a * 3 + 1], zd = x[a * 3 + 2];
     double ex = xd - snap_x[a * 3 + 0], ey = yd - snap_x[a * 3 + 1], ez = zd - snap_x[a * 3 + 2];
@@ -543,14 +606,18 @@ __global__ void k_check_gather_scaled(
         *flag_set = 1;
     }
     Real *g = gathered + static_cast<size_t>(idx) * 8;
+    const double *pa = (p_guest != nullptr && idx < guest_pad) ? p_guest : p;
     g[0] = static_cast<Real>(xd);
     g[1] = static_cast<Real>(yd);
     g[2] = static_cast<Real>(zd);
-    g[3] = static_cast<Real>(p[a * 4 + 3]); // w
-    g[4] = static_cast<Real>(p[a * 4 + 0]); // q
-    g[5] = static_cast<Real>(p[a * 4 + 1]); // sig
-    g[6] = static_cast<Real>(p[a * 4 + 2]); // eps
+    g[3] = static_cast<Real>(pa[a * 4 + 3]); // w
+    g[4] = static_cast<Real>(pa[a * 4 + 0]); // q
+    g[5] = static_cast<Real>(pa[a * 4 + 1]); // sig
+    g[6] = static_cast<Real>(pa[a * 4 + 2]); // eps
     g[7] = 0;
+    if (p_guest != nullptr && idx >= guest_pad) {
+        write_second_record(gathered + static_cast<size_t>(K + 1 + idx) * 8, g[0], g[1], g[2], p_guest + a * 4);
+    }
     if (g_du_dx) {
         g_du_dx[0 * acc_stride + idx] = 0;
         g_du_dx[1 * acc_stride + idx] = 0;
@@ -598,7 +665,7 @@ __global__ void k_scatter_accum(const int K, const unsigned int *__restrict__ pe
     }
     const int d = idx / K, a = idx - d * K; // component-major source: consecutive threads read consecutive slots
     const u64 v = g[static_cast<size_t>(d) * acc_stride + a];
-    if (v != 0) {
+    if (v != 0 && perm[a] != NB_HOLE) {
         atomicAdd(out + static_cast<size_t>(perm[a]) * D + d, v);
     }
 }
@@ -882,14 +949,18 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
             r.ra = row_idxs ? row_idxs[ridx] : static_cast<unsigned int>(ridx);
         }
     };
-    auto load_records = [&](TileRegs<Real> &r) {
+    // `cost`: the item's fourth word.  Its sign bit marks the items of a merged order's GUEST rows (kernels_nblist.hip.hpp): their
+    // columns -- the all-pairs atoms -- are read under the group's parameters, from the second set of records K + 1 records further on
+    // (a scalar offset on the base address; record 2 K + 1 is that set's zero sentinel)
+    auto load_records = [&](TileRegs<Real> &r, const int cost) {
         const unsigned int ra0 = __builtin_amdgcn_readfirstlane(r.ra); // first row atom of the tile: always valid
         r.ox = gathered[static_cast<size_t>(ra0) * 8 + 0];
         r.oy = gathered[static_cast<size_t>(ra0) * 8 + 1];
         r.oz = gathered[static_cast<size_t>(ra0) * 8 + 2];
+        const Real *__restrict__ col_records = gathered + (cost < 0 ? (static_cast<size_t>(uK) + 1) * 8 : 0);
 #pragma unroll
         for (int c = 0; c < 7; c++) {
-            r.cj[c] = gathered[static_cast<size_t>(r.ja) * 8 + c]; // record K is the zero sentinel: no branch
+            r.cj[c] = col_records[static_cast<size_t>(r.ja) * 8 + c]; // record K is the zero sentinel: no branch
         }
         if (lane < TILE) {
 #pragma unroll
@@ -939,8 +1010,9 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
     [[maybe_unused]] int sub_cur = sub_drawn, sub_next = 0;
     TileRegs<Real> cur;
     if (item != NO_ITEM) {
-        load_indices(items[item], cur);
-        load_records(cur);
+        const int4 it_first = items[item];
+        load_indices(it_first, cur);
+        load_records(cur, it_first.w);
     }
     TM_T(tp_fetch);
     if constexpr (sizeof(Real) == 8) {
@@ -1450,7 +1522,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
         TM_T(t_bc);
         if (have_next) {
             load_indices(it_next, nxt);
-            load_records(nxt);
+            load_records(nxt, it_next.w);
         }
         wave_lds_sync();
         TM_T(t_c);

@@ -411,7 +411,8 @@ void Neighborlist<Real>::build_device(
         k_block_bounds<Real, false><<<grid, tpb, 0, stream>>>(
             ncb, NC_, ut ? nullptr : d_col_idxs_.data, nrb, NR_, ut ? nullptr : d_row_idxs_.data, ut ? 1 : 0, d_gathered, d_box,
             d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data, d_counters_.data, n_snap, d_x, d_snap_x, d_snap_box,
-            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, rebase_box ? d_snap_box : nullptr);
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, rebase_box ? d_snap_box : nullptr,
+            ut ? guest_rows_ : 0, ut ? guest_blocks_ : 0);
         HIP_CHECK(hipGetLastError());
         TM_DEBUG_SYNC("k_block_bounds", stream);
     }
@@ -424,7 +425,8 @@ void Neighborlist<Real>::build_device(
         k_find_ixns<Real, true><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
             cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
-            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, ls_n, ls_x, ls_snap_x, ls_snap_box);
+            d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, ls_n, ls_x, ls_snap_x, ls_snap_box,
+            guest_rows_, guest_blocks_);
     } else {
         k_find_ixns<Real, false><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
@@ -561,14 +563,36 @@ NonbondedAllPairs<Real>::NonbondedAllPairs(
     this->allocate();
 }
 
+template <typename Real>
+NonbondedAllPairs<Real>::NonbondedAllPairs(
+    const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, MergedTag,
+    const std::vector<unsigned int> &host_idxs, const std::vector<unsigned int> &guest_idxs)
+    : steps_per_sort_(STEPS_PER_SORT), N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding),
+      disable_hilbert_(disable_hilbert_sort), calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N + TILE), merged_mode_(true) {
+    this->allocate();
+    const int L = static_cast<int>(guest_idxs.size()), K1 = static_cast<int>(host_idxs.size());
+    guest_rows_ = L;
+    guest_pad_ = ceil_divide(L, TILE) * TILE;
+    std::vector<unsigned int> slots(guest_idxs);
+    slots.resize(guest_pad_, NB_HOLE);
+    slots.insert(slots.end(), host_idxs.begin(), host_idxs.end());
+    K_ = guest_pad_ + K1;
+    n_atoms_ = L + K1;
+    h_atom_idxs_ = slots;
+    d_atom_idxs_.copy_from(slots.data(), K_);
+    nblist_.resize(K_);
+    nblist_.set_guest(guest_rows_, guest_pad_ / TILE);
+}
+
 template <typename Real> void NonbondedAllPairs<Real>::allocate() {
     if (sizeof(Real) == 8) {
         d_es_table_ = es_force_table_device(beta_);
     }
-    d_atom_idxs_.realloc(N_);
-    d_perm_.realloc(N_);
-    d_gathered_.realloc(static_cast<size_t>(N_ + 1) * 8); // + one all-zero sentinel record
-    acc_stride_ = (N_ + 7) & ~7; // every component array starts on a 64-byte line
+    const int cap = slot_capacity(); // (a merged order pads the guest rows to a block boundary: up to TILE - 1 holes)
+    d_atom_idxs_.realloc(cap);
+    d_perm_.realloc(cap);
+    d_gathered_.realloc(static_cast<size_t>(cap + 1) * 8 * (merged_mode_ ? 2 : 1)); // + one all-zero sentinel record (merged: two sets)
+    acc_stride_ = (cap + 7) & ~7; // every component array starts on a 64-byte line
     d_g_du_dx_.realloc(static_cast<size_t>(acc_stride_) * 3);
     d_g_du_dp_.realloc(static_cast<size_t>(acc_stride_) * 4);
     d_snap_x_.realloc(static_cast<size_t>(N_) * 3);
@@ -624,6 +648,10 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
     d_atom_idxs_.copy_from(u.data(), K);
     nblist_.resize(K);
     K_ = K;
+    n_atoms_ = K;
+    h_atom_idxs_ = u;
+    std::sort(h_atom_idxs_.begin(), h_atom_idxs_.end());
+    idxs_version_++;
     calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
     force_rebuild_ = true;
 }
@@ -642,7 +670,7 @@ bool NonbondedAllPairs<Real>::piggyback_forces(
     // A potential that covers every atom takes the table's forces into its own Hilbert-ordered accumulator: whoever consumes
     // that accumulator (the un-permute pass, or the integrator through a deferred hand-over) then finds bonded and
     // nonbonded forces of an atom in one place, and the caller's accumulator is not touched.
-    piggyback_redirect_ = K_ == N_ && group_rows_ == 0;
+    piggyback_redirect_ = covers_all();
     return true;
 }
 
@@ -655,6 +683,50 @@ template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const Fu
     piggyback_energy_table_ = d_table;
     piggyback_energy_blocks_ = blocks;
     return true;
+}
+
+// process-wide A/B switch (tm_debug_set_merge_producers, TM_AMD_NO_MERGE): planned all-pairs + interaction-group pairs run as one pipeline
+bool g_merge_producers = std::getenv("TM_AMD_NO_MERGE") == nullptr;
+
+template <typename Real>
+Potential *NonbondedAllPairs<Real>::merged_carrier(NonbondedAllPairsBase *group, const int P_group, const double *d_p_group) {
+    if (!g_merge_producers || merged_mode_ || group_rows_ != 0 || empty_ || group == nullptr || group == this || d_p_group == nullptr) {
+        return nullptr;
+    }
+    if (merged_group_ != group || merged_versions_[0] != idxs_version_ || merged_versions_[1] != group->idxs_version()) {
+        // a new pairing (or an atom set changed: set_atom_idxs, local MD narrowing this potential): decide again, once
+        merged_.reset();
+        merged_group_ = group;
+        merged_versions_[0] = idxs_version_;
+        merged_versions_[1] = group->idxs_version();
+        merged_refused_ = true;
+        const std::vector<unsigned int> &g = group->host_atom_idxs();
+        const int L = group->num_group_rows();
+        const bool fits = group->is_interaction_group() && !group->is_empty_group() && group->precision_bytes() == static_cast<int>(sizeof(Real)) &&
+                          group->get_beta() == beta_ && group->get_cutoff() == cutoff_ && group->get_nblist_padding() == nblist_padding_ &&
+                          group->hilbert_disabled() == disable_hilbert_ && L > 0 && static_cast<int>(g.size()) - L == K_;
+        if (fits) {
+            // the group's columns must be exactly this potential's atoms (its rows are disjoint from its columns by construction)
+            std::vector<unsigned int> cols(g.begin() + L, g.end());
+            std::sort(cols.begin(), cols.end());
+            if (cols == h_atom_idxs_) {
+                merged_.reset(new NonbondedAllPairs<Real>(
+                    N_, beta_, cutoff_, disable_hilbert_, nblist_padding_, MergedTag{}, h_atom_idxs_, std::vector<unsigned int>(g.begin(), g.begin() + L)));
+                merged_refused_ = false;
+                merged_group_epoch_ = group->inputs_epoch();
+            }
+        }
+    }
+    if (merged_refused_ || P_group != N_ * PARAMS_PER_ATOM) {
+        return nullptr;
+    }
+    if (merged_group_epoch_ != group->inputs_epoch()) { // the group's inputs changed behind an unchanged pointer (set_params)
+        merged_->invalidate_cached_inputs();
+        merged_group_epoch_ = group->inputs_epoch();
+    }
+    merged_->guest_p_ = d_p_group;
+    merged_->box_scales_ = box_scales_ || group->expects_box_scaling();
+    return merged_.get();
 }
 
 template <typename Real> std::vector<long long> NonbondedAllPairs<Real>::debug_timing() {
@@ -691,7 +763,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     sync_list_mode();
     // positions pre-gathered by the consumer of the previous deferred call are usable iff they were made from exactly
     // these inputs and the order they were written in still stands (no re-sort, no forced rebuild on this call)
-    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
+    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && guest_p_ == pre_guest_p_ && d_box == pre_box_ && !force_rebuild_ &&
                              calls_since_sort_ % steps_per_sort_ != 0;
     out.consumed_sorted_pregather = pregathered && pre_sorted_;
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, nullptr, nullptr, false, stream, pregathered);
@@ -709,14 +781,17 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
     out.next.flag_clear = d_flags_.data + (parity_ ^ 1);
     out.next.g_du_dx = d_g_du_dx_.data;
     out.next.stride = acc_stride_;
-    if (K_ == N_ && group_rows_ == 0 && nblist_.upper_triangular()) { // plain all-pairs over every atom: see PregatherTarget
+    out.next.second_records = merged_mode_ ? K_ + 1 : 0;
+    if (covers_all() && nblist_.upper_triangular()) { // plain (or merged) all-pairs over every atom: see PregatherTarget
         out.next.perm = d_perm_.data;
         out.next.sorted_n = K_;
+        out.next.covers_atoms = n_atoms_;
         out.next.blk_ctr = nblist_.d_col_ctr();
         out.next.blk_ext = nblist_.d_col_ext();
         out.next.nbl_counters = nblist_.d_counters_rw();
     }
     offer_p_ = d_p;
+    offer_guest_p_ = guest_p_;
     return true;
 }
 
@@ -726,6 +801,7 @@ template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const
     pre_x_ = d_x;
     pre_box_ = d_box;
     pre_p_ = offer_p_;
+    pre_guest_p_ = offer_guest_p_;
 }
 
 template <typename Real>
@@ -742,7 +818,7 @@ void NonbondedAllPairs<Real>::execute_device(
     // above all no forced list rebuild -- the update kernel has already made the displacement test for these coordinates.
     // (Accumulators are not touched by an energy-only launch; the hand-over is consumed: the next call gathers itself.)
     const bool pregathered = d_du_dx == nullptr && d_du_dp == nullptr && d_u != nullptr && pre_valid_ && d_x == pre_x_ &&
-                             d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ && calls_since_sort_ % steps_per_sort_ != 0;
+                             d_p == pre_p_ && guest_p_ == pre_guest_p_ && d_box == pre_box_ && !force_rebuild_ && calls_since_sort_ % steps_per_sort_ != 0;
     this->run_pipeline(d_x, d_p, d_box, d_du_dx, d_du_dp, d_u, true, stream, pregathered);
 }
 
@@ -757,7 +833,7 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
         return true;
     }
     sync_list_mode();
-    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
+    const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && guest_p_ == pre_guest_p_ && d_box == pre_box_ && !force_rebuild_ &&
                              calls_since_sort_ % steps_per_sort_ != 0;
     defer_u_reduce_ = true;
     try {
@@ -785,13 +861,22 @@ bool NonbondedAllPairs<Real>::probe_ready(const int N, const int P, const double
         return false;
     }
     sync_list_mode();
-    return pre_valid_ && pre_sorted_ && d_x == pre_x_ && d_p == pre_p_ && d_box == pre_box_ && !force_rebuild_ &&
-           calls_since_sort_ % steps_per_sort_ != 0 && K_ == N_ && group_rows_ == 0 && nblist_.upper_triangular() &&
+    return pre_valid_ && pre_sorted_ && d_x == pre_x_ && d_p == pre_p_ && guest_p_ == pre_guest_p_ && d_box == pre_box_ && !force_rebuild_ &&
+           calls_since_sort_ % steps_per_sort_ != 0 && covers_all() && nblist_.upper_triangular() &&
            (static_list() || scale_aware()) && piggyback_table_ == nullptr && piggyback_energy_table_ == nullptr;
 }
 
 template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
-    d_gathered2_.reserve(static_cast<size_t>(N_ + 1) * 8);
+    const Real *had = d_gathered2_.data;
+    d_gathered2_.reserve(static_cast<size_t>(slot_capacity() + 1) * 8 * (merged_mode_ ? 2 : 1));
+    if (merged_mode_ && d_gathered2_.data != had && guest_pad_ > guest_rows_) {
+        // the holes of a merged order have no atom whose thread would write them: their records (w = 1e18, write_hole_record) once
+        std::vector<Real> holes(static_cast<size_t>(guest_pad_ - guest_rows_) * 8, static_cast<Real>(0));
+        for (int k = 0; k < guest_pad_ - guest_rows_; k++) {
+            holes[static_cast<size_t>(k) * 8 + 3] = static_cast<Real>(1e18);
+        }
+        HIP_CHECK(hipMemcpy(d_gathered2_.data + static_cast<size_t>(guest_rows_) * 8, holes.data(), holes.size() * sizeof(Real), hipMemcpyHostToDevice));
+    }
     d_u_partials2_.reserve(grid_);
     ProbeTarget t;
     t.gathered = d_gathered_.data;
@@ -813,6 +898,7 @@ template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
     t.nbl_counters = nblist_.d_counters_rw();
     t.blk_ctr = nblist_.d_col_ctr();
     t.blk_ext = nblist_.d_col_ext();
+    t.second_records = merged_mode_ ? K_ + 1 : 0;
     probe_d_box_ = pre_box_;
     return t; // pre_valid_ / pre_sorted_ stay: the sorted records still describe (x, box), or -- after the commit -- (x', box')
 }
@@ -909,6 +995,10 @@ void NonbondedAllPairs<Real>::run_pipeline(
     hipStream_t stream, const bool pregathered) {
     const int tpb = DEFAULT_TPB;
     sync_list_mode();
+    if (merged_mode_ && (guest_p_ == nullptr || d_du_dp != nullptr)) {
+        throw std::runtime_error("NonbondedAllPairs (merged carrier): needs the group's parameters bound, and evaluates forces or energies only");
+    }
+    pipeline_calls_++;
     pre_valid_ = false; // consumed by this call or stale after it
     // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker
     // does that whenever it raises the rebuild flag, and the host cannot know): the list has to be rebuilt whatever the
@@ -923,6 +1013,12 @@ void NonbondedAllPairs<Real>::run_pipeline(
         if (!disable_hilbert_ && group_rows_ > 0) { // interaction group: each side keeps its own contiguous, sorted range
             hilbert_->sort_device(group_rows_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
             hilbert_->sort_device(K_ - group_rows_, d_atom_idxs_.data + group_rows_, d_x, d_box, d_perm_.data + group_rows_, stream);
+        } else if (!disable_hilbert_ && merged_mode_) { // merged carrier: [guest rows | holes | all-pairs atoms], each side sorted for itself
+            hilbert_->sort_device(guest_rows_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
+            if (guest_pad_ > guest_rows_) {
+                HIP_CHECK(hipMemsetAsync(d_perm_.data + guest_rows_, 0xff, (guest_pad_ - guest_rows_) * sizeof(unsigned int), stream)); // NB_HOLE
+            }
+            hilbert_->sort_device(K_ - guest_pad_, d_atom_idxs_.data + guest_pad_, d_x, d_box, d_perm_.data + guest_pad_, stream);
         } else if (!disable_hilbert_) {
             hilbert_->sort_device(K_, d_atom_idxs_.data, d_x, d_box, d_perm_.data, stream);
         } else {
@@ -943,12 +1039,14 @@ void NonbondedAllPairs<Real>::run_pipeline(
         // a mover (barostat) changes the box by fractions of a percent between list builds: see k_check_gather_scaled
         k_check_gather_scaled<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now, flag_next,
-            d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
+            d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data,
+            merged_mode_ ? guest_p_ : nullptr, guest_pad_);
         HIP_CHECK(hipGetLastError());
     } else if (!pregathered) {
         k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now,
-            flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data);
+            flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data,
+            merged_mode_ ? guest_p_ : nullptr, guest_pad_);
         HIP_CHECK(hipGetLastError());
         TM_DEBUG_SYNC("k_check_gather", stream);
     }
@@ -1020,7 +1118,7 @@ void NonbondedAllPairs<Real>::run_pipeline(
         // reference's callers: cutoff == 1.2 nm); see INSIDE_SWITCH.
         const bool inside = sizeof(Real) == 8 && cutoff_ <= TM_ES_SWITCH_D;
 #ifdef TM_ROWBLOCK
-        if (K_ >= g_rowblock_min_k && nblist_.num_row_blocks() <= RB_MAX_ROW_BLOCKS) {
+        if (K_ >= g_rowblock_min_k && nblist_.num_row_blocks() <= RB_MAX_ROW_BLOCKS && !merged_mode_) {
             // large systems: one workgroup per (row block, column range) unit, see kernels_nonbonded_rowblock.hip.hpp
 #define TM_LAUNCH_ROWBLOCKS(INSIDE)                                                                                    \
     k_nonbonded_rowblocks<Real, INSIDE><<<n_cus * RB_WGS_PER_CU, RB_THREADS, 0, stream>>>(                             \
@@ -1174,6 +1272,9 @@ void NonbondedInteractionGroup<Real>::set_atom_idxs(const std::vector<int> &row_
         HIP_CHECK(hipStreamSynchronize(0));
         this->K_ = K;
     }
+    this->n_atoms_ = this->empty_ ? 0 : NR + NC;
+    this->h_atom_idxs_ = all; // rows (ascending), then -- unless empty -- the columns as given
+    this->idxs_version_++;
     this->calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
     this->force_rebuild_ = true;
 }

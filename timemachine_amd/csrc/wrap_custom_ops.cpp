@@ -549,6 +549,12 @@ template <int PREC> void declare_potentials(py::module &m) {
                  check(tm_nonbonded_all_pairs_get_build_count(p.h, &n));
                  return n;
              })
+        .def("get_merged_stats", [](AllPairs &p) { // diagnostic: (evaluations made as the carrier of an interaction group, its list's tiles, its list's builds)
+            long long calls = 0;
+            unsigned int tiles = 0, builds = 0;
+            check(tm_nonbonded_all_pairs_get_merged_stats(p.h, &calls, &tiles, &builds));
+            return py::make_tuple(calls, tiles, builds);
+        })
         .def(
             "debug_timing",
             [](AllPairs &p, const int max_waves) {
@@ -1156,6 +1162,14 @@ void declare_functions(py::module &m) {
             return previous;
         },
         py::arg("min_atoms"));
+    m.def(
+        "debug_set_merge_producers",
+        [](const bool enabled) {
+            int previous = 0;
+            check(tm_debug_set_merge_producers(enabled ? 1 : 0, &previous));
+            return previous != 0;
+        },
+        py::arg("enabled"));
     m.def(
         "debug_set_barostat_fast_path",
         [](const bool enabled) { // A/B aid: barostat attempts on the potential's current list (true) or reference-shaped (false); -> the old value

@@ -495,7 +495,15 @@ def _all_pairs_get_build_count(self):
     return n.value
 
 
+def _all_pairs_get_merged_stats(self):
+    """diagnostic: (evaluations made as the carrier of an interaction group, its list's tiles, its list's builds)"""
+    calls, tiles, builds = ctypes.c_longlong(0), ctypes.c_uint(0), ctypes.c_uint(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_merged_stats(self._h, ctypes.byref(calls), ctypes.byref(tiles), ctypes.byref(builds)))
+    return calls.value, tiles.value, builds.value
+
+
 for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
+    _k.get_merged_stats = _all_pairs_get_merged_stats  # diagnostic (not in the reference surface)
     _k.get_build_count = _all_pairs_get_build_count  # diagnostic (not in the reference surface)
     _k.debug_timing = _all_pairs_debug_timing
     _k.set_atom_idxs = _all_pairs_set_atom_idxs
@@ -1072,6 +1080,14 @@ def debug_set_rowblock_min_k(min_atoms):
     prev = _c_int(0)
     _check(_lib.tm_debug_set_rowblock_min_k(_c_int(int(min_atoms)), ctypes.byref(prev)))
     return prev.value
+
+
+def debug_set_merge_producers(enabled):
+    """A/B aid: an all-pairs potential and an interaction group on exactly its atoms run as one pipeline (True) or each for itself
+    (False); -> the old value.  Bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_merge_producers(_c_int(1 if enabled else 0), ctypes.byref(prev)))
+    return bool(prev.value)
 
 
 def debug_set_barostat_fast_path(enabled):

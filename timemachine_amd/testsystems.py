@@ -414,3 +414,72 @@ def bound_potentials(sys: System, precision=np.float32, nblist_padding: float = 
         P.Nonbonded(sys.num_atoms, sys.exclusion_idxs, sys.scale_factors, sys.beta, sys.cutoff, nblist_padding=nblist_padding).bind(sys.nb_params)
     )
     return bps
+
+
+# ---- the composition the reference's RBFE / AHFE states have (timemachine/fe/system.py:133-146) -------------------------------
+def rbfe_shaped_state(sys: System, n_ligand: int, nblist_padding: float = 0.1, env_charge_scale: Optional[float] = None):
+    """``HostGuestSystem.get_U_fns()`` for a System whose LAST ``n_ligand`` atoms are the ligand (add_chain_ligand): the list the
+    reference's single-topology code builds (fe/single_topology.py:2100-2154, host and guest combined) and packs into every
+    RBFE window -- in the dataclass's field order, ``chiral_bond`` left out as the reference leaves it out (fe/system.py:100-107):
+
+        bond, angle, proper, improper                       host + ligand terms concatenated
+        chiral_atom                                         ligand only
+        nonbonded_pair_list   NonbondedPairListPrecomputed  ligand-ligand pairs, combining rules and 1-4 scales folded in
+        nonbonded_all_pairs   Nonbonded(atom_idxs=host)     host-host; parameters [host; zeros for the ligand] (:1984-2008)
+        nonbonded_ixn_group   NonbondedInteractionGroup     ligand rows x host columns; parameters [host; ligand], w_ligand from
+                                                            lambda (:2010-2055); ``env_charge_scale`` rescales the host charges
+                                                            here only, as an environment BCC handle does (:2040-2043)
+
+    Returns [(potential dataclass, parameter array)]: bind them one by one for a Context (fe/free_energy.py:614-657 packs the same
+    list into one SummedPotential), or hand the two lists to potentials.SummedPotential."""
+    from . import potentials as P
+
+    N = sys.num_atoms
+    n_host = N - n_ligand
+    lig = np.arange(n_host, N, dtype=np.int32)
+    host = np.arange(n_host, dtype=np.int32)
+    # proper / improper: add_chain_ligand appends two improper-form terms after the ligand's proper torsions
+    n_improper = 2 if (n_ligand >= 8 and len(sys.torsion_idxs) >= 2) else 0
+    n_tors = len(sys.torsion_idxs)
+    proper_idxs, proper_params = sys.torsion_idxs[: n_tors - n_improper], sys.torsion_params[: n_tors - n_improper]
+    improper_idxs, improper_params = sys.torsion_idxs[n_tors - n_improper :], sys.torsion_params[n_tors - n_improper :]
+    # chiral centres along the chain: (centre, three others), restrained at the reference's strength (fe/chiral_utils.py)
+    centres = lig[1:-2:4]
+    chiral_idxs = np.stack([centres, centres - 1, centres + 1, centres + 2], 1).astype(np.int32)
+    chiral_params = np.full(len(chiral_idxs), 1000.0)
+    # ligand-ligand pairs with the exclusion scales folded in (value = fraction REMOVED); fully excluded pairs dropped
+    in_lig = (sys.exclusion_idxs >= n_host).all(axis=1)
+    removed = {(int(i), int(j)): sc for (i, j), sc in zip(np.sort(sys.exclusion_idxs[in_lig], axis=1), sys.scale_factors[in_lig])}
+    pairs, pair_params = [], []
+    for a in range(n_host, N):
+        for b in range(a + 1, N):
+            sq, slj = removed.get((a, b), (0.0, 0.0))
+            if sq == 1.0 and slj == 1.0:
+                continue
+            pa, pb = sys.nb_params[a], sys.nb_params[b]
+            pairs.append((a, b))
+            pair_params.append(((1.0 - sq) * pa[0] * pb[0], pa[1] + pb[1], (1.0 - slj) * pa[2] * pb[2], 0.0))
+    pairs = np.array(pairs, dtype=np.int32).reshape(-1, 2)
+    pair_params = np.array(pair_params, dtype=np.float64).reshape(-1, 4)
+    # host-host: exclusions among host atoms, ligand rows of the parameters zeroed (the choice is arbitrary: never read)
+    in_host = (sys.exclusion_idxs < n_host).all(axis=1)
+    host_params = sys.nb_params.copy()
+    host_params[n_host:] = 0.0
+    ixn_params = sys.nb_params.copy()
+    if env_charge_scale is not None:
+        ixn_params[:n_host, 0] *= env_charge_scale
+    return [
+        (P.HarmonicBond(sys.bond_idxs), sys.bond_params),
+        (P.HarmonicAngle(sys.angle_idxs), sys.angle_params),
+        (P.PeriodicTorsion(proper_idxs), proper_params),
+        (P.PeriodicTorsion(improper_idxs), improper_params),
+        (P.ChiralAtomRestraint(chiral_idxs), chiral_params),
+        (P.NonbondedPairListPrecomputed(pairs, sys.beta, sys.cutoff), pair_params),
+        (P.Nonbonded(N, sys.exclusion_idxs[in_host], sys.scale_factors[in_host], sys.beta, sys.cutoff, atom_idxs=host, nblist_padding=nblist_padding), host_params),
+        (P.NonbondedInteractionGroup(N, lig, sys.beta, sys.cutoff, col_atom_idxs=host, nblist_padding=nblist_padding), ixn_params),
+    ]
+
+
+def rbfe_bound_potentials(sys: System, n_ligand: int, nblist_padding: float = 0.1, env_charge_scale: Optional[float] = None):
+    """rbfe_shaped_state, each potential bound to its parameters (the `bps` of a Context)"""
+    return [pot.bind(np.asarray(prm, dtype=np.float64)) for pot, prm in rbfe_shaped_state(sys, n_ligand, nblist_padding, env_charge_scale)]
