@@ -94,6 +94,7 @@ def parse_args(argv=None):
                     "results do not depend on it bit for bit (reference default 0.1; 0.18 measured fastest here, DESIGN.md section 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-npt", action="store_true", help="skip the barostat-interval-25 leg (profiling runs: keeps the trace's tail the timed NVT steps)")
+    ap.add_argument("--no-rbfe-shape", action="store_true", help="skip the legs on the reference's RBFE state composition (rbfe_shape in the record)")
     ap.add_argument("--profile-steps", type=int, default=400)
     ap.add_argument("--windows", type=int, default=None, help="lambda windows (md: rows of the end-of-run u_kl gather, default 8; hrex: states, default 24)")
     ap.add_argument("--steps-per-frame", type=int, default=400, help="hrex: MD steps between exchanges (fe/free_energy.py default)")
@@ -910,6 +911,11 @@ def run_md(args, rank, local_rank, world, backend):
                     "host wall clock of the call; trajectories bit-identical to stepping alone (tests/test_gpu_parity.py)")
             except Exception as exc:  # pragma: no cover
                 out["replicas_per_gpu_error"] = str(exc)
+        if not args.no_rbfe_shape:
+            try:
+                out["rbfe_shape"] = rbfe_shape_legs(co, args, seed, n_sec)
+            except Exception as exc:  # pragma: no cover
+                out["rbfe_shape_error"] = repr(exc)
         if not args.no_cpu_baseline:
             if JOB_CPUS:  # the CPU baseline uses the job's CPUs, not this rank's slice of them
                 try:
@@ -922,6 +928,99 @@ def run_md(args, rank, local_rank, world, backend):
                 out["cpu_baseline_configs"]["gpu_beside"] = gpu_configs_1_2()
 
     emit_json(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the composition the reference's RBFE windows have (fe/system.py:133-146), next to the benchmark's single Nonbonded
+# ---------------------------------------------------------------------------------------------------------------------
+def rbfe_shape_legs(co, args, seed, n_sec, sizes=("config4", "config5")):
+    """What the engine delivers on the state composition production runs (HostGuestSystem: bonded terms, chiral restraints,
+    ligand-ligand precomputed pairs, host-host Nonbonded(atom_idxs=host), ligand-environment NonbondedInteractionGroup -- packed into
+    one SummedPotential as fe/free_energy.py:614-657 packs it) against the SAME box with one all-atom Nonbonded (the composition of the
+    reference's dhfr / hif2a BENCHMARK states and of `value`), at BASELINE config 4's size (6.3k atoms, tests/test_benchmark.py:541)
+    and config 5's (31.5k): NVT in both precisions, NPT with the barostat every 25 steps (and which path its attempts took), four
+    windows stepped together, and the composition with producer merging switched off (rounds 1-5: two lists, two tile launches, the
+    atom-order update kernel)."""
+    from timemachine_amd import potentials as P
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    out = {}
+    for size in sizes:
+        system, n_lig = (ts.config4_solvated_ligand(0.3), 30) if size == "config4" else (ts.config5_complex_sized(0.3), 40)
+        N = system.num_atoms
+
+        def pack(bound, prec):
+            summed = P.SummedPotential([bp.potential for bp in bound], [bp.params for bp in bound])
+            return [summed.bind_params_list([bp.params for bp in bound]).to_gpu(prec).bound_impl]
+
+        def make_bps(prec, composition="single"):
+            bound = ts.bound_potentials(system, prec, nblist_padding=args.padding) if composition == "single" else ts.rbfe_bound_potentials(system, n_lig, nblist_padding=args.padding)
+            return pack(bound, prec)
+
+        x, v = equilibrate(co, LangevinIntegrator, system, make_bps, seed, args.equil_scale, np.float32)
+
+        def leg(prec, composition, barostat_interval=0, merge=True, n_group=1):
+            before = co.debug_set_merge_producers(merge)
+            try:
+                ctxts, baros, all_bps = [], [], []
+                for k in range(n_group):
+                    bps = make_bps(prec, composition)
+                    movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, ts.molecule_groups(system), barostat_interval, seed + k).impl(bps)] if barostat_interval else []
+                    ctxts.append(co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, seed + 31 * k).impl(), bps, movers=movers))
+                    baros += movers
+                    all_bps.append(bps)
+                rec = {}
+                if n_group == 1:
+                    ctxt = ctxts[0]
+                    ctxt.multiple_steps(SETTLE_STEPS, 0)
+                    device_sync(co)
+                    ctxt.multiple_steps(n_sec, 0)
+                    dev_s = 1e-3 * ctxt.last_multiple_steps_ms()
+                    rec.update(ns_day=n_sec / dev_s * 86400.0 * DT * 1e-3, us_per_step=1e6 * dev_s / n_sec)
+                else:
+                    co.multiple_steps_group(ctxts, SETTLE_STEPS)
+                    device_sync(co)
+                    t0 = time.perf_counter()
+                    co.multiple_steps_group(ctxts, n_sec)
+                    wall = time.perf_counter() - t0
+                    rec.update(aggregate_ns_day=n_group * n_sec / wall * 86400.0 * DT * 1e-3, us_per_replica_step=1e6 * wall / (n_sec * n_group), replicas=n_group)
+                assert all(np.all(np.isfinite(c.get_x_t())) for c in ctxts), "trajectory diverged"
+                if baros:
+                    attempts, fast = baros[0].get_attempt_paths()
+                    rec.update(barostat_attempts=attempts, barostat_attempts_on_current_list=fast)
+                nb = find_all_pairs(all_bps[0])
+                calls, tiles, builds = nb.get_merged_stats()
+                rec["merged_evaluations"] = calls  # evaluations the all-pairs potential made as the carrier of the interaction group
+                for _ in range(8):  # (the list counters read 0 between the step that asked for a rebuild and the rebuild itself)
+                    tiles = nb.get_merged_stats()[1] if calls else nb.get_tile_ixn_count()
+                    if tiles:
+                        break
+                    ctxts[0].multiple_steps(1, 0)
+                rec["tiles_32x32"] = tiles
+                return rec
+            finally:
+                co.debug_set_merge_producers(before)
+
+        f64, f32 = np.float64, np.float32
+        r = {"atoms": N, "ligand_atoms": n_lig, "timed_steps": n_sec}
+        r["single_nonbonded"] = {"nvt_f64": leg(f64, "single"), "nvt_f32": leg(f32, "single"), "npt_25_f32": leg(f32, "single", 25), "grouped_4_f32": leg(f32, "single", n_group=4)}
+        r["nvt_f64"] = leg(f64, "rbfe")
+        r["nvt_f32"] = leg(f32, "rbfe")
+        r["npt_25_f32"] = leg(f32, "rbfe", 25)
+        r["npt_25_f64"] = leg(f64, "rbfe", 25)
+        r["grouped_4_f32"] = leg(f32, "rbfe", n_group=4)
+        r["producers_not_merged"] = {"nvt_f64": leg(f64, "rbfe", merge=False), "nvt_f32": leg(f32, "rbfe", merge=False), "npt_25_f32": leg(f32, "rbfe", 25, merge=False)}
+        r["ratio_to_single_nonbonded"] = {k: r[k]["ns_day"] / r["single_nonbonded"][k]["ns_day"] for k in ("nvt_f64", "nvt_f32", "npt_25_f32")}
+        r["ratio_to_single_nonbonded"]["grouped_4_f32"] = r["grouped_4_f32"]["aggregate_ns_day"] / r["single_nonbonded"]["grouped_4_f32"]["aggregate_ns_day"]
+        r["npt_over_nvt_f32"] = r["npt_25_f32"]["ns_day"] / r["nvt_f32"]["ns_day"]
+        r["npt_over_nvt_f64"] = r["npt_25_f64"]["ns_day"] / r["nvt_f64"]["ns_day"]
+        out[size] = r
+    out["note"] = ("HostGuestSystem.get_U_fns() (timemachine/fe/system.py:133-146; testsystems.rbfe_shaped_state) packed into one SummedPotential, "
+                   "against one all-atom Nonbonded on the same box (single_nonbonded); HIP events around the timed steps of one trajectory, host wall "
+                   "clock for the grouped legs; merged_evaluations > 0: the two tile producers ran as one pipeline (csrc/engine.hpp, merged carrier); "
+                   "producers_not_merged: the same state with tm_debug_set_merge_producers(0) -- rounds 1-5's path")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
