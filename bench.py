@@ -84,7 +84,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--mode", choices=["md", "hrex"], default="md")
+    ap.add_argument("--mode", choices=["md", "hrex", "potentials"], default="md")
+    ap.add_argument("--frames", type=int, default=4, help="potentials: coordinate frames per execute_batch call")
+    ap.add_argument("--systems", default="dhfr,config5", help="potentials: comma-separated subset of dhfr,config5")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cutoff", type=float, default=1.2)
     ap.add_argument("--workload", choices=["dhfr", "water"], default="dhfr", help="dhfr: 7023 waters + a 2490-atom solute with every bonded term kind and "
@@ -1024,6 +1026,121 @@ def rbfe_shape_legs(co, args, seed, n_sec, sizes=("config4", "config5")):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# --mode potentials: the reference benchmark's second half (tests/test_benchmark.py:148-191, 624-678: benchmark_potential)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_potentials(args):
+    """`benchmark_potential`: unbound.execute_batch(coords[F], params[5], boxes[F], du_dx, du_dp, u) timed host to host, executions per
+    second, f32 and f64 -- for Nonbonded, NonbondedInteractionGroup (the two the reference singles out, :624-678) and the SummedPotential
+    of the reference's RBFE composition (testsystems.rbfe_shaped_state), on the DHFR-shaped box (23.5k atoms) and the config-5-sized
+    complex (31.4k).  Frames: F snapshots 10 MD steps apart (:103).  Parameter sets: five copies of the state's (as the reference
+    stacks them, :647,:664) AND five lambda windows (ligand charges / w scaled: what compute_potential_matrix and u_kln
+    re-evaluation feed, fe/free_energy.py:1148-1200).  Beside the full call (u + du/dx + du/dp): forces only, energy only, and a single
+    execute() of every term of config 2 (2 243 atoms)."""
+    from timemachine_amd import potentials as P
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+    if co.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
+    co.set_device(0)
+    n_frames, n_params, n_batches = args.frames, 5, 2
+    out = {"metric": "potential executions per second, host to host (execute_batch over frames x 5 parameter sets)", "unit": "executions/s", "frames": n_frames,
+           "param_sets": n_params, "batches_timed": n_batches, "reference": "tests/test_benchmark.py:148-191 (benchmark_potential), :624-678", "device": co.device_name(),
+           "binding": co.BINDING, "systems": {}}
+
+    def frames_of(system, make_bound):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in make_bound()]
+        x, v = equilibrate(co, LangevinIntegrator, system, lambda p: [bp.to_gpu(p).bound_impl for bp in make_bound()], 11, args.equil_scale, np.float32)
+        ctxt = co.Context(x, v, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, 3).impl(), bps)
+        xs, boxes = ctxt.multiple_steps(10 * n_frames, 10)
+        return xs, boxes
+
+    def throttled_us():
+        """CPU time this job was denied by its cgroup quota so far (cpu.stat: throttled_usec), or None"""
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as fh:
+                for line in fh:
+                    if line.startswith("throttled_usec"):
+                        return int(line.split()[1])
+        except (OSError, ValueError):
+            pass
+        return None
+
+    def timed(unbound, coords, params, boxes, flags):
+        for _ in range(int(os.environ.get("TM_AMD_POT_WARMUPS", "1"))):
+            unbound.execute_batch(coords, params, boxes, *flags)  # untimed: allocations, list builds, clocks
+        runs = coords.shape[0] * params.shape[0]
+        ts_ = []
+        th0, c0 = throttled_us(), time.process_time()
+        for _ in range(n_batches):
+            co.device_synchronize()
+            t0 = time.perf_counter()
+            unbound.execute_batch(coords, params, boxes, *flags)
+            ts_.append(time.perf_counter() - t0)
+        th1 = throttled_us()
+        return {"executions_per_s": runs / float(np.mean(ts_)), "us_per_execution": 1e6 * float(np.mean(ts_)) / runs, "us_per_execution_best_batch": 1e6 * float(np.min(ts_)) / runs,
+                "host_cpu_s_per_wall_s": (time.process_time() - c0) / max(sum(ts_), 1e-9), "cgroup_throttled_us": None if th0 is None or th1 is None else th1 - th0}
+
+    forms = {"u_du_dx_du_dp": (True, True, True), "du_dx": (True, False, False), "u": (False, False, True)}
+    for name in args.systems.split(","):
+        if name == "dhfr":
+            system, n_lig = ts.dhfr_shaped_box(), 0
+        else:
+            system, n_lig = ts.config5_complex_sized(0.3), 40
+        N = system.num_atoms
+        xs, boxes = frames_of(system, lambda: ts.bound_potentials(system, np.float32, nblist_padding=0.1))
+        rec = {"atoms": N}
+        pots = {"Nonbonded": (P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff), system.nb_params)}
+        if n_lig:
+            lig = np.arange(N - n_lig, N, dtype=np.int32)
+            pots["NonbondedInteractionGroup"] = (P.NonbondedInteractionGroup(N, lig, system.beta, system.cutoff), system.nb_params)
+            state = ts.rbfe_shaped_state(system, n_lig)
+            label = "SummedPotential(" + ", ".join(type(p).__name__ for p, _ in state) + ")"
+            pots[label] = (P.SummedPotential([p for p, _ in state], [q for _, q in state]), np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state]))
+        for label, (pot, prm) in pots.items():
+            prm = np.asarray(prm, dtype=np.float64)
+            same = np.stack([prm] * n_params)
+            rec[label] = {}
+            for prec, tag in ((np.float32, "f32"), (np.float64, "f64")):
+                unbound = pot.to_gpu(prec).unbound_impl
+                r = {form: timed(unbound, xs, same, boxes, flags) for form, flags in forms.items()}
+                if n_lig:
+                    # five lambda windows: the ligand's charges and w differ, everything else is the state's
+                    windows = np.stack([prm] * n_params)
+                    flat_lig = None
+                    if label.startswith("SummedPotential"):
+                        sizes = [int(np.asarray(q).size) for _, q in state]
+                        off = sum(sizes[:-1])  # the interaction group's parameters are the last block
+                        flat_lig = off + 4 * (N - n_lig)
+                    for k in range(n_params):
+                        lam = 0.1 * k
+                        view = windows[k].reshape(-1)[flat_lig:].reshape(-1, 4) if flat_lig is not None else windows[k].reshape(-1, 4)[N - n_lig :]
+                        view[:, 0] *= 1.0 - 0.5 * lam
+                        view[:, 3] = lam * system.cutoff
+                    r["u_five_lambda_windows"] = timed(unbound, xs, windows, boxes, forms["u"])
+                rec[label][tag] = r
+        out["systems"][name] = rec
+    # one execute() of every term of config 2, host to host (the reference's compare_forces call shape, tests/common.py:250-334)
+    s2 = ts.small_solvated_ligand(lamb=0.3)
+    single = {}
+    for prec, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        impls = [(P.Nonbonded(s2.num_atoms, s2.exclusion_idxs, s2.scale_factors, s2.beta, s2.cutoff).to_gpu(prec).unbound_impl, s2.nb_params),
+                 (P.HarmonicBond(s2.bond_idxs).to_gpu(prec).unbound_impl, s2.bond_params), (P.HarmonicAngle(s2.angle_idxs).to_gpu(prec).unbound_impl, s2.angle_params),
+                 (P.PeriodicTorsion(s2.torsion_idxs).to_gpu(prec).unbound_impl, s2.torsion_params)]
+        per = {}
+        for impl, prm in impls:
+            tms = []
+            for rep in range(22):
+                t0 = time.perf_counter()
+                impl.execute(s2.coords, prm, s2.box, True, True, True)
+                tms.append(time.perf_counter() - t0)
+            per[type(impl).__name__] = 1e6 * float(np.mean(tms[2:]))
+        single[tag] = {"us_per_execute": per, "us_all_four_terms": sum(per.values())}
+    out["config2_single_execute"] = single
+    emit_json(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # --mode hrex
 # ---------------------------------------------------------------------------------------------------------------------
 def _runtime_env(name):
@@ -1239,7 +1356,10 @@ def main(argv=None):
         JOB_CPUS = None
     PINNED_CPUS = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     try:
-        if args.mode == "hrex":
+        if args.mode == "potentials":
+            if rank == 0:
+                run_potentials(args)
+        elif args.mode == "hrex":
             run_hrex(args, rank, local_rank, world, backend)
         else:
             run_md(args, rank, local_rank, world, backend)

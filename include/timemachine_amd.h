@@ -160,6 +160,19 @@ int tm_potential_execute_batch_sparse(tm_potential_t pot, int coords_size, int N
                                       const uint32_t *coords_batch_idxs, const uint32_t *params_batch_idxs,
                                       const double *coords, const double *params, const double *boxes, uint64_t *du_dx,
                                       uint64_t *du_dp, tm_int128 *u);
+/* The same three calls as the reference's BINDING delivers them (wrap_kernels.cpp:1066-1101, 820-860, 960-990): du_dx / du_dp / u as
+ * doubles (FIXED_TO_FLOAT, the virtual du_dp_fixed_to_float with its per-column exponents, convert_energy_to_fp: NaN for an
+ * overflowed energy) -- converted ON THE DEVICE, inputs staged through pinned memory in one copy, one synchronisation per call.
+ * Values equal the u64 forms converted on the host bit for bit (tests/test_gpu_potentials_surface.py); the u64 forms stay for
+ * callers that want the integers.  The compiled pybind11 module calls these; its ctypes twin keeps calling the u64 forms and
+ * converting on the host, which makes every test that runs on both bindings a comparison of the two. */
+int tm_potential_execute_f64(tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box,
+                             double *du_dx, double *du_dp, double *u);
+int tm_potential_execute_batch_f64(tm_potential_t pot, int coord_batch_size, int N, int param_batch_size, int P,
+                                   const double *coords, const double *params, const double *boxes, double *du_dx, double *du_dp, double *u);
+int tm_potential_execute_batch_sparse_f64(tm_potential_t pot, int coords_size, int N, int params_size, int P, int batch_size,
+                                          const uint32_t *coords_batch_idxs, const uint32_t *params_batch_idxs, const double *coords,
+                                          const double *params, const double *boxes, double *du_dx, double *du_dp, double *u);
 /* virtual Potential::du_dp_fixed_to_float (per-column exponents for nonbonded terms, slices for Summed)
  *                                                                    potential.cu:322-326; nonbonded_all_pairs.cu:292-308 */
 int tm_potential_du_dp_fixed_to_float(tm_potential_t pot, int N, int P, const uint64_t *du_dp, double *out);
@@ -177,6 +190,10 @@ int tm_bound_potential_get_potential(tm_bound_potential_t bp, tm_potential_t *ou
 int tm_bound_potential_execute(tm_bound_potential_t bp, int N, const double *coords, const double *box, uint64_t *du_dx, tm_int128 *u);
 int tm_bound_potential_execute_batch(tm_bound_potential_t bp, int coord_batch_size, int N, const double *coords,
                                      const double *boxes, uint64_t *du_dx, tm_int128 *u);
+/* ... and as the binding delivers them (doubles; see tm_potential_execute_f64)                   wrap_kernels.cpp:1186-1290 */
+int tm_bound_potential_execute_f64(tm_bound_potential_t bp, int N, const double *coords, const double *box, double *du_dx, double *u);
+int tm_bound_potential_execute_batch_f64(tm_bound_potential_t bp, int coord_batch_size, int N, const double *coords, const double *boxes,
+                                         double *du_dx, double *u);
 
 /* ---- LangevinIntegrator(masses f64[N], temperature, dt, friction, seed)   wrap_kernels.cpp:691-715; langevin_integrator.cu:14-43
  * Bound as <float> only, like the reference (wrap_kernels.cpp:700). */

@@ -329,3 +329,74 @@ def test_context_without_nonbonded_potentials_performs_no_box_check(co, P):
     assert len(boxes) == 1
     with pytest.raises(RuntimeError, match="number of new velocities disagree with current coords"):
         ctxt.set_v_t(np.zeros((s.num_atoms - 1, 3)))
+
+
+@pytest.mark.parametrize("precision", [np.float32, np.float64])
+def test_doubles_from_the_device_equal_the_host_conversions_of_the_raw_accumulators(co, P, precision):
+    """execute / execute_batch / execute_batch_sparse / BoundPotential.execute[_batch] return doubles converted on the DEVICE
+    (tm_potential_execute_f64 ...).  They must equal, bit for bit, what the reference's binding computes on the host from the raw
+    accumulators (wrap_kernels.cpp:1066-1101: FIXED_TO_FLOAT; du_dp_fixed_to_float with the nonbonded columns' 2^36 / 2^37 / 2^38 /
+    2^36 and the slices of a SummedPotential; convert_energy_to_fp with NaN for an overflow) -- here: execute_raw + numpy."""
+    from timemachine_amd import testsystems as ts
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    state = ts.rbfe_shaped_state(s, 20)
+    summed = P.SummedPotential([p for p, _ in state], [q for _, q in state])
+    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
+    impl = summed.to_gpu(precision).unbound_impl
+    rng = np.random.default_rng(2)
+    xs = np.stack([s.coords + rng.normal(0, 0.002, s.coords.shape) for _ in range(3)])
+    boxes = np.stack([s.box] * 3)
+    params = np.stack([flat, flat * 1.01])
+
+    def expected(x, prm, box):
+        dx, dp, u = impl.execute_raw(x, prm, box, True, True, True)
+        e_dx = dx.view(np.int64).astype(np.float64) / 2.0**36
+        e_dp = dp.view(np.int64).astype(np.float64) / 2.0**36
+        off = 0
+        for pot, q in state:  # the nonbonded blocks carry per-column exponents (q, sig, eps, w)
+            n = int(np.asarray(q).size)
+            if type(pot).__name__.startswith("Nonbonded"):
+                blk = dp[off : off + n].view(np.int64).astype(np.float64).reshape(-1, 4)
+                e_dp[off : off + n] = (blk / np.array([2.0**36, 2.0**37, 2.0**38, 2.0**36])).reshape(-1)
+            off += n
+        return e_dx, e_dp, float(u) / 2.0**36
+
+    dx, dp, u = impl.execute(xs[0], flat, boxes[0])
+    e = expected(xs[0], flat, boxes[0])
+    np.testing.assert_array_equal(dx, e[0])
+    np.testing.assert_array_equal(dp, e[1])
+    assert u == e[2]
+    bdx, bdp, bu = impl.execute_batch(xs, params, boxes, True, True, True)
+    assert bdx.shape == (3, 2) + s.coords.shape and bdp.shape == (3, 2, flat.size) and bu.shape == (3, 2)
+    ci, pi = np.array([2, 0, 1, 2], dtype=np.uint32), np.array([1, 1, 0, 0], dtype=np.uint32)
+    sdx, sdp, su = impl.execute_batch_sparse(xs, params, boxes, ci, pi, True, True, True)
+    for i in range(3):
+        for j in range(2):
+            e = expected(xs[i], params[j], boxes[i])
+            np.testing.assert_array_equal(bdx[i, j], e[0])
+            np.testing.assert_array_equal(bdp[i, j], e[1])
+            assert bu[i, j] == e[2]
+    for k in range(4):
+        np.testing.assert_array_equal(sdx[k], bdx[ci[k], pi[k]])
+        np.testing.assert_array_equal(sdp[k], bdp[ci[k], pi[k]])
+        assert su[k] == bu[ci[k], pi[k]]
+    # None for what was not asked for, in every form
+    assert impl.execute(xs[0], flat, boxes[0], False, False, True)[:2] == (None, None)
+    only_u = impl.execute_batch(xs, params, boxes, False, False, True)
+    assert only_u[0] is None and only_u[1] is None
+    np.testing.assert_array_equal(only_u[2], bu)
+    bound = co.BoundPotential(impl, flat)
+    b_dx, b_u = bound.execute(xs[1], boxes[1])
+    np.testing.assert_array_equal(b_dx, bdx[1, 0])
+    assert b_u == bu[1, 0]
+    bb_dx, bb_u = bound.execute_batch(xs, boxes, True, True)
+    np.testing.assert_array_equal(bb_dx, bdx[:, 0])
+    np.testing.assert_array_equal(bb_u, bu[:, 0])
+    # an overflowed energy reads NaN (convert_energy_to_fp): three atoms on top of each other -- every clashing pair's energy is
+    # clamped to LLONG_MAX (FLOAT_TO_FIXED_ENERGY), and two of those no longer fit the int64 range the conversion accepts
+    clash = s.coords.copy()
+    clash[3] = clash[0]
+    clash[6] = clash[0]
+    nb = P.NonbondedAllPairs(s.num_atoms, s.beta, s.cutoff).to_gpu(precision).unbound_impl
+    assert np.isnan(nb.execute(clash, s.nb_params, s.box, False, False, True)[2])

@@ -423,6 +423,34 @@ int tm_potential_execute_batch_sparse(
     TM_CATCH
 }
 
+int tm_potential_execute_f64(
+    tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, double *du_dx, double *du_dp, double *u) {
+    TM_TRY
+    pot->p->execute_host_f64(1, N, 1, P, -1, nullptr, nullptr, coords, params, box, du_dx, du_dp, u);
+    TM_CATCH
+}
+
+int tm_potential_execute_batch_f64(
+    tm_potential_t pot, int C, int N, int Pb, int P, const double *coords, const double *params, const double *boxes, double *du_dx,
+    double *du_dp, double *u) {
+    TM_TRY
+    pot->p->execute_host_f64(C, N, Pb, P, -1, nullptr, nullptr, coords, params, boxes, du_dx, du_dp, u);
+    TM_CATCH
+}
+
+int tm_potential_execute_batch_sparse_f64(
+    tm_potential_t pot, int coords_size, int N, int params_size, int P, int batch_size, const uint32_t *cidx, const uint32_t *pidx,
+    const double *coords, const double *params, const double *boxes, double *du_dx, double *du_dp, double *u) {
+    TM_TRY
+    require(batch_size >= 0, "batch_size must not be negative");
+    for (int i = 0; i < batch_size; i++) {
+        require(cidx[i] < static_cast<uint32_t>(coords_size), "coords_batch_idxs contains an index that is out of bounds");
+        require(pidx[i] < static_cast<uint32_t>(params_size), "params_batch_idxs contains an index that is out of bounds");
+    }
+    pot->p->execute_host_f64(coords_size, N, params_size, P, batch_size, cidx, pidx, coords, params, boxes, du_dx, du_dp, u);
+    TM_CATCH
+}
+
 int tm_potential_du_dp_fixed_to_float(tm_potential_t pot, int N, int P, const uint64_t *du_dp, double *out) {
     TM_TRY
     pot->p->du_dp_fixed_to_float(N, P, reinterpret_cast<const u64 *>(du_dp), out);
@@ -475,6 +503,18 @@ int tm_bound_potential_get_potential(tm_bound_potential_t bp, tm_potential_t *ou
 int tm_bound_potential_execute(tm_bound_potential_t bp, int N, const double *coords, const double *box, uint64_t *du_dx, tm_int128 *u) {
     TM_TRY
     bp->p->execute_host(N, coords, box, reinterpret_cast<u64 *>(du_dx), as_i128(u));
+    TM_CATCH
+}
+
+int tm_bound_potential_execute_f64(tm_bound_potential_t bp, int N, const double *coords, const double *box, double *du_dx, double *u) {
+    TM_TRY
+    bp->p->execute_host_f64(1, N, coords, box, du_dx, u);
+    TM_CATCH
+}
+
+int tm_bound_potential_execute_batch_f64(tm_bound_potential_t bp, int C, int N, const double *coords, const double *boxes, double *du_dx, double *u) {
+    TM_TRY
+    bp->p->execute_host_f64(C, N, coords, boxes, du_dx, u);
     TM_CATCH
 }
 

@@ -164,7 +164,7 @@ private:
 
 class Potential {
 public:
-    virtual ~Potential() {}
+    virtual ~Potential();
     // How many terms of this potential's list the busiest atom takes part in (set by the constructors of the term-list
     // potentials; "unknown" = very many).  A ForcePlan uses it to decide whether the potential's slices accumulate through the
     // per-wave LDS window (ForceLayout::win): it pays where many terms meet on the same atoms -- a protein's angles, torsions and
@@ -241,6 +241,12 @@ public:
         i128 *d_u, hipStream_t stream) = 0;
 
     virtual void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float);
+    // the same conversion as a layout the device can apply (execute_host_f64): spans of the parameter vector whose derivatives carry
+    // the nonbonded per-column exponents (2^36, 2^37, 2^38, 2^36 by index % 4) -- everything else is 2^36
+    struct DuDpSpan {
+        int offset, count;
+    };
+    virtual void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const {}
 
     void execute_host(
         const int N, const int P, const double *h_x, const double *h_p, const double *h_box, u64 *h_du_dx, u64 *h_du_dp, i128 *h_u);
@@ -258,6 +264,17 @@ public:
         const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *d_x, const double *d_p,
         const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream);
 
+    // The host entry points as the reference's BINDING delivers them (wrap_kernels.cpp:731-1131: doubles, NaN for an overflowed
+    // energy): one packed host-to-device copy from pinned staging, one memset, the evaluations, the fixed-point -> double conversion
+    // ON THE DEVICE, the results copied back, one synchronisation.  (The u64 forms above return the raw accumulators and convert
+    // on the host, 3.3 M elements per 20-evaluation batch of a 23.5k-atom system: more time than the kernels take.)
+    // batch_size < 0: the dense coords x params matrix (execute / execute_batch); else the listed (coords, params) entries.
+    // d_bound_p != nullptr: a BoundPotential's device-resident parameters (params_size == 1, h_p unused).
+    void execute_host_f64(
+        const int coords_size, const int N, const int params_size, const int P, const int batch_size, const unsigned int *coords_batch_idxs,
+        const unsigned int *params_batch_idxs, const double *h_x, const double *h_p, const double *h_box, double *h_du_dx, double *h_du_dp,
+        double *h_u, const double *d_bound_p = nullptr);
+
     void execute_batch_sparse_device(
         const int N, const int P, const int batch_size, const unsigned int *coords_batch_idxs,
         const unsigned int *params_batch_idxs, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx,
@@ -268,6 +285,10 @@ private:
     DeviceBuffer<double> hs_x_, hs_p_, hs_box_;
     DeviceBuffer<u64> hs_du_dx_, hs_du_dp_;
     DeviceBuffer<i128> hs_u_;
+    // execute_host_f64: one device block (inputs | fixed-point outputs | double outputs) and its pinned host staging, grow-only
+    DeviceBuffer<char> hf_block_;
+    void *hf_pinned_ = nullptr;
+    size_t hf_pinned_bytes_ = 0;
 };
 
 // reference: cpp/src/bound_potential.{hpp,cu}
@@ -285,6 +306,10 @@ public:
     void execute_device(const int N, const double *d_x, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream);
     void execute_host(const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
     void execute_batch_host(const int coord_batch_size, const int N, const double *h_x, const double *h_box, u64 *h_du_dx, i128 *h_u);
+    // BoundPotential.execute / execute_batch as the binding delivers them (doubles; Potential::execute_host_f64)
+    void execute_host_f64(const int coord_batch_size, const int N, const double *h_x, const double *h_box, double *h_du_dx, double *h_u) {
+        potential->execute_host_f64(coord_batch_size, N, 1, size, -1, nullptr, nullptr, h_x, nullptr, h_box, h_du_dx, nullptr, h_u, d_p.data);
+    }
 
 private:
     DeviceBuffer<double> hs_x_, hs_box_;
@@ -316,6 +341,13 @@ public:
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+    void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override {
+        int off = offset;
+        for (size_t i = 0; i < potentials_.size(); i++) {
+            potentials_[i]->du_dp_nonbonded_spans(N, params_sizes_[i], off, out);
+            off += params_sizes_[i];
+        }
+    }
 
 private:
     std::vector<std::shared_ptr<Potential>> potentials_;
@@ -345,6 +377,11 @@ public:
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+    void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override {
+        if (!potentials_.empty()) {
+            potentials_[0]->du_dp_nonbonded_spans(N, P, offset, out);
+        }
+    }
 
 private:
     std::vector<std::shared_ptr<Potential>> potentials_;
@@ -658,6 +695,7 @@ public:
 
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+    void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override { out.push_back({offset, P}); }
 
 protected:
     // shared with NonbondedInteractionGroup: same pipeline over K_ = (rows | columns) atoms with a row/column list
@@ -788,6 +826,7 @@ public:
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+    void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override { out.push_back({offset, P}); }
 private:
     int M_;
     double beta_, cutoff_;
@@ -804,6 +843,7 @@ public:
     void plan_forces(const int N, const int P, const double *d_p, ForcePlan &plan) override;
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
+    void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override { out.push_back({offset, P}); }
 private:
     int B_;
     double beta_, cutoff_;

@@ -4,6 +4,11 @@
 #include "fixed_point.hip.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
 #include <numeric>
 #include <vector>
 
@@ -49,6 +54,186 @@ void Potential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp,
     for (int i = 0; i < P; i++) {
         du_dp_float[i] = fixed_to_float<double>(du_dp[i]);
     }
+}
+
+Potential::~Potential() {
+    if (hf_pinned_ != nullptr) {
+        (void)hipHostFree(hf_pinned_);
+    }
+}
+
+// fixed-point accumulators -> the doubles the binding returns (wrap_kernels.cpp:1066-1101: FIXED_TO_FLOAT, du_dp_fixed_to_float,
+// convert_energy_to_fp): (double)(int64) v / 2^k is exact arithmetic on both sides, so the values equal the host conversions' bit for bit
+static const int DU_DP_MAX_SPANS = 32;
+struct DuDpSpanTable {
+    int n;
+    int offset[DU_DP_MAX_SPANS], count[DU_DP_MAX_SPANS];
+};
+__global__ __launch_bounds__(256) void k_outputs_to_double(
+    const size_t n_dx, const u64 *__restrict__ du_dx, double *__restrict__ o_dx, const size_t n_dp, const int P, const u64 *__restrict__ du_dp,
+    double *__restrict__ o_dp, const DuDpSpanTable spans, const int n_u, const i128 *__restrict__ u, double *__restrict__ o_u) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_dx; i += stride) {
+        o_dx[i] = static_cast<double>(static_cast<long long>(du_dx[i])) / static_cast<double>(TM_FIXED_EXPONENT);
+    }
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_dp; i += stride) {
+        const int k = static_cast<int>(i % static_cast<size_t>(P)); // position in the parameter vector
+        double scale = static_cast<double>(TM_FIXED_EXPONENT);
+        for (int sp = 0; sp < spans.n; sp++) {
+            const int r = k - spans.offset[sp];
+            if (r >= 0 && r < spans.count[sp]) {
+                const int col = r & 3; // (q, sig, eps, w): nonbonded_all_pairs.cu:292-308
+                scale = col == 1 ? static_cast<double>(TM_FIXED_EXPONENT_DU_DSIG) : (col == 2 ? static_cast<double>(TM_FIXED_EXPONENT_DU_DEPS) : (col == 0 ? static_cast<double>(TM_FIXED_EXPONENT_DU_DCHARGE) : static_cast<double>(TM_FIXED_EXPONENT_DU_DW)));
+            }
+        }
+        o_dp[i] = static_cast<double>(static_cast<long long>(du_dp[i])) / scale;
+    }
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < static_cast<size_t>(n_u); i += stride) {
+        const i128 v = u[i];
+        o_u[i] = fixed_point_overflow(v) ? __builtin_nan("") : static_cast<double>(static_cast<long long>(v)) / static_cast<double>(TM_FIXED_EXPONENT);
+    }
+}
+
+void Potential::execute_host_f64(
+    const int coords_size, const int N, const int params_size, const int P, const int batch_size, const unsigned int *coords_batch_idxs,
+    const unsigned int *params_batch_idxs, const double *h_x, const double *h_p, const double *h_box, double *h_du_dx, double *h_du_dp,
+    double *h_u, const double *d_bound_p) {
+    hipStream_t stream = 0;
+    static const bool debug_io = std::getenv("TM_AMD_DEBUG_HOSTIO") != nullptr; // stage timings of this call on stderr
+    static const bool debug_io_sync = debug_io && std::string(std::getenv("TM_AMD_DEBUG_HOSTIO")) == "sync"; // ... each stage waited for
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (debug_io) {
+            if (debug_io_sync) {
+                HIP_CHECK(hipStreamSynchronize(stream));
+            }
+            fprintf(stderr, "[hostio] %-10s %9.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+        }
+    };
+    const bool dense = batch_size < 0;
+    const size_t total = dense ? static_cast<size_t>(coords_size) * params_size : static_cast<size_t>(batch_size);
+    const size_t n_x = static_cast<size_t>(coords_size) * N * D, n_p = d_bound_p ? 0 : static_cast<size_t>(params_size) * P, n_box = static_cast<size_t>(coords_size) * D * D;
+    const size_t n_dx = h_du_dx ? total * N * D : 0, n_dp = (h_du_dp && P > 0) ? total * P : 0, n_u = h_u ? total : 0;
+    // device block: [x | p | box] doubles, [u] i128 (16-byte aligned: first of the outputs), [du_dx | du_dp] u64, then the doubles [du_dx | du_dp | u]
+    const size_t in_bytes = ((n_x + n_p + n_box) * sizeof(double) + 15) & ~static_cast<size_t>(15);
+    const size_t fixed_bytes = n_u * sizeof(i128) + (n_dx + n_dp) * sizeof(u64);
+    const size_t out_bytes = (n_dx + n_dp + n_u) * sizeof(double);
+    hf_block_.reserve(in_bytes + fixed_bytes + out_bytes + 64);
+    char *base = hf_block_.data;
+    double *d_x = reinterpret_cast<double *>(base), *d_p = d_x + n_x, *d_box = d_p + n_p;
+    i128 *d_u = reinterpret_cast<i128 *>(base + in_bytes);
+    u64 *d_du_dx = reinterpret_cast<u64 *>(d_u + n_u), *d_du_dp = d_du_dx + n_dx;
+    double *o_dx = reinterpret_cast<double *>(base + in_bytes + fixed_bytes), *o_dp = o_dx + n_dx, *o_u = o_dp + n_dp;
+    // pinned staging: the inputs, and the outputs while they are small (large outputs go straight to the caller's arrays)
+    const size_t CHUNK = static_cast<size_t>(8) << 20;
+    const size_t small_out = out_bytes <= CHUNK ? out_bytes : 0;
+    const size_t need = in_bytes + (small_out ? small_out : 2 * CHUNK);
+    if (need > hf_pinned_bytes_) {
+        if (hf_pinned_ != nullptr) {
+            HIP_CHECK(hipHostFree(hf_pinned_));
+            hf_pinned_ = nullptr;
+        }
+        hf_pinned_bytes_ = need + (need >> 2);
+        HIP_CHECK(hipHostMalloc(&hf_pinned_, hf_pinned_bytes_, hipHostMallocDefault));
+    }
+    double *s_in = static_cast<double *>(hf_pinned_);
+    std::memcpy(s_in, h_x, n_x * sizeof(double));
+    if (n_p > 0) {
+        std::memcpy(s_in + n_x, h_p, n_p * sizeof(double));
+    }
+    std::memcpy(s_in + n_x + n_p, h_box, n_box * sizeof(double));
+    stamp("staged");
+    HIP_CHECK(hipMemcpyAsync(d_x, s_in, (n_x + n_p + n_box) * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (fixed_bytes > 0) {
+        HIP_CHECK(hipMemsetAsync(d_u, 0, fixed_bytes, stream)); // the kernels accumulate
+    }
+    const double *p_dev = d_bound_p ? d_bound_p : (P > 0 ? d_p : nullptr);
+    u64 *a_dx = n_dx ? d_du_dx : nullptr, *a_dp = n_dp ? d_du_dp : nullptr;
+    i128 *a_u = n_u ? d_u : nullptr;
+    if (dense) {
+        this->execute_batch_device(coords_size, N, params_size, P, d_x, p_dev, d_box, a_dx, a_dp, a_u, stream);
+    } else {
+        this->execute_batch_sparse_device(N, P, batch_size, coords_batch_idxs, params_batch_idxs, d_x, p_dev, d_box, a_dx, a_dp, a_u, stream);
+    }
+    stamp("evaluated");
+    DuDpSpanTable spans;
+    spans.n = 0;
+    if (n_dp) {
+        std::vector<DuDpSpan> v;
+        this->du_dp_nonbonded_spans(N, P, 0, v);
+        if (v.size() > static_cast<size_t>(DU_DP_MAX_SPANS)) {
+            throw std::runtime_error("execute_host_f64: more nonbonded parameter blocks than the conversion table holds");
+        }
+        for (const DuDpSpan &sp : v) {
+            spans.offset[spans.n] = sp.offset;
+            spans.count[spans.n] = sp.count;
+            spans.n++;
+        }
+    }
+    const size_t work = std::max(n_dx, std::max(n_dp, n_u));
+    if (work > 0) {
+        const int blocks = static_cast<int>(std::min<size_t>(ceil_divide(static_cast<int>(std::min<size_t>(work, 1u << 30)), 256), 2048));
+        k_outputs_to_double<<<std::max(blocks, 1), 256, 0, stream>>>(n_dx, d_du_dx, o_dx, n_dp, std::max(P, 1), d_du_dp, o_dp, spans, static_cast<int>(n_u), d_u, o_u);
+        HIP_CHECK(hipGetLastError());
+    }
+    stamp("converted");
+    if (small_out > 0) {
+        char *s_out = static_cast<char *>(hf_pinned_) + in_bytes;
+        HIP_CHECK(hipMemcpyAsync(s_out, o_dx, out_bytes, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const double *r = reinterpret_cast<const double *>(s_out);
+        if (n_dx) {
+            std::memcpy(h_du_dx, r, n_dx * sizeof(double));
+        }
+        if (n_dp) {
+            std::memcpy(h_du_dp, r + n_dx, n_dp * sizeof(double));
+        }
+        if (n_u) {
+            std::memcpy(h_u, r + n_dx + n_dp, n_u * sizeof(double));
+        }
+    } else {
+        // large outputs: device -> two pinned chunks in turn (a copy into the caller's pageable array is staged by the runtime at a
+        // fraction of the link's rate), each chunk moved on to the caller's array while the next one is in flight
+        struct Piece {
+            const char *src;
+            char *dst;
+            size_t bytes;
+        };
+        std::vector<Piece> pieces;
+        auto cut = [&](const void *src, void *dst, size_t bytes) {
+            for (size_t off = 0; off < bytes; off += CHUNK) {
+                pieces.push_back({static_cast<const char *>(src) + off, static_cast<char *>(dst) + off, std::min(CHUNK, bytes - off)});
+            }
+        };
+        cut(o_dx, h_du_dx, n_dx * sizeof(double));
+        cut(o_dp, h_du_dp, n_dp * sizeof(double));
+        cut(o_u, h_u, n_u * sizeof(double));
+        static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+        static thread_local int ev_device = -1;
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (ev[0] == nullptr || ev_device != dev) {
+            for (hipEvent_t &e : ev) {
+                if (e != nullptr) {
+                    (void)hipEventDestroy(e);
+                }
+                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            ev_device = dev;
+        }
+        char *pin[2] = {static_cast<char *>(hf_pinned_) + in_bytes, static_cast<char *>(hf_pinned_) + in_bytes + CHUNK};
+        for (size_t k = 0; k <= pieces.size(); k++) {
+            if (k < pieces.size()) {
+                HIP_CHECK(hipMemcpyAsync(pin[k & 1], pieces[k].src, pieces[k].bytes, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipEventRecord(ev[k & 1], stream));
+            }
+            if (k > 0) {
+                HIP_CHECK(hipEventSynchronize(ev[(k - 1) & 1]));
+                std::memcpy(pieces[k - 1].dst, pin[(k - 1) & 1], pieces[k - 1].bytes);
+            }
+        }
+    }
+    stamp("returned");
 }
 
 void Potential::execute_batch_device(
@@ -292,10 +477,15 @@ void SummedPotential::execute_device(
     }
     // Children run one after the other on the caller's stream whatever `parallel` says (see engine.hpp).
     int offset = 0;
+    static const bool debug_children = std::getenv("TM_AMD_DEBUG_CHILDREN") != nullptr;
     for (int i = 0; i < n; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
         potentials_[i]->execute_device(
             N, params_sizes_[i], d_x, d_p + offset, d_box, d_du_dx, d_du_dp == nullptr ? nullptr : d_du_dp + offset,
             d_u == nullptr ? nullptr : d_u_buffer_.data + i, stream);
+        if (debug_children) {
+            fprintf(stderr, "[child %d] enqueue %.1f us\n", i, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
         offset += params_sizes_[i];
     }
     if (d_u) {

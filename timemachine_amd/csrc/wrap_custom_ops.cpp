@@ -217,26 +217,15 @@ py::tuple potential_execute(PyPotential &pot, const arr_d &coords, const arr_d &
                             const bool want_u) {
     verify_coords_and_box(coords, box);
     const int N = static_cast<int>(coords.shape(0)), P = static_cast<int>(params.size());
-    std::vector<uint64_t> du_dx(want_dx ? static_cast<size_t>(N) * 3 : 0, 9999), du_dp(want_dp ? P : 0, 9999);
-    tm_int128 u{0, 0};
+    // (the conversions of wrap_kernels.cpp:1066-1101 happen on the device, behind tm_potential_execute_f64: same values)
+    arr_d dx(std::vector<py::ssize_t>{want_dx ? N : 0, 3}), dp(want_dp ? shape_of(params) : std::vector<py::ssize_t>{0});
+    double u = 0.0;
+    double *p_dx = want_dx ? dx.mutable_data() : nullptr, *p_dp = want_dp ? dp.mutable_data() : nullptr;
     {
         py::gil_scoped_release nogil;
-        check(tm_potential_execute(pot.h, N, P, coords.data(), params.data(), box.data(), want_dx ? du_dx.data() : nullptr, want_dp ? du_dp.data() : nullptr,
-                                   want_u ? &u : nullptr));
+        check(tm_potential_execute_f64(pot.h, N, P, coords.data(), params.data(), box.data(), p_dx, p_dp, want_u ? &u : nullptr));
     }
-    py::object r_dx = py::none(), r_dp = py::none(), r_u = py::none();
-    if (want_dx) {
-        r_dx = fixed_to_float_array(du_dx, {N, 3});
-    }
-    if (want_dp) {
-        arr_d dp(shape_of(params));
-        du_dp_to_float(pot, N, P, du_dp.data(), dp.mutable_data());
-        r_dp = dp;
-    }
-    if (want_u) {
-        r_u = py::float_(tm_energy_to_float(&u));
-    }
-    return py::make_tuple(r_dx, r_dp, r_u);
+    return py::make_tuple(want_dx ? py::object(dx) : py::none(), want_dp ? py::object(dp) : py::none(), want_u ? py::object(py::float_(u)) : py::none());
 }
 
 // the un-converted accumulators (uint64[N,3] | None, uint64[P] | None, python int | None): not part of the reference surface;
@@ -270,37 +259,17 @@ py::tuple potential_execute_batch(PyPotential &pot, const arr_d &coords, const a
     }
     const int C = static_cast<int>(coords.shape(0)), N = static_cast<int>(coords.shape(1)), Pb = static_cast<int>(params.shape(0));
     const int P = Pb ? static_cast<int>(params.size() / Pb) : 0;
-    const size_t total = static_cast<size_t>(C) * Pb;
-    std::vector<uint64_t> du_dx(want_dx ? total * N * 3 : 0, 9999), du_dp(want_dp ? total * P : 0, 9999);
-    std::vector<tm_int128> u(want_u ? total : 0, tm_int128{0, 0});
+    std::vector<py::ssize_t> dp_shape{want_dp ? C : 0, Pb};
+    for (py::ssize_t d = 1; d < params.ndim(); d++) {
+        dp_shape.push_back(params.shape(d));
+    }
+    arr_d dx(std::vector<py::ssize_t>{want_dx ? C : 0, Pb, N, 3}), dp(dp_shape), e(std::vector<py::ssize_t>{want_u ? C : 0, Pb});
+    double *p_dx = want_dx ? dx.mutable_data() : nullptr, *p_dp = want_dp ? dp.mutable_data() : nullptr, *p_u = want_u ? e.mutable_data() : nullptr;
     {
         py::gil_scoped_release nogil;
-        check(tm_potential_execute_batch(pot.h, C, N, Pb, P, coords.data(), params.data(), boxes.data(), want_dx ? du_dx.data() : nullptr,
-                                         want_dp ? du_dp.data() : nullptr, want_u ? u.data() : nullptr));
+        check(tm_potential_execute_batch_f64(pot.h, C, N, Pb, P, coords.data(), params.data(), boxes.data(), p_dx, p_dp, p_u));
     }
-    py::object r_dx = py::none(), r_dp = py::none(), r_u = py::none();
-    if (want_dx) {
-        r_dx = fixed_to_float_array(du_dx, {C, Pb, N, 3});
-    }
-    if (want_dp) {
-        std::vector<py::ssize_t> shape{C, Pb};
-        for (py::ssize_t d = 1; d < params.ndim(); d++) {
-            shape.push_back(params.shape(d));
-        }
-        arr_d dp(shape);
-        for (size_t i = 0; i < total; i++) {
-            du_dp_to_float(pot, N, P, du_dp.data() + i * P, dp.mutable_data() + i * P);
-        }
-        r_dp = dp;
-    }
-    if (want_u) {
-        arr_d e(std::vector<py::ssize_t>{C, Pb});
-        for (size_t i = 0; i < total; i++) {
-            e.mutable_data()[i] = tm_energy_to_float(&u[i]);
-        }
-        r_u = e;
-    }
-    return py::make_tuple(r_dx, r_dp, r_u);
+    return py::make_tuple(want_dx ? py::object(dx) : py::none(), want_dp ? py::object(dp) : py::none(), want_u ? py::object(e) : py::none());
 }
 
 py::tuple potential_execute_batch_sparse(PyPotential &pot, const arr_d &coords, const arr_d &params, const arr_d &boxes, const arr_u &coords_batch_idxs,
@@ -331,36 +300,18 @@ py::tuple potential_execute_batch_sparse(PyPotential &pot, const arr_d &coords, 
         }
     }
     const int P = Ps ? static_cast<int>(params.size() / Ps) : 0;
-    std::vector<uint64_t> du_dx(want_dx ? static_cast<size_t>(B) * N * 3 : 0, 9999), du_dp(want_dp ? static_cast<size_t>(B) * P : 0, 9999);
-    std::vector<tm_int128> u(want_u ? B : 0, tm_int128{0, 0});
+    std::vector<py::ssize_t> dp_shape{want_dp ? B : 0};
+    for (py::ssize_t d = 1; d < params.ndim(); d++) {
+        dp_shape.push_back(params.shape(d));
+    }
+    arr_d dx(std::vector<py::ssize_t>{want_dx ? B : 0, N, 3}), dp(dp_shape), e(std::vector<py::ssize_t>{want_u ? B : 0});
+    double *p_dx = want_dx ? dx.mutable_data() : nullptr, *p_dp = want_dp ? dp.mutable_data() : nullptr, *p_u = want_u ? e.mutable_data() : nullptr;
     {
         py::gil_scoped_release nogil;
-        check(tm_potential_execute_batch_sparse(pot.h, Cs, N, Ps, P, B, coords_batch_idxs.data(), params_batch_idxs.data(), coords.data(), params.data(),
-                                                boxes.data(), want_dx ? du_dx.data() : nullptr, want_dp ? du_dp.data() : nullptr, want_u ? u.data() : nullptr));
+        check(tm_potential_execute_batch_sparse_f64(pot.h, Cs, N, Ps, P, B, coords_batch_idxs.data(), params_batch_idxs.data(), coords.data(), params.data(),
+                                                    boxes.data(), p_dx, p_dp, p_u));
     }
-    py::object r_dx = py::none(), r_dp = py::none(), r_u = py::none();
-    if (want_dx) {
-        r_dx = fixed_to_float_array(du_dx, {B, N, 3});
-    }
-    if (want_dp) {
-        std::vector<py::ssize_t> shape{B};
-        for (py::ssize_t d = 1; d < params.ndim(); d++) {
-            shape.push_back(params.shape(d));
-        }
-        arr_d dp(shape);
-        for (int i = 0; i < B; i++) {
-            du_dp_to_float(pot, N, P, du_dp.data() + static_cast<size_t>(i) * P, dp.mutable_data() + static_cast<size_t>(i) * P);
-        }
-        r_dp = dp;
-    }
-    if (want_u) {
-        arr_d e(std::vector<py::ssize_t>{B});
-        for (int i = 0; i < B; i++) {
-            e.mutable_data()[i] = tm_energy_to_float(&u[i]);
-        }
-        r_u = e;
-    }
-    return py::make_tuple(r_dx, r_dp, r_u);
+    return py::make_tuple(want_dx ? py::object(dx) : py::none(), want_dp ? py::object(dp) : py::none(), want_u ? py::object(e) : py::none());
 }
 
 void declare_potential(py::module &m) {
@@ -640,14 +591,14 @@ void declare_bound_potential(py::module &m) {
             [](PyBound &b, const arr_d &coords, const arr_d &box, const bool want_dx, const bool want_u) -> py::tuple {
                 verify_coords_and_box(coords, box);
                 const int N = static_cast<int>(coords.shape(0));
-                std::vector<uint64_t> du_dx(want_dx ? static_cast<size_t>(N) * 3 : 0, 9999);
-                tm_int128 u{0, 0};
+                arr_d dx(std::vector<py::ssize_t>{want_dx ? N : 0, 3});
+                double u = 0.0;
+                double *p_dx = want_dx ? dx.mutable_data() : nullptr;
                 {
                     py::gil_scoped_release nogil;
-                    check(tm_bound_potential_execute(b.h, N, coords.data(), box.data(), want_dx ? du_dx.data() : nullptr, want_u ? &u : nullptr));
+                    check(tm_bound_potential_execute_f64(b.h, N, coords.data(), box.data(), p_dx, want_u ? &u : nullptr));
                 }
-                return py::make_tuple(want_dx ? py::object(fixed_to_float_array(du_dx, {N, 3})) : py::none(),
-                                      want_u ? py::object(py::float_(tm_energy_to_float(&u))) : py::none());
+                return py::make_tuple(want_dx ? py::object(dx) : py::none(), want_u ? py::object(py::float_(u)) : py::none());
             },
             py::arg("coords"), py::arg("box"), py::arg("compute_du_dx") = true, py::arg("compute_u") = true, "-> (du_dx | None, u | None); wrap_kernels.cpp:1149-1186")
         .def(
@@ -660,24 +611,13 @@ void declare_bound_potential(py::module &m) {
                     throw std::runtime_error("number of batches of coords and boxes don't match");
                 }
                 const int C = static_cast<int>(coords.shape(0)), N = static_cast<int>(coords.shape(1));
-                std::vector<uint64_t> du_dx(want_dx ? static_cast<size_t>(C) * N * 3 : 0, 9999);
-                std::vector<tm_int128> u(want_u ? C : 0, tm_int128{0, 0});
+                arr_d dx(std::vector<py::ssize_t>{want_dx ? C : 0, N, 3}), e(std::vector<py::ssize_t>{want_u ? C : 0});
+                double *p_dx = want_dx ? dx.mutable_data() : nullptr, *p_u = want_u ? e.mutable_data() : nullptr;
                 {
                     py::gil_scoped_release nogil;
-                    check(tm_bound_potential_execute_batch(b.h, C, N, coords.data(), boxes.data(), want_dx ? du_dx.data() : nullptr, want_u ? u.data() : nullptr));
+                    check(tm_bound_potential_execute_batch_f64(b.h, C, N, coords.data(), boxes.data(), p_dx, p_u));
                 }
-                py::object r_dx = py::none(), r_u = py::none();
-                if (want_dx) {
-                    r_dx = fixed_to_float_array(du_dx, {C, N, 3});
-                }
-                if (want_u) {
-                    arr_d e(std::vector<py::ssize_t>{C});
-                    for (int i = 0; i < C; i++) {
-                        e.mutable_data()[i] = tm_energy_to_float(&u[i]);
-                    }
-                    r_u = e;
-                }
-                return py::make_tuple(r_dx, r_u);
+                return py::make_tuple(want_dx ? py::object(dx) : py::none(), want_u ? py::object(e) : py::none());
             },
             py::arg("coords"), py::arg("boxes"), py::arg("compute_du_dx"), py::arg("compute_u"), "-> (du_dx[C,N,3] | None, u[C] | None); wrap_kernels.cpp:1187-1274")
         .def(
