@@ -1072,13 +1072,17 @@ def run_potentials(args):
         runs = coords.shape[0] * params.shape[0]
         ts_ = []
         th0, c0 = throttled_us(), time.process_time()
+        dev_ms = []
         for _ in range(n_batches):
             co.device_synchronize()
             t0 = time.perf_counter()
             unbound.execute_batch(coords, params, boxes, *flags)
             ts_.append(time.perf_counter() - t0)
+            dev_ms.append(co.debug_last_host_call_device_ms())
         th1 = throttled_us()
         return {"executions_per_s": runs / float(np.mean(ts_)), "us_per_execution": 1e6 * float(np.mean(ts_)) / runs, "us_per_execution_best_batch": 1e6 * float(np.min(ts_)) / runs,
+                # the evaluations alone on the device (HIP events behind the staging copy and in front of the conversion / copy back)
+                "device_us_per_execution": 1e3 * float(np.mean(dev_ms)) / runs,
                 "host_cpu_s_per_wall_s": (time.process_time() - c0) / max(sum(ts_), 1e-9), "cgroup_throttled_us": None if th0 is None or th1 is None else th1 - th0}
 
     forms = {"u_du_dx_du_dp": (True, True, True), "du_dx": (True, False, False), "u": (False, False, True)}

@@ -139,6 +139,12 @@ int tm_nonbonded_all_pairs_get_build_count(tm_potential_t pot, unsigned int *cou
  * tm_debug_set_merge_producers).  *calls = force / energy evaluations made that way since construction (0: never merged);
  * *tiles / *builds = tile count and list builds of that pipeline's list (as the two entry points above report for the potential's own) */
 int tm_nonbonded_all_pairs_get_merged_stats(tm_potential_t pot, long long *calls, unsigned int *tiles, unsigned int *builds);
+/* diagnostic: energy-only evaluations that gather for themselves (batches over stored frames / parameter sets) are remembered on the
+ * device: when the check + gather kernel finds every operand of the all-pairs items unchanged (values as the kernels read them, the
+ * box, the order), the all-pairs launch gets an empty item list and its sum is the remembered one -- the same integer, the cost of a
+ * kernel prologue (csrc/engine.hpp: EnergyMemo; tm_debug_set_energy_memo).  *evaluations = such evaluations since construction (the
+ * potential's own and its merged carrier's), *skipped = those whose all-pairs launch was empty. */
+int tm_nonbonded_all_pairs_get_memo_stats(tm_potential_t pot, long long *evaluations, long long *skipped);
 /* per-wave cycle counters of the last tile-kernel launch: [waves][8] = {setup, phase1, phase2, flush, items, batches, total, 0};
  * all zero unless the library was built with -DTM_TIMING (development aid, see scripts/ablate.py) */
 int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n);
@@ -322,6 +328,12 @@ int tm_debug_set_box_scaling_reuse(int enabled);
  * full evaluations, decision).  Process-wide; *previous (may be NULL) receives the old value.  Energies, decisions and trajectories
  * are bit-identical either way. */
 int tm_debug_set_barostat_fast_path(int enabled, int *previous);
+/* diagnostic: device time (HIP events on the call's stream) of the EVALUATIONS of this process's last tm_potential_execute*_f64 /
+ * tm_bound_potential_execute*_f64 call -- behind the staging copy, in front of the conversion and the copy back (bench.py --mode potentials) */
+int tm_debug_last_host_call_device_ms(double *ms);
+/* debugging / A-B aid: the energy memo (tm_nonbonded_all_pairs_get_memo_stats) on / off; process-wide (TM_AMD_NO_ENERGY_MEMO in the
+ * environment sets the initial value to 0); *previous (may be NULL) receives the old value.  Energies are bit-identical either way. */
+int tm_debug_set_energy_memo(int enabled, int *previous);
 /* debugging / A-B aid: forces-only and energy-only plans (MD steps, barostat attempts, Summed / Fanout energy calls) run an all-pairs
  * potential and an interaction group whose columns are exactly its atoms as ONE pipeline (see tm_nonbonded_all_pairs_get_merged_stats);
  * 0 = each keeps its own list, launch and hand-over (rounds 1-5).  Process-wide (TM_AMD_NO_MERGE in the environment sets the initial

@@ -9,5 +9,5 @@ for sysn, rec in d["systems"].items():
         if lab == "atoms":
             continue
         for prec, r in v.items():
-            print("  ", lab[:44].ljust(44), prec, "  ".join("%s=%.1f" % (k, x["us_per_execution"]) for k, x in r.items()))
+            print("  ", lab[:44].ljust(44), prec, "  ".join("%s=%.1f(dev %.1f)" % (k, x["us_per_execution"], x.get("device_us_per_execution", float("nan"))) for k, x in r.items()))
 print("config 2, one execute() per term:", json.dumps(d["config2_single_execute"]))

@@ -425,3 +425,127 @@ def test_which_barostat_path_runs_in_which_composition(co, P):
         assert attempts_of([bp.to_gpu(np.float32).bound_impl for bp in host_only]) == (12, 0)
     with _Switches(co, merge=False, static_k=0, fast=True):
         assert attempts_of([bp.to_gpu(np.float32).bound_impl for bp in ts.rbfe_bound_potentials(s, n_lig)]) == (12, 0)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("which,static_k", [("config2", 4608), ("config2", 0), ("config4", 0)])
+def test_remembered_energies_are_the_recomputed_ones(co, P, which, static_k, precision):
+    """Energy-only evaluations that gather for themselves are remembered on the device (csrc/engine.hpp: EnergyMemo): when every
+    operand of the all-pairs items is unchanged the launch gets an empty item list and the sum is the remembered one.  A sequence of
+    evaluations that exercises every way the operands can change (or not) -- the same frame under the same and other parameter sets
+    (ligand only: the all-pairs part is skipped; host too: it is not), other frames, another box, a forces call in between (rewrites
+    records without comparing: the memo must not be trusted), a Hilbert re-sort -- must give, call by call, the integers of a run
+    with the memo switched off; for a single Nonbonded and for the reference's RBFE composition (merged carrier: the guest rows'
+    items always run, in a launch of their own)."""
+    from timemachine_amd import testsystems as ts
+
+    s, n_lig = _system(which)
+    N = s.num_atoms
+    state = ts.rbfe_shaped_state(s, n_lig, env_charge_scale=0.9)
+    rng = np.random.default_rng(8)
+    frames = [s.coords + rng.normal(0.0, 0.002, s.coords.shape) for _ in range(3)]
+    if precision == np.float32:
+        frames = [f.astype(np.float32).astype(np.float64) for f in frames]
+    box2 = s.box * 1.001
+    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
+    sizes = [int(np.asarray(q).size) for _, q in state]
+    off_group = sum(sizes[:-1])
+
+    def window(lam, host_scale=1.0):
+        p = flat.copy()
+        g = p[off_group:].reshape(-1, 4)
+        g[N - n_lig :, 0] *= 1.0 - 0.5 * lam
+        g[N - n_lig :, 3] = lam * s.cutoff
+        h = p[off_group - 4 * N : off_group].reshape(-1, 4)  # the host-host Nonbonded's block
+        h[:, 0] *= host_scale
+        return p
+
+    nb_single = (P.Nonbonded(N, s.exclusion_idxs, s.scale_factors, s.beta, s.cutoff), None)
+    summed = (P.SummedPotential([p for p, _ in state], [q for _, q in state]), None)
+
+    def script(impl, params_of):
+        out = []
+        e = lambda x, prm, box=s.box: out.append(int(impl.execute_raw(x, prm, box, False, False, True)[2]))
+        e(frames[0], params_of(0.0))
+        e(frames[0], params_of(0.0))            # nothing changed
+        e(frames[0], params_of(0.2))            # the ligand's parameters
+        e(frames[0], params_of(0.2))
+        e(frames[0], params_of(0.2, 0.97))      # the host's charges too
+        e(frames[1], params_of(0.2, 0.97))      # another frame
+        e(frames[1], params_of(0.4, 0.97))
+        e(frames[1], params_of(0.4, 0.97), box2)  # another box, nothing else
+        e(frames[1], params_of(0.4, 0.97), box2)
+        impl.execute_raw(frames[2], params_of(0.0), s.box, True, False, False)  # a forces call: records rewritten, nothing compared
+        e(frames[1], params_of(0.4, 0.97), box2)
+        e(frames[2], params_of(0.0))
+        for _ in range(101):                     # across the all-pairs potential's re-sort (every 100 calls)
+            e(frames[2], params_of(0.1))
+        e(frames[2], params_of(0.1))
+        return out
+
+    for pot, _ in (summed, nb_single):
+        is_summed = pot is summed[0]
+
+        def params_of(lam, host_scale=1.0):
+            w = window(lam, host_scale)
+            if is_summed:
+                return w
+            # one all-atom Nonbonded: host block with the ligand's rows taken from the group's block
+            full = w[off_group - 4 * N : off_group].reshape(-1, 4).copy()
+            full[N - n_lig :] = w[off_group:].reshape(-1, 4)[N - n_lig :]
+            return full
+
+        with _Switches(co, merge=True, static_k=static_k):
+            before = co.debug_set_energy_memo(True)
+            try:
+                impl = pot.to_gpu(precision).unbound_impl
+                with_memo = script(impl, params_of)
+                evals, skipped = _all_pairs_of(impl).get_memo_stats()
+                co.debug_set_energy_memo(False)
+                impl2 = pot.to_gpu(precision).unbound_impl
+                without = script(impl2, params_of)
+                assert _all_pairs_of(impl2).get_memo_stats() == (0, 0)
+            finally:
+                co.debug_set_energy_memo(before)
+        assert with_memo == without
+        assert len(set(with_memo[:11])) >= (6 if is_summed else 5)  # the script does change the energy
+        assert evals == len(with_memo)
+        # skipped: call 2 (nothing changed), the repeats, and -- composition only -- the ligand-only changes
+        expected_min = 100 if not is_summed else 103
+        assert skipped >= expected_min, (evals, skipped)
+        if not is_summed:
+            assert skipped <= 106, (evals, skipped)
+
+
+def test_hrex_energy_rows_with_the_memo_equal_rows_without(co, P):
+    """compute_potential_matrix (fe/free_energy.py:1148-1200 through execute_batch_sparse) over three replicas' frames x the neighbouring
+    windows of the RBFE composition: the same matrix with the memo on and off, and most evaluations skip the all-pairs launch"""
+    from timemachine_amd import hrex
+    from timemachine_amd import testsystems as ts
+
+    s, n_lig = _system("config2")
+    N = s.num_atoms
+    state = ts.rbfe_shaped_state(s, n_lig)
+    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
+    off_group = flat.size - 4 * N
+    n_states = 6
+    params = np.stack([flat] * n_states)
+    for k in range(n_states):
+        g = params[k][off_group:].reshape(-1, 4)
+        g[N - n_lig :, 3] = 0.1 * k * s.cutoff
+        g[N - n_lig :, 0] *= 1.0 - 0.05 * k
+    rng = np.random.default_rng(4)
+    coords = np.stack([s.coords + rng.normal(0, 0.002, s.coords.shape) for _ in range(n_states)])
+    boxes = np.stack([s.box] * n_states)
+    rows = {}
+    for memo in (True, False):
+        before = co.debug_set_energy_memo(memo)
+        try:
+            impl = P.SummedPotential([p for p, _ in state], [q for _, q in state]).to_gpu(np.float32).unbound_impl
+            rows[memo] = hrex.compute_potential_matrix(impl, coords, boxes, params, np.arange(n_states), max_delta_states=2)
+            if memo:
+                evals, skipped = _all_pairs_of(impl).get_memo_stats()
+        finally:
+            co.debug_set_energy_memo(before)
+    np.testing.assert_array_equal(rows[True], rows[False])
+    assert evals == np.isfinite(rows[True]).sum() and skipped == evals - n_states, (evals, skipped)  # one all-pairs launch per frame

@@ -392,6 +392,12 @@ int tm_nonbonded_all_pairs_get_merged_stats(tm_potential_t pot, long long *calls
     TM_CATCH
 }
 
+int tm_nonbonded_all_pairs_get_memo_stats(tm_potential_t pot, long long *evaluations, long long *skipped) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { p.memo_stats(evaluations, skipped); });
+    TM_CATCH
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int tm_potential_execute(
     tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, uint64_t *du_dx, uint64_t *du_dp,
@@ -939,6 +945,19 @@ int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
     require(g_rowblock_built || min_atoms == std::numeric_limits<int>::max(),
             "the row-block kernel is not built into this library (load the variant libtimemachine_amd_rowblock.so: TM_AMD_LIB)");
     g_rowblock_min_k = min_atoms;
+    TM_CATCH
+}
+int tm_debug_last_host_call_device_ms(double *ms) {
+    TM_TRY
+    *ms = g_last_host_call_device_ms;
+    TM_CATCH
+}
+int tm_debug_set_energy_memo(int enabled, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_energy_memo ? 1 : 0;
+    }
+    g_energy_memo = enabled != 0;
     TM_CATCH
 }
 int tm_debug_set_merge_producers(int enabled, int *previous) {

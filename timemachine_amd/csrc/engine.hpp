@@ -45,7 +45,23 @@ static const int FUSED_MAX_SEGMENTS = 16;
 static const int NB_SHARDS = 4;         // item buckets per cost class (row block % 4): spreads the build's bucket-cursor atomics
 static const int NB_CLASSES = 16;       // work items are bucketed by cost (estimated interacting pairs), heaviest first
 static const int NB_COUNTER_CLASS0 = 4;
-static const int NB_NUM_COUNTERS = NB_COUNTER_CLASS0 + NB_SHARDS * NB_CLASSES;
+static const int NB_COUNTER_GUEST = NB_COUNTER_CLASS0 + NB_SHARDS * NB_CLASSES; // merged orders: items of the guest rows, once more in a list of their own
+static const int NB_NUM_COUNTERS = NB_COUNTER_GUEST + 1;
+// What a nonbonded pipeline remembers about its last ENERGY-ONLY evaluation (device side; NonbondedAllPairs::run_pipeline, "memo"):
+// the check + gather kernel compares every record it is about to overwrite with what it writes, so the device knows whether the
+// all-pairs part of the coming evaluation has the operands of the last one -- then its launch gets an empty item list and the sum is
+// taken from here.  Exact: equal operands (as the kernels read them, in Real), equal box, same order => the same integer sum.
+struct EnergyMemo {
+    int changed_main; // a record that the all-pairs items read was rewritten with other values since the cached sum was made
+    int valid;        // cached_main belongs to the records as they are (but for changed_main)
+    int ran_main;     // this evaluation's decision (k_memo_select)
+    int reserved_;
+    double box[9];    // the box of the cached sum
+    long long evaluations, skipped; // diagnostics: memo evaluations since construction, of which the all-pairs launch was empty
+    i128 cached_main;
+    unsigned int main_counts[NB_SHARDS * NB_CLASSES];  // what the main launch reads as its item counts: the list's own, or zeros
+    unsigned int second_counts[NB_SHARDS * NB_CLASSES]; // ... and the second launch (the guest rows' items, all in bucket 0)
+};
 struct FusedSegment {
     int kind;
     int count;            // terms
@@ -531,6 +547,7 @@ public:
     void set_guest(const int rows, const int blocks) {
         guest_rows_ = rows;
         guest_blocks_ = blocks;
+        d_guest_items_.realloc(static_cast<size_t>(std::max(blocks, 1)) * (ceil_divide(max_size_, 64) + 1));
     }
     int get_num_row_idxs() const { return NR_; }
     int num_row_blocks() const { return ceil_divide(NR_, TILE); }
@@ -548,6 +565,8 @@ public:
     unsigned int items_cap() const { return static_cast<unsigned int>(items_cap_); }
     const unsigned int *d_col_atoms() const { return d_col_atoms_.data; }
     const int2 *d_row_segments() const { return d_row_segments_.data; } // per row block {start in d_col_atoms, listed columns}
+    const int4 *d_guest_items() const { return d_guest_items_.data; }   // merged orders: the guest rows' items once more, compact
+    unsigned int guest_items_cap() const { return static_cast<unsigned int>(d_guest_items_.length); }
 
 private:
     const int max_size_;
@@ -558,6 +577,7 @@ private:
     DeviceBuffer<unsigned int> d_counters_;  // [0] pool cursor, [1] work items, [2] 32-wide tile count, [4..12) items per cost class
     DeviceBuffer<unsigned int> d_col_atoms_; // CSR pool
     DeviceBuffer<int4> d_items_;             // NB_CLASSES buckets of items_cap_ work items, heaviest class first
+    DeviceBuffer<int4> d_guest_items_;       // merged orders (set_guest): the guest rows' items again, counted in counters[NB_COUNTER_GUEST]
     size_t items_cap_ = 0;
     DeviceBuffer<int2> d_row_segments_;
     DeviceBuffer<Real> d_scratch_gathered_; // host entry points only
@@ -566,6 +586,8 @@ private:
 
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
+extern double g_last_host_call_device_ms; // potential.hip: device time of the evaluations of the last execute_host_f64 call
+extern bool g_energy_memo;     // energy-only evaluations are remembered on the device (EnergyMemo; tm_debug_set_energy_memo)
 extern bool g_merge_producers; // ForcePlan::merge_producers runs all-pairs + interaction group as one pipeline (tm_debug_set_merge_producers)
 extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)
 extern bool g_box_scaling_reuse; // process-wide switch of the scale-aware rebuild test (tm_debug_set_box_scaling_reuse)
@@ -682,6 +704,8 @@ public:
     bool expects_box_scaling() const override { return box_scales_; }
     bool is_empty_group() const override { return empty_; }
     // diagnostics (tests assert which path ran): force / energy evaluations this potential made as a merged carrier's host
+    // diagnostic: {memo evaluations made, of which the device skipped the all-pairs launch} -- reads the device
+    void memo_stats(long long *evaluations, long long *skipped);
     void merged_stats(long long *calls, unsigned int *tiles, unsigned int *builds) {
         *calls = merged_ ? merged_->pipeline_calls_ : 0;
         *tiles = merged_ ? merged_->num_tile_ixns() : 0;
@@ -726,6 +750,11 @@ protected:
     std::vector<unsigned int> h_atom_idxs_;           // host copy of d_atom_idxs_ (group: rows then columns)
     unsigned int idxs_version_ = 1, inputs_epoch_ = 1;
     long long pipeline_calls_ = 0;
+    // ---- energy-only evaluations remembered (EnergyMemo) ----
+    DeviceBuffer<EnergyMemo> d_memo_;
+    DeviceBuffer<i128> d_u_partials_b_; // the second launch of a memo evaluation (guest rows' items + the plan's table)
+    bool memo_chain_ = false;           // the last pipeline call was a memo evaluation: the device's memo describes the records
+    long long memo_skips_ = 0;          // (host-side count of memo evaluations; what the device decided is in d_memo_)
     const char *name_ = "NonbondedAllPairs"; // class name used in error messages
     int steps_per_sort_;
     int group_rows_ = 0;  // > 0: the first group_rows_ entries of d_atom_idxs_ are the row group (sorted separately)

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void k_block_bounds(
     if (tid < NB_SHARDS * NB_CLASSES) {
         counters[NB_COUNTER_CLASS0 + tid] = 0;
     }
+    if (tid == 0) {
+        counters[NB_COUNTER_GUEST] = 0;
+    }
     if (snap_x) {
         for (int t = tid; t < n_snap; t += nthreads) {
             snap_x[t] = x[t];
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     // guest_blocks row blocks are the GROUP's row atoms (guest_rows of them, then holes up to the block boundary).  They see every
     // column block from guest_blocks on -- the all-pairs atoms -- and none of their own kind; their items carry the sign bit in
     // their fourth word, which tells the tile kernel to read the columns' records under the group's parameters.
-    const int guest_rows = 0, const int guest_blocks = 0) {
+    const int guest_rows = 0, const int guest_blocks = 0,
+    int4 *__restrict__ guest_items = nullptr) { // ... and go once more into this compact list (counted in counters[NB_COUNTER_GUEST])
     if (!force && *flag == 0) {
         return;
     }
@@ -519,8 +523,11 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
             } else { // more chunks than the staging area holds (N > 131k): claim one by one
                 const unsigned int bucket = shard * NB_CLASSES + cls;
                 const unsigned int pos = atomicAdd(&counters[NB_COUNTER_CLASS0 + bucket], 1u);
-                items[static_cast<size_t>(bucket) * items_cap + pos] =
-                    make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
+                const int4 item = make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
+                items[static_cast<size_t>(bucket) * items_cap + pos] = item;
+                if (guest && guest_items != nullptr) {
+                    guest_items[atomicAdd(&counters[NB_COUNTER_GUEST], 1u)] = item;
+                }
             }
         }
     }
@@ -535,8 +542,11 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         const unsigned int total = packed & 0xfffu, pos = (packed >> 12) & 0x7ffu, cls = packed >> 23;
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
-        items[static_cast<size_t>(shard * NB_CLASSES + cls) * items_cap + s_base[cls] + pos] =
-            make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
+        const int4 item = make_int4(rb, static_cast<int>(seg_start + off), static_cast<int>(len), static_cast<int>(total) | guest_bit);
+        items[static_cast<size_t>(shard * NB_CLASSES + cls) * items_cap + s_base[cls] + pos] = item;
+        if (guest && guest_items != nullptr) {
+            guest_items[atomicAdd(&counters[NB_COUNTER_GUEST], 1u)] = item;
+        }
     }
 #ifdef TM_NBL_TIMING
     TM_NBL_STAMP();

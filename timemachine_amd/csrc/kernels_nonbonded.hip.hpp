@@ -466,7 +466,9 @@ __global__ void k_check_gather(
     // merged orders (NonbondedAllPairs as the carrier of an interaction group, engine.hpp): slots [0, guest_pad) are the group's row
     // atoms under ITS parameters p_guest (padded to whole blocks with holes, perm == NB_HOLE), the rest the all-pairs atoms under p;
     // those get a second record under p_guest at record index K + 1 + slot (what the group's items read as columns)
-    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0) {
+    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0,
+    // != nullptr: note whether a record the all-pairs items read changes its values (EnergyMemo, engine.hpp)
+    EnergyMemo *__restrict__ memo = nullptr) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0; // the flag the NEXT call will use; its consumers finished a call ago (stream order)
@@ -502,13 +504,19 @@ __global__ void k_check_gather(
     }
     Real *g = gathered + static_cast<size_t>(idx) * 8;
     const double *pa = (p_guest != nullptr && idx < guest_pad) ? p_guest : p;
+    const Real wn = static_cast<Real>(pa[a * 4 + 3]), qn = static_cast<Real>(pa[a * 4 + 0]), sn = static_cast<Real>(pa[a * 4 + 1]), en = static_cast<Real>(pa[a * 4 + 2]);
+    if (memo != nullptr && !(p_guest != nullptr && idx < guest_pad)) { // (guest rows' records are not operands of the all-pairs items)
+        if (!(g[0] == xn && g[1] == yn && g[2] == zn && g[3] == wn && g[4] == qn && g[5] == sn && g[6] == en)) {
+            memo->changed_main = 1; // benign race: every writer stores the same value.  (NaN compares unequal: changed)
+        }
+    }
     g[0] = xn;
     g[1] = yn;
     g[2] = zn;
-    g[3] = static_cast<Real>(pa[a * 4 + 3]); // w
-    g[4] = static_cast<Real>(pa[a * 4 + 0]); // q
-    g[5] = static_cast<Real>(pa[a * 4 + 1]); // sig
-    g[6] = static_cast<Real>(pa[a * 4 + 2]); // eps
+    g[3] = wn;
+    g[4] = qn;
+    g[5] = sn;
+    g[6] = en;
     g[7] = 0;
     if (p_guest != nullptr && idx >= guest_pad) {
         write_second_record(gathered + static_cast<size_t>(K + 1 + idx) * 8, xn, yn, zn, p_guest + a * 4);
@@ -548,7 +556,7 @@ __global__ void k_check_gather_scaled(
     const double threshold2, // D^2
     int *__restrict__ flag_set, int *__restrict__ flag_clear, Real *__restrict__ gathered, u64 *__restrict__ g_du_dx,
     u64 *__restrict__ g_du_dp, const int acc_stride, int *__restrict__ slot_of_atom,
-    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0) { // merged orders: see k_check_gather
+    const double *__restrict__ p_guest = nullptr, const int guest_pad = 0, EnergyMemo *__restrict__ memo = nullptr) { // merged orders, memo: see k_check_gather
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         *flag_clear = 0;
@@ -607,6 +615,15 @@ __global__ void k_check_gather_scaled(
     }
     Real *g = gathered + static_cast<size_t>(idx) * 8;
     const double *pa = (p_guest != nullptr && idx < guest_pad) ? p_guest : p;
+    {
+        const Real xn = static_cast<Real>(xd), yn = static_cast<Real>(yd), zn = static_cast<Real>(zd);
+        const Real wn = static_cast<Real>(pa[a * 4 + 3]), qn = static_cast<Real>(pa[a * 4 + 0]), sn = static_cast<Real>(pa[a * 4 + 1]), en = static_cast<Real>(pa[a * 4 + 2]);
+        if (memo != nullptr && !(p_guest != nullptr && idx < guest_pad)) {
+            if (!(g[0] == xn && g[1] == yn && g[2] == zn && g[3] == wn && g[4] == qn && g[5] == sn && g[6] == en)) {
+                memo->changed_main = 1;
+            }
+        }
+    }
     g[0] = static_cast<Real>(xd);
     g[1] = static_cast<Real>(yd);
     g[2] = static_cast<Real>(zd);
@@ -653,6 +670,61 @@ __device__ __forceinline__ void rebase_snapshot_box(const double *__restrict__ b
     for (int d = 0; d < 3; d++) {
         snap_box[d * 4] = box[d * 4];
         snap_box[9 + d] = total[d];
+    }
+}
+
+// ---- energy-only evaluations remembered (EnergyMemo, engine.hpp) ---------------------------------------------
+// After the check + gather kernel (which noted whether an all-pairs operand changed) and the list kernels (which may have rebuilt):
+// decide whether the all-pairs launch of this evaluation has work, and hand both launches their item counts.  One wave.
+static __global__ __launch_bounds__(64) void k_memo_select(EnergyMemo *__restrict__ memo, const int trust, const double *__restrict__ box, const unsigned int *__restrict__ counters) {
+    const int lane = threadIdx.x;
+    bool same_box = true;
+    for (int k = 0; k < 9; k++) {
+        same_box = same_box && memo->box[k] == box[k];
+    }
+    const bool run_main = !(trust && memo->valid && !memo->changed_main && same_box);
+    memo->main_counts[lane] = run_main ? counters[NB_COUNTER_CLASS0 + lane] : 0u;
+    memo->second_counts[lane] = lane == 0 ? counters[NB_COUNTER_GUEST] : 0u; // bucket (shard 0, class 0) = position 0 of the guest list
+    if (lane == 0) {
+        memo->ran_main = run_main ? 1 : 0;
+    }
+}
+// ... and afterwards: the evaluation's total = (this launch's sum, or the remembered one) + the second launch's sum; the memo takes the
+// all-pairs sum over.  One workgroup.
+static __global__ __launch_bounds__(256) void k_memo_finish(
+    EnergyMemo *__restrict__ memo, const double *__restrict__ box, const i128 *__restrict__ partials_main, const int n_main, const i128 *__restrict__ partials_second,
+    const int n_second, i128 *__restrict__ out) {
+    __shared__ i128 s_part[2][4];
+    i128 a = 0, b = 0;
+    const bool ran = memo->ran_main != 0;
+    if (ran) {
+        for (int i = threadIdx.x; i < n_main; i += 256) {
+            a += partials_main[i];
+        }
+    }
+    for (int i = threadIdx.x; i < n_second; i += 256) {
+        b += partials_second[i];
+    }
+    a = wave_sum_i128(a);
+    b = wave_sum_i128(b);
+    if ((threadIdx.x & 63) == 0) {
+        s_part[0][threadIdx.x >> 6] = a;
+        s_part[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const i128 main_sum = ran ? s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3] : memo->cached_main;
+        out[0] = main_sum + s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
+        memo->cached_main = main_sum;
+        memo->valid = 1;
+        memo->changed_main = 0;
+        for (int k = 0; k < 9; k++) {
+            memo->box[k] = box[k];
+        }
+        memo->evaluations += 1;
+        if (!ran) {
+            memo->skipped += 1;
+        }
     }
 }
 
@@ -941,8 +1013,11 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
     };
     auto load_indices = [&](const int4 it, TileRegs<Real> &r) {
         r.rb = it.x;
-        r.ccount = it.z;
-        r.ja = lane < it.z ? col_atoms[it.y + lane] : uK;
+        // (bit 1 of `upper_triangular`: the guest rows' items of a merged order -- sign bit of their fourth word -- take no columns in
+        // this launch: memo evaluations run them in a launch of their own)
+        const int ncols = ((upper_triangular & 2) && it.w < 0) ? 0 : it.z;
+        r.ccount = ncols;
+        r.ja = lane < ncols ? col_atoms[it.y + lane] : uK;
         const int ridx = it.x * TILE + (lane & (TILE - 1));
         r.ra = uK;
         if (ridx < NR) {
@@ -1160,7 +1235,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
             raw_compact = gram && __ballot(wrapped) == 0ull;
             const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, col_w))); // column 0 of an item is always live
             flat = __ballot((col_live && col_w != w0) || (row_valid && row_w != w0)) == 0ull;
-            needs_order = upper_triangular && __ballot(col_live && ja <= row_first + (TILE - 1)) != 0ull;
+            needs_order = (upper_triangular & 1) && __ballot(col_live && ja <= row_first + (TILE - 1)) != 0ull;
         }
         const bool fast = gram && flat && !needs_order; // Gram form without the w term, no order test: almost every item
         // this lane's column atom as the filters see it.  Gram form: -2c and the threshold cut2 - |c|^2 (rows bring |r|^2 along).

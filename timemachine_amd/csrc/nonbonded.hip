@@ -426,7 +426,7 @@ void Neighborlist<Real>::build_device(
             N_, NC_, NR_, nullptr, nullptr, d_col_ctr_.data, d_col_ext_.data, d_col_ctr_.data, d_col_ext_.data, d_gathered, d_box,
             cutoff, cost_cutoff, d_counters_.data, d_col_atoms_.data, d_items_.data, static_cast<unsigned int>(items_cap_), d_row_segments_.data,
             d_flag ? d_flag : reinterpret_cast<const int *>(d_counters_.data), dummy_flag_force, ls_n, ls_x, ls_snap_x, ls_snap_box,
-            guest_rows_, guest_blocks_);
+            guest_rows_, guest_blocks_, guest_blocks_ > 0 ? d_guest_items_.data : nullptr);
     } else {
         k_find_ixns<Real, false><<<nrb, NBL_THREADS, lds, stream>>>(
             N_, NC_, NR_, d_col_idxs_.data, d_row_idxs_.data, d_col_ctr_.data, d_col_ext_.data, d_row_ctr_.data, d_row_ext_.data,
@@ -685,6 +685,24 @@ template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const Fu
     return true;
 }
 
+// process-wide A/B switch (tm_debug_set_energy_memo, TM_AMD_NO_ENERGY_MEMO): energy-only evaluations are remembered on the device
+bool g_energy_memo = std::getenv("TM_AMD_NO_ENERGY_MEMO") == nullptr;
+
+template <typename Real> void NonbondedAllPairs<Real>::memo_stats(long long *evaluations, long long *skipped) {
+    *evaluations = 0;
+    *skipped = 0;
+    NonbondedAllPairs<Real> *who[2] = {this, merged_.get()};
+    for (NonbondedAllPairs<Real> *p : who) {
+        if (p != nullptr && p->d_memo_.data != nullptr) {
+            EnergyMemo m;
+            HIP_CHECK(hipDeviceSynchronize());
+            p->d_memo_.copy_to(&m, 1);
+            *evaluations += m.evaluations;
+            *skipped += m.skipped;
+        }
+    }
+}
+
 // process-wide A/B switch (tm_debug_set_merge_producers, TM_AMD_NO_MERGE): planned all-pairs + interaction-group pairs run as one pipeline
 bool g_merge_producers = std::getenv("TM_AMD_NO_MERGE") == nullptr;
 
@@ -797,6 +815,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
 
 template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) {
     pre_valid_ = true;
+    memo_chain_ = false; // (the consumer rewrote records: the device's energy memo no longer describes them)
     pre_sorted_ = sorted_bounds_done;
     pre_x_ = d_x;
     pre_box_ = d_box;
@@ -843,8 +862,13 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
         throw;
     }
     defer_u_reduce_ = false;
-    partials = d_u_partials_.data;
-    count = u_partials_count_;
+    if (u_partials_count_ < 0) { // a memo evaluation: its total, one value (run_pipeline)
+        partials = d_u_partials_.data + grid_ - 1;
+        count = 1;
+    } else {
+        partials = d_u_partials_.data;
+        count = u_partials_count_;
+    }
     return true;
 }
 
@@ -899,6 +923,7 @@ template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
     t.blk_ctr = nblist_.d_col_ctr();
     t.blk_ext = nblist_.d_col_ext();
     t.second_records = merged_mode_ ? K_ + 1 : 0;
+    memo_chain_ = false; // (a commit rewrites records)
     probe_d_box_ = pre_box_;
     return t; // pre_valid_ / pre_sorted_ stay: the sorted records still describe (x, box), or -- after the commit -- (x', box')
 }
@@ -999,6 +1024,19 @@ void NonbondedAllPairs<Real>::run_pipeline(
         throw std::runtime_error("NonbondedAllPairs (merged carrier): needs the group's parameters bound, and evaluates forces or energies only");
     }
     pipeline_calls_++;
+    // Energy-only evaluations that gather for themselves (batches over stored frames and parameter sets: execute_batch[_sparse],
+    // compute_potential_matrix, u_kln re-evaluation; fe/free_energy.py:1148-1200) are REMEMBERED: see EnergyMemo.  `trust`: the
+    // device's memo describes the records as they are -- true iff the previous call into this pipeline was a memo evaluation too
+    // (any other call form rewrites records without comparing, and so do the integrator's and the barostat's hand-overs).
+    const bool memo_mode = g_energy_memo && d_u != nullptr && d_du_dx == nullptr && d_du_dp == nullptr && !pregathered && group_rows_ == 0;
+    const bool memo_trust = memo_mode && memo_chain_;
+    memo_chain_ = false; // (set again at the end of a memo evaluation)
+    if (memo_mode && d_memo_.data == nullptr) {
+        d_memo_.realloc(1);
+        HIP_CHECK(hipMemsetAsync(d_memo_.data, 0, sizeof(EnergyMemo), stream));
+        d_u_partials_b_.realloc(grid_);
+    }
+    EnergyMemo *memo = memo_mode ? d_memo_.data : nullptr;
     pre_valid_ = false; // consumed by this call or stale after it
     // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker
     // does that whenever it raises the rebuild flag, and the host cannot know): the list has to be rebuilt whatever the
@@ -1040,13 +1078,13 @@ void NonbondedAllPairs<Real>::run_pipeline(
         k_check_gather_scaled<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now, flag_next,
             d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data,
-            merged_mode_ ? guest_p_ : nullptr, guest_pad_);
+            merged_mode_ ? guest_p_ : nullptr, guest_pad_, memo);
         HIP_CHECK(hipGetLastError());
     } else if (!pregathered) {
         k_check_gather<Real><<<ceil_divide(std::max(K_, 16), tpb), tpb, 0, stream>>>(
             K_, d_perm_.data, d_x, d_p, d_box, d_snap_x_.data, d_snap_box_.data, rebuild_threshold2(), flag_now,
             flag_next, d_gathered_.data, d_du_dx ? d_g_du_dx_.data : nullptr, d_du_dp ? d_g_du_dp_.data : nullptr, acc_stride_, d_slot_of_atom_.data,
-            merged_mode_ ? guest_p_ : nullptr, guest_pad_);
+            merged_mode_ ? guest_p_ : nullptr, guest_pad_, memo);
         HIP_CHECK(hipGetLastError());
         TM_DEBUG_SYNC("k_check_gather", stream);
     }
@@ -1097,6 +1135,47 @@ void NonbondedAllPairs<Real>::run_pipeline(
     }
     piggyback_table_ = nullptr;
     piggyback_blocks_ = 0;
+    if (memo_mode) {
+        // (a) which launch has work: decided on the device; (b) the all-pairs items (guest rows' items emptied: bit 1 of the order flag);
+        // (c) the guest rows' items from their own list, with the plan's table riding -- skipped when there is neither; (d) the total
+        k_memo_select<<<1, 64, 0, stream>>>(memo, memo_trust ? 1 : 0, d_box, nblist_.d_counters());
+        HIP_CHECK(hipGetLastError());
+        const int split_m = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
+        using MemoShape = TileShape<Real, tile_wide<Real, true, false, false, false>()>;
+        const int n_wg = n_cus * MemoShape::wgs_per_cu;
+#define TM_LAUNCH_MEMO(COUNTS, CAP, ITEMS, ORDER, OUT, TABLE, TBLOCKS, ...)                                            \
+    k_nonbonded_tiles<Real, true, false, false, ##__VA_ARGS__><<<n_wg, 64 * MemoShape::waves, 0, stream>>>(               \
+        K_, nblist_.get_num_row_idxs(), ORDER, nullptr, COUNTS, CAP, ITEMS, nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, \
+        d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, OUT, TABLE, TBLOCKS, d_x, nullptr, 3, 1, nullptr, d_timing_.data)
+        const int prof_m = Profiler::get().begin("nonbonded_tiles", stream);
+        const int order_main = (nblist_.upper_triangular() ? 1 : 0) | (merged_mode_ ? 2 : 0);
+        if (split_m == 4) {
+            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, false, 4);
+        } else if (split_m == 2) {
+            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, false, 2);
+        } else {
+            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0);
+        }
+        const bool second = merged_mode_ || pig_table != nullptr;
+        if (second) {
+            TM_LAUNCH_MEMO(memo->second_counts, nblist_.guest_items_cap(), nblist_.d_guest_items(), 1, d_u_partials_b_.data, pig_table, pig_blocks);
+        }
+#undef TM_LAUNCH_MEMO
+        Profiler::get().end("nonbonded_tiles", prof_m, stream);
+        HIP_CHECK(hipGetLastError());
+        i128 *total = defer_u_reduce_ ? d_u_partials_.data + grid_ - 1 : d_u; // (deferred: the caller reads ONE value from the end of the partials)
+        k_memo_finish<<<1, 256, 0, stream>>>(memo, d_box, d_u_partials_.data, n_wg, d_u_partials_b_.data, second ? n_wg : 0, total);
+        HIP_CHECK(hipGetLastError());
+        if (defer_u_reduce_) {
+            u_partials_count_ = -1; // marks "one value at d_u_partials_ + grid_ - 1" for execute_energy_partials
+        }
+        calls_since_sort_++;
+        parity_ ^= 1;
+        force_rebuild_ = false;
+        memo_chain_ = true;
+        memo_skips_++;
+        return;
+    }
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
     // Small systems have fewer work items (about K / 2) than the launch has waves: their items are dealt in halves or
     // quarters (SPLIT) so that a launch does not last as long as one lone wave needs for a whole tile.

@@ -56,6 +56,8 @@ void Potential::du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp,
     }
 }
 
+double g_last_host_call_device_ms = 0.0; // device time of the evaluations of the last execute_host_f64 call of this process (diagnostic)
+
 Potential::~Potential() {
     if (hf_pinned_ != nullptr) {
         (void)hipHostFree(hf_pinned_);
@@ -147,6 +149,24 @@ void Potential::execute_host_f64(
     if (fixed_bytes > 0) {
         HIP_CHECK(hipMemsetAsync(d_u, 0, fixed_bytes, stream)); // the kernels accumulate
     }
+    // device time of the evaluations alone (diagnostic: tm_debug_last_host_call_device_ms): events behind the staging copies and
+    // in front of the conversion
+    static thread_local hipEvent_t ev_eval[2] = {nullptr, nullptr};
+    static thread_local int ev_eval_device = -1;
+    {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        if (ev_eval[0] == nullptr || ev_eval_device != dev) {
+            for (hipEvent_t &e : ev_eval) {
+                if (e != nullptr) {
+                    (void)hipEventDestroy(e);
+                }
+                HIP_CHECK(hipEventCreate(&e));
+            }
+            ev_eval_device = dev;
+        }
+    }
+    HIP_CHECK(hipEventRecord(ev_eval[0], stream));
     const double *p_dev = d_bound_p ? d_bound_p : (P > 0 ? d_p : nullptr);
     u64 *a_dx = n_dx ? d_du_dx : nullptr, *a_dp = n_dp ? d_du_dp : nullptr;
     i128 *a_u = n_u ? d_u : nullptr;
@@ -155,6 +175,7 @@ void Potential::execute_host_f64(
     } else {
         this->execute_batch_sparse_device(N, P, batch_size, coords_batch_idxs, params_batch_idxs, d_x, p_dev, d_box, a_dx, a_dp, a_u, stream);
     }
+    HIP_CHECK(hipEventRecord(ev_eval[1], stream));
     stamp("evaluated");
     DuDpSpanTable spans;
     spans.n = 0;
@@ -234,6 +255,10 @@ void Potential::execute_host_f64(
         }
     }
     stamp("returned");
+    float ms = 0.0f; // (both events have completed: the stream was waited for above)
+    if (hipEventElapsedTime(&ms, ev_eval[0], ev_eval[1]) == hipSuccess) {
+        g_last_host_call_device_ms = static_cast<double>(ms);
+    }
 }
 
 void Potential::execute_batch_device(

@@ -500,6 +500,11 @@ template <int PREC> void declare_potentials(py::module &m) {
                  check(tm_nonbonded_all_pairs_get_build_count(p.h, &n));
                  return n;
              })
+        .def("get_memo_stats", [](AllPairs &p) { // diagnostic: (energy-only evaluations remembered on the device, of which the all-pairs launch was empty)
+            long long evals = 0, skipped = 0;
+            check(tm_nonbonded_all_pairs_get_memo_stats(p.h, &evals, &skipped));
+            return py::make_tuple(evals, skipped);
+        })
         .def("get_merged_stats", [](AllPairs &p) { // diagnostic: (evaluations made as the carrier of an interaction group, its list's tiles, its list's builds)
             long long calls = 0;
             unsigned int tiles = 0, builds = 0;
@@ -1102,6 +1107,19 @@ void declare_functions(py::module &m) {
             return previous;
         },
         py::arg("min_atoms"));
+    m.def("debug_last_host_call_device_ms", []() { // device time of the evaluations of the last execute / execute_batch[_sparse] call (diagnostic)
+        double ms = 0.0;
+        check(tm_debug_last_host_call_device_ms(&ms));
+        return ms;
+    });
+    m.def(
+        "debug_set_energy_memo",
+        [](const bool enabled) {
+            int previous = 0;
+            check(tm_debug_set_energy_memo(enabled ? 1 : 0, &previous));
+            return previous != 0;
+        },
+        py::arg("enabled"));
     m.def(
         "debug_set_merge_producers",
         [](const bool enabled) {

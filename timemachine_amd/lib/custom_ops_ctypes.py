@@ -495,6 +495,13 @@ def _all_pairs_get_build_count(self):
     return n.value
 
 
+def _all_pairs_get_memo_stats(self):
+    """diagnostic: (energy-only evaluations remembered on the device, of which the all-pairs launch was empty)"""
+    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_memo_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
 def _all_pairs_get_merged_stats(self):
     """diagnostic: (evaluations made as the carrier of an interaction group, its list's tiles, its list's builds)"""
     calls, tiles, builds = ctypes.c_longlong(0), ctypes.c_uint(0), ctypes.c_uint(0)
@@ -504,6 +511,7 @@ def _all_pairs_get_merged_stats(self):
 
 for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
     _k.get_merged_stats = _all_pairs_get_merged_stats  # diagnostic (not in the reference surface)
+    _k.get_memo_stats = _all_pairs_get_memo_stats  # diagnostic (not in the reference surface)
     _k.get_build_count = _all_pairs_get_build_count  # diagnostic (not in the reference surface)
     _k.debug_timing = _all_pairs_debug_timing
     _k.set_atom_idxs = _all_pairs_set_atom_idxs
@@ -1080,6 +1088,22 @@ def debug_set_rowblock_min_k(min_atoms):
     prev = _c_int(0)
     _check(_lib.tm_debug_set_rowblock_min_k(_c_int(int(min_atoms)), ctypes.byref(prev)))
     return prev.value
+
+
+def debug_last_host_call_device_ms():
+    """device time of the evaluations of the last tm_potential_execute*_f64 call of this process (diagnostic; the ctypes twin's own
+    execute methods call the u64 forms, which do not set it)"""
+    ms = ctypes.c_double(0.0)
+    _check(_lib.tm_debug_last_host_call_device_ms(ctypes.byref(ms)))
+    return ms.value
+
+
+def debug_set_energy_memo(enabled):
+    """A/B aid: energy-only evaluations remembered on the device (True) or always recomputed (False); -> the old value.
+    Bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_energy_memo(_c_int(1 if enabled else 0), ctypes.byref(prev)))
+    return bool(prev.value)
 
 
 def debug_set_merge_producers(enabled):
