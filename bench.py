@@ -109,6 +109,9 @@ def parse_args(argv=None):
     ap.add_argument("--replica-group", type=int, default=4,
                     help="replicas of one rank stepped together on its GPU (custom_ops.multiple_steps_group): hrex mode's MD phase, and the "
                          "replicas_per_gpu legs of md mode; 1 = one after the other, as the reference does")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank drives device 0 (collectives over gloo): a ONE-GPU rehearsal of the N-rank launch -- rank start-up, CPU pinning under the "
+                         "job's quota, N HIP contexts, the gather / exchange collectives and grouped stepping on real hardware; the aggregate is one GPU's, not N GPUs'")
     ap.add_argument("--stub", action="store_true", help="no GPU work: a stand-in Context that sleeps (CPU tests of the launch / collective / report plumbing)")
     return ap.parse_args(argv)
 
@@ -171,7 +174,9 @@ def init_distributed(args):
 
         backend = args.backend
         if backend == "auto":
-            backend = "nccl" if (torch.cuda.is_available() and not args.stub) else "gloo"
+            backend = "nccl" if (torch.cuda.is_available() and not args.stub and not args.share_gpu) else "gloo"
+        if args.share_gpu and backend == "nccl":
+            raise SystemExit("bench.py: --share-gpu puts every rank on device 0, which RCCL refuses; use --backend gloo (the default with --share-gpu)")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -560,7 +565,7 @@ def run_md(args, rank, local_rank, world, backend):
 
         if co.device_count() < 1:
             raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
-        co.set_device(local_rank)
+        co.set_device(0 if args.share_gpu else local_rank)
         precision = np.float64 if args.precision == "f64" else np.float32
         build = ts.dhfr_shaped_box if args.workload == "dhfr" else ts.dhfr_sized_water_box
         system = build(seed=2025, hmr=True, cutoff=args.cutoff)
@@ -661,7 +666,7 @@ def run_md(args, rank, local_rank, world, backend):
     per_rank = parallel.gather_objects({
         "rank": rank, "local_rank": local_rank, "ms_per_step": rank_ms_per_step[0], "windows": my_windows,
         "host_cpu_us_per_step": rank_cpu_us_per_step[0], "cpus": len(PINNED_CPUS) if PINNED_CPUS else None,
-        "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
+        "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(0 if args.share_gpu else local_rank, args.stub), "host": socket.gethostname(),
     })
 
     if rank != 0:
@@ -712,6 +717,10 @@ def run_md(args, rank, local_rank, world, backend):
         "mbar_gather_ok": gather_ok,
         "mbar_gather_ms": gather_ms,
     }
+    if args.share_gpu:
+        out["share_gpu"] = True
+        out["share_gpu_note"] = (f"REHEARSAL: all {world} ranks drive device 0 (gloo collectives); `value` is ONE GPU's aggregate over {world} concurrently stepped "
+                                 "processes -- compare it with replicas_per_gpu of the one-process line, not with an N-GPU figure")
 
     if prof is not None:
         tiles = prof["tiles"]
@@ -1180,7 +1189,7 @@ def run_hrex(args, rank, local_rank, world, backend):
 
         if co.device_count() < 1:
             raise SystemExit("bench.py needs a GPU: timemachine_amd has no CPU fallback")
-        co.set_device(local_rank)
+        co.set_device(0 if args.share_gpu else local_rank)
         system = ts.config5_complex_sized(0.0)
         N = system.num_atoms
         lig = np.arange(system.num_water_atoms, N)
@@ -1267,10 +1276,13 @@ def run_hrex(args, rank, local_rank, world, backend):
             "rank": rank, "local_rank": local_rank, "resident_replicas": [int(r) for r in mine], "md_ms_per_frame": 1e3 * timers["md"] / n_frames,
             "ms_per_step": 1e3 * timers["md"] / replica_steps,
             "host_cpu_us_per_step": 1e6 * cpu_s / replica_steps, "host_cpu_load": cpu_s / max(elapsed_rank, 1e-9), "cpus": len(PINNED_CPUS) if PINNED_CPUS else None,
-            "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(local_rank, args.stub), "host": socket.gethostname(),
+            "device": "stub" if args.stub else co.device_name(), "pci_bus_id": pci_bus_id(0 if args.share_gpu else local_rank, args.stub), "host": socket.gethostname(),
         })
+        # every rank ran the swap chain for itself on the gathered matrix: the permutations must be the same everywhere
+        chains = parallel.gather_objects([list(map(int, p)) for p in dh.replica_idx_by_state_by_iter] + [list(map(int, dh.replica_idx_by_state))])
         if rank != 0:
             return None, None
+        chains_identical = all(c == chains[0] for c in chains)
         accepted = sum(a for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for a, _ in it)
         proposed = sum(p for it in dh.fraction_accepted_by_pair_by_iter[-n_frames:] for _, p in it)
         fields = {
@@ -1295,6 +1307,7 @@ def run_hrex(args, rank, local_rank, world, backend):
             "enqueue_threads": _group_threads(N),
             "gpu_max_hw_queues": None if args.stub else _runtime_env("GPU_MAX_HW_QUEUES"),
             "resident_replicas_rank0": len(mine),
+            "swap_chains_identical_across_ranks": chains_identical,
         }
         return fields, per_rank
 
@@ -1336,8 +1349,12 @@ def run_hrex(args, rank, local_rank, world, backend):
         "device": "stub" if args.stub else co.device_name(),
     }
     for k in ("frames_per_s", "per_frame_ms", "exchange_latency_ms", "swap_acceptance", "value_per_gpu", "host_cpu_us_per_step", "host_cpu_load", "cpu_quota",
-              "replica_group", "enqueue_threads", "gpu_max_hw_queues"):
+              "replica_group", "enqueue_threads", "gpu_max_hw_queues", "swap_chains_identical_across_ranks"):
         record[k] = main_fields[k]
+    if args.share_gpu:
+        record["share_gpu"] = True
+        record["share_gpu_note"] = (f"REHEARSAL: all {world} ranks drive device 0 (gloo collectives); `value` is ONE GPU's aggregate over {world} concurrently "
+                                    "working processes -- compare it with the one-process hrex line, not with an N-GPU figure")
     if production is not None:
         production["note"] = ("the reference's production shape (examples/run_rbfe_legs.py: fe/rbfe.py:113-121,191-192, fe/free_energy.py:695-708): f32 potentials, a Monte "
                               "Carlo barostat every 25 steps in every window, replicas stepped together; same windows, half the frames")

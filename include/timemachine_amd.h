@@ -14,11 +14,14 @@
  *   - handles are opaque and reference counted internally: a BoundPotential keeps its Potential alive, a
  *     Summed/Fanout potential keeps its children alive, a Context keeps integrator and potentials alive
  *     (reference: all bound classes are held by std::shared_ptr).  Destroy every handle you were given exactly once.
- *   - objects are stateful and NOT thread-safe (reference: cpp/src/potential.hpp:7).  Every entry point runs under ONE
- *     process-wide recursive lock, held for the whole call (a tm_context_multiple_steps call included): threads that drive
- *     different GPUs from one process are serialised -- use one process per GPU, as bench.py and the reference's
- *     parallel/client.py do.  A binding that keeps the Python GIL while it waits for this lock stalls the interpreter; the
- *     compiled binding releases the GIL around every call that reaches the device.
+ *   - Threading: objects are stateful and NOT thread-safe (reference: cpp/src/potential.hpp:7).  Every entry point runs under the
+ *     recursive lock of the calling thread's CURRENT DEVICE (hipGetDevice), held for the whole call (a tm_context_multiple_steps
+ *     call included): two threads never enter objects of one device at once, and threads that drive DIFFERENT GPUs from one
+ *     process -- each with its own device current (tm_set_device) and its own objects -- run concurrently (one process-wide lock
+ *     up to round 5).  One process per GPU, as bench.py and the reference's parallel/client.py do, remains the tested layout.  A
+ *     binding that keeps the Python GIL while it waits for the lock stalls the interpreter; the compiled binding releases the GIL
+ *     around every call that reaches the device.  Process-wide debug switches (tm_debug_set_*) are plain flags: set them before
+ *     threads start.
  *   - loading the library exports GPU_MAX_HW_QUEUES=8 to the process environment unless the variable is already set (see
  *     tm_context_multiple_steps_group); nothing else in the environment is touched.
  *   - a long tm_context_multiple_steps[_group] call does not spin on the host while the device works: the enqueueing thread stays
@@ -328,6 +331,12 @@ int tm_debug_set_box_scaling_reuse(int enabled);
  * full evaluations, decision).  Process-wide; *previous (may be NULL) receives the old value.  Energies, decisions and trajectories
  * are bit-identical either way. */
 int tm_debug_set_barostat_fast_path(int enabled, int *previous);
+/* test hooks of the locking contract (see "Threading" at the top of this header): tm_debug_set_thread_lock_device makes the calling
+ * thread take device `device`'s lock whatever HIP's current device is (-1: back to hipGetDevice; a box without a GPU has no device to
+ * make current); tm_debug_hold_api_lock enters the ABI like any entry point, holds the lock for `milliseconds` and reports the largest
+ * number of threads that were ever inside it at once (a negative duration resets that figure).  Two threads on two devices: 2; on one: 1. */
+int tm_debug_set_thread_lock_device(int device);
+int tm_debug_hold_api_lock(int milliseconds, int *max_concurrent);
 /* diagnostic: device time (HIP events on the call's stream) of the EVALUATIONS of this process's last tm_potential_execute*_f64 /
  * tm_bound_potential_execute*_f64 call -- behind the staging copy, in front of the conversion and the copy back (bench.py --mode potentials) */
 int tm_debug_last_host_call_device_ms(double *ms);

@@ -144,3 +144,18 @@ def test_pin_rank_to_cpus_slices_the_allowed_set():
         assert bench.pin_rank_to_cpus(0, 1) == before  # a single rank keeps everything
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_bench_share_gpu_rehearsal_of_the_n_rank_launch():
+    """`--gpus N --share-gpu`: N ranks that all drive device 0 over gloo -- the one-GPU rehearsal of the 8-GPU job (rank launch, CPU
+    pinning, N device contexts, the collectives, grouped stepping).  The record says what it is, the hrex line vouches that every rank
+    ran the same swap chain, and RCCL is refused (it cannot put two ranks on one device)."""
+    md = _line(_run("--gpus", "2", "--share-gpu", "--steps", "40", "--warmup", "10"))
+    assert md["share_gpu"] is True and md["backend"] == "gloo" and "REHEARSAL" in md["share_gpu_note"] and md["mbar_gather_ok"] is True
+    hx = _line(_run("--gpus", "2", "--share-gpu", "--mode", "hrex", "--windows", "6", "--steps", "800", "--warmup", "400"))
+    assert hx["share_gpu"] is True and hx["swap_chains_identical_across_ranks"] is True
+    assert [r["resident_replicas"] for r in hx["per_rank"]] == [[0, 2, 4], [1, 3, 5]]
+    plain = _line(_run("--gpus", "2", "--mode", "hrex", "--windows", "6", "--steps", "400", "--warmup", "400"))
+    assert "share_gpu" not in plain and plain["swap_chains_identical_across_ranks"] is True
+    r = _run("--gpus", "2", "--share-gpu", "--backend", "nccl", "--steps", "10", "--warmup", "5")
+    assert r.returncode != 0

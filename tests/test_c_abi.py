@@ -254,3 +254,41 @@ def test_loading_the_library_exports_the_hardware_queue_count():
     # ... and the Python package itself does not touch the environment any more
     text = open(os.path.join(REPO, "timemachine_amd", "__init__.py")).read()
     assert "environ" not in text
+
+
+def test_api_lock_is_per_device_not_per_process():
+    """The C ABI's threading contract (include/timemachine_amd.h, "Threading"): an entry point holds the lock of the calling thread's
+    current DEVICE.  Two host threads on two devices are inside the ABI at the same time; two on one device never are.  No GPU here:
+    tm_debug_set_thread_lock_device stands in for hipSetDevice, tm_debug_hold_api_lock for a long call (reference contract:
+    cpp/src/potential.hpp:7 -- not thread-safe per OBJECT, which lives on one device)."""
+    import ctypes
+    import threading
+
+    from timemachine_amd.csrc import build
+
+    lib = ctypes.CDLL(build.LIB)
+
+    def run(devices):
+        reset = ctypes.c_int(0)
+        assert lib.tm_debug_hold_api_lock(ctypes.c_int(-1), ctypes.byref(reset)) == 0  # (a negative duration resets the high-water mark)
+        seen = [0] * len(devices)
+        barrier = threading.Barrier(len(devices))
+
+        def worker(k):
+            assert lib.tm_debug_set_thread_lock_device(ctypes.c_int(devices[k])) == 0
+            barrier.wait()
+            out = ctypes.c_int(0)
+            assert lib.tm_debug_hold_api_lock(ctypes.c_int(150), ctypes.byref(out)) == 0
+            seen[k] = out.value
+            lib.tm_debug_set_thread_lock_device(ctypes.c_int(-1))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(devices))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return max(seen)
+
+    assert run([0, 1]) == 2  # two devices: both threads inside at once
+    assert run([3, 3]) == 1  # one device: one after the other
+    assert run([0, 1, 1]) == 2

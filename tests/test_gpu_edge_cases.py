@@ -673,3 +673,46 @@ def test_linear_triatomic_is_stable_in_f32(co, P):
     angles = [kahan_angle(x[0], x[1], x[2]) for x in xs]
     assert np.mean(angles) > 3.0, np.mean(angles)
     assert np.amax(np.abs(xs - 5.0)) < 15.0 and np.all(np.isfinite(xs))
+
+
+def test_two_contexts_driven_from_two_host_threads():
+    """Two MD contexts of one device stepped from two Python threads at once: the compiled binding releases the GIL around the call
+    and the C ABI's per-device lock keeps the two calls apart (objects are not thread-safe: cpp/src/potential.hpp:7), so both
+    trajectories are the ones the contexts take when stepped one after the other, bit for bit."""
+    import threading
+
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, custom_ops as co
+
+    co.set_device(0)
+    s = ts.small_solvated_ligand(lamb=0.3)
+
+    def make(seed):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.rbfe_bound_potentials(s, 20)]
+        return co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.5e-3, 1.0, s.masses, seed).impl(), bps)
+
+    ref = []
+    for seed in (5, 6):
+        c = make(seed)
+        c.multiple_steps(300, 0)
+        ref.append((c.get_x_t(), c.get_v_t()))
+    ctxts = [make(5), make(6)]
+    errors = []
+
+    def worker(c):
+        try:
+            co.set_device(0)
+            for _ in range(3):
+                c.multiple_steps(100, 0)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(c,)) for c in ctxts]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for c, (x, v) in zip(ctxts, ref):
+        np.testing.assert_array_equal(c.get_x_t(), x)
+        np.testing.assert_array_equal(c.get_v_t(), v)

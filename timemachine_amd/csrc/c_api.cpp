@@ -4,7 +4,10 @@
 #include "engine.hpp"
 #include "profiler.hpp"
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -47,14 +50,30 @@ static thread_local std::string g_last_error;
 // consumer that never imports the Python package gets the same behaviour as the Python binding (include/timemachine_amd.h).
 __attribute__((constructor)) static void tm_export_hw_queue_count() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
-// Threading contract of the C ABI: every entry point runs under ONE process-wide lock.  The objects behind the handles keep
-// host-side state between calls (pre-gathered inputs, piggy-backed tables, launch parities, uploaded plans) and the reference
-// never runs two of these calls at once either -- its pybind11 layer holds the GIL through every one of them.  The compiled
-// binding here releases the GIL around device calls (a Python thread doing I/O keeps running); this lock is what keeps two
-// Python threads from entering the same Potential / Context meanwhile.  Recursive: entry points call each other.
-static std::recursive_mutex g_api_mutex;
+// Threading contract of the C ABI: every entry point runs under the lock of the calling thread's CURRENT DEVICE.  The objects
+// behind the handles keep host-side state between calls (pre-gathered inputs, piggy-backed tables, launch parities, uploaded plans)
+// and live on one device; the reference's own contract is per object ("*Not* guaranteed to be thread-safe", cpp/src/potential.hpp:7)
+// and its pybind11 layer holds the GIL through every call.  The compiled binding here releases the GIL around device calls, so
+// this lock is what keeps two host threads from entering the same Potential / Context meanwhile -- while a process that drives
+// SEVERAL GPUs from threads (one thread per device, hipSetDevice / tm_set_device in each) is not serialised across devices: a
+// tm_context_multiple_steps call on device 0 no longer holds up device 1 (round 5: one process-wide lock).  Objects of one device
+// must still not be entered from two threads at once -- which this lock enforces -- and a thread must have the object's device
+// current, as HIP itself demands.  Recursive: entry points call each other.
+static const int TM_MAX_LOCK_DEVICES = 64;
+static std::recursive_mutex g_api_mutex[TM_MAX_LOCK_DEVICES + 1]; // [TM_MAX_LOCK_DEVICES]: no device (host-only entry points on a box without one)
+static thread_local int g_lock_device_override = -1;               // tm_debug_set_thread_lock_device (CPU tests: no device to make current)
+static std::recursive_mutex &api_mutex() {
+    int dev = g_lock_device_override;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = TM_MAX_LOCK_DEVICES;
+        }
+    }
+    return g_api_mutex[(dev >= 0 && dev < TM_MAX_LOCK_DEVICES) ? dev : TM_MAX_LOCK_DEVICES];
+}
 #define TM_TRY                                                                                                         \
-    std::lock_guard<std::recursive_mutex> tm_api_lock_(g_api_mutex);                                                   \
+    std::lock_guard<std::recursive_mutex> tm_api_lock_(api_mutex());                                                   \
     try {
 #define TM_CATCH                                                                                                       \
     }                                                                                                                  \
@@ -945,6 +964,27 @@ int tm_debug_set_rowblock_min_k(int min_atoms, int *previous) {
     require(g_rowblock_built || min_atoms == std::numeric_limits<int>::max(),
             "the row-block kernel is not built into this library (load the variant libtimemachine_amd_rowblock.so: TM_AMD_LIB)");
     g_rowblock_min_k = min_atoms;
+    TM_CATCH
+}
+int tm_debug_set_thread_lock_device(int device) {
+    g_lock_device_override = device; // (no lock: it chooses the lock)
+    return TM_OK;
+}
+int tm_debug_hold_api_lock(int milliseconds, int *max_concurrent) {
+    static std::atomic<int> inside{0}, seen{0};
+    TM_TRY
+    const int now = ++inside;
+    int prev = seen.load();
+    while (now > prev && !seen.compare_exchange_weak(prev, now)) {
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(milliseconds));
+    --inside;
+    if (max_concurrent) {
+        *max_concurrent = seen.load();
+    }
+    if (milliseconds < 0) {
+        seen.store(0);
+    }
     TM_CATCH
 }
 int tm_debug_last_host_call_device_ms(double *ms) {

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <cmath>
 #include <iostream>
 
@@ -537,9 +538,17 @@ static void wait_for_stream(hipStream_t stream) {
         HIP_CHECK(hipStreamSynchronize(stream));
         return;
     }
+    // (one event per host thread AND device: an event belongs to the device that was current when it was made)
     static thread_local hipEvent_t ev = nullptr;
-    if (ev == nullptr) {
+    static thread_local int ev_device = -1;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (ev == nullptr || ev_device != dev) {
+        if (ev != nullptr) {
+            (void)hipEventDestroy(ev);
+        }
         HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ev_device = dev;
     }
     HIP_CHECK(hipEventRecord(ev, stream));
     for (int polls = 0;; polls++) {
@@ -765,8 +774,10 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
 // stepped on the null stream by one call and on a group stream by the next.
 static hipStream_t group_stream(const size_t k) {
     static std::map<int, std::vector<hipStream_t>> pools; // per device (a process that switches devices gets a pool on each)
+    static std::mutex pools_mutex;                        // (threads driving different devices hold different API locks)
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(pools_mutex);
     std::vector<hipStream_t> &pool = pools[dev];
     if (pool.empty()) {
         const char *e = std::getenv("TM_AMD_GROUP_STREAMS");

@@ -180,14 +180,16 @@ static unsigned int hilbert_index_3d(unsigned int c0, unsigned int c1, unsigned 
 }
 
 const std::vector<unsigned int> &HilbertSort::lut() {
-    static std::vector<unsigned int> table;
-    if (table.empty()) {
-        table.resize(HILBERT_GRID_DIM * HILBERT_GRID_DIM * HILBERT_GRID_DIM);
+    // (a function-local static with an initialiser: the first call is thread-safe -- constructors of potentials on different
+    // devices may run on different host threads at once, each under its own device's API lock)
+    static const std::vector<unsigned int> table = []() {
+        std::vector<unsigned int> t(HILBERT_GRID_DIM * HILBERT_GRID_DIM * HILBERT_GRID_DIM);
         for (int i = 0; i < HILBERT_GRID_DIM; i++)
             for (int j = 0; j < HILBERT_GRID_DIM; j++)
                 for (int k = 0; k < HILBERT_GRID_DIM; k++)
-                    table[(i * HILBERT_GRID_DIM + j) * HILBERT_GRID_DIM + k] = hilbert_index_3d(i, j, k, HILBERT_N_BITS);
-    }
+                    t[(i * HILBERT_GRID_DIM + j) * HILBERT_GRID_DIM + k] = hilbert_index_3d(i, j, k, HILBERT_N_BITS);
+        return t;
+    }();
     return table;
 }
 
