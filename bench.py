@@ -296,6 +296,14 @@ def find_all_pairs(bps):
     raise RuntimeError("no NonbondedAllPairs in the state")
 
 
+def find_all_pairs_of(impl):
+    """the NonbondedAllPairs inside one (unbound) potential implementation"""
+    for p in _walk(impl):
+        if type(p).__name__.startswith("NonbondedAllPairs"):
+            return p
+    raise RuntimeError("no NonbondedAllPairs in the potential")
+
+
 def find_nonbonded(bps):
     """the FanoutSummedPotential([AllPairs, Exclusions]) that Nonbonded.to_gpu builds"""
     for bp in bps:
@@ -1202,21 +1210,44 @@ def run_hrex(args, rank, local_rank, world, backend):
         def make_bps(p):
             return [bp.to_gpu(p).bound_impl for bp in ts.bound_potentials(system, p, nblist_padding=args.padding)]
 
+        # the reference's RBFE state composition (fe/system.py:133-146; testsystems.rbfe_shaped_state): windows differ in the interaction
+        # group's parameters (ligand rows); the energy matrix evaluates the state's two tile producers -- host-host Nonbonded +
+        # ligand-environment group, packed into one SummedPotential -- under the neighbouring windows' parameters
+        n_lig = N - system.num_water_atoms
+        rbfe_state = ts.rbfe_shaped_state(system, n_lig, nblist_padding=args.padding)
+        group_params_by_state = np.stack([np.asarray(rbfe_state[7][1], dtype=np.float64)] * n_states)
+        for k, lam in enumerate(lambdas):
+            group_params_by_state[k][lig, 3] = lam * system.cutoff
+            group_params_by_state[k][lig, 0] *= 1.0 - 0.5 * lam
+        host_params_flat = np.asarray(rbfe_state[6][1], dtype=np.float64).reshape(-1)
+        rbfe_matrix_params = np.stack([np.concatenate([host_params_flat, group_params_by_state[k].reshape(-1)]) for k in range(n_states)])
+
+        def make_rbfe_bps(p):
+            return [pot.bind(np.asarray(prm, dtype=np.float64)).to_gpu(p).bound_impl for pot, prm in rbfe_state]
+
         x0, v0 = equilibrate(co, LangevinIntegrator, system, make_bps, 99, args.equil_scale, np.float32)
     else:
         N = 31000
 
-    def measure(precision_name, barostat_interval, n_frames, warm_frames):
-        """one HREX measurement: this rank's resident replicas built afresh, warm-up frames, n_frames timed; -> (record fields, per_rank)"""
+    def measure(precision_name, barostat_interval, n_frames, warm_frames, composition="single_nonbonded"):
+        """one HREX measurement: this rank's resident replicas built afresh, warm-up frames, n_frames timed; -> (record fields, per_rank)
+        composition: "single_nonbonded" (the benchmark states' shape: one all-atom Nonbonded) or "rbfe" (HostGuestSystem)"""
         dh = hrex.DistributedHREX(n_states, TEMPERATURE, max_delta_states=args.max_delta_states, world_size=world, rank=rank)
         mine = dh.local_replicas
+        rbfe = composition == "rbfe" and not args.stub
+        state_params = None
         if not args.stub:
             prec = np.float64 if precision_name == "f64" else np.float32
-            unbound = P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff).to_gpu(prec).unbound_impl
+            if rbfe:
+                unbound = P.SummedPotential([rbfe_state[6][0], rbfe_state[7][0]], [rbfe_state[6][1], rbfe_state[7][1]]).to_gpu(prec).unbound_impl
+                state_params = rbfe_matrix_params
+            else:
+                unbound = P.Nonbonded(N, system.exclusion_idxs, system.scale_factors, system.beta, system.cutoff).to_gpu(prec).unbound_impl
+                state_params = params_by_state
             ctxts, bound_nb = [], []
             for r in mine:
-                bps = make_bps(prec)
-                bps[-1].set_params(params_by_state[r].reshape(-1))
+                bps = make_rbfe_bps(prec) if rbfe else make_bps(prec)
+                bps[-1].set_params((group_params_by_state if rbfe else params_by_state)[r].reshape(-1))
                 # the production shape (fe/rbfe.py:113-121,191-192; fe/free_energy.py:695-708): a barostat in every window's context
                 movers = [MonteCarloBarostat(N, 1.0, TEMPERATURE, ts.molecule_groups(system), barostat_interval, 700 + r).impl(bps)] if barostat_interval > 0 else []
                 ctxts.append(co.Context(x0, v0, system.box, LangevinIntegrator(TEMPERATURE, DT, FRICTION, system.masses, 500 + r).impl(), bps, movers=movers))
@@ -1239,13 +1270,13 @@ def run_hrex(args, rank, local_rank, world, backend):
             else:
                 coords = np.stack([c.get_x_t() for c in ctxts])
                 boxes = np.stack([c.get_box() for c in ctxts])  # (every window has its own box once a barostat is at work)
-                rows = hrex.compute_potential_matrix(unbound, coords, boxes, params_by_state, dh.replica_idx_by_state, args.max_delta_states, replicas=mine)
+                rows = hrex.compute_potential_matrix(unbound, coords, boxes, state_params, dh.replica_idx_by_state, args.max_delta_states, replicas=mine)
             t2 = time.perf_counter()
             new_states = dh.exchange(rows, seed=1000 + it)  # collective: one all_gather + the identical swap chain everywhere
             t3 = time.perf_counter()
             if not args.stub:
                 for i in range(len(mine)):
-                    bound_nb[i].set_params(params_by_state[new_states[i]].reshape(-1))
+                    bound_nb[i].set_params((group_params_by_state if rbfe else params_by_state)[new_states[i]].reshape(-1))
             t4 = time.perf_counter()
             if timed:
                 timers["md"] += t1 - t0
@@ -1308,7 +1339,16 @@ def run_hrex(args, rank, local_rank, world, backend):
             "gpu_max_hw_queues": None if args.stub else _runtime_env("GPU_MAX_HW_QUEUES"),
             "resident_replicas_rank0": len(mine),
             "swap_chains_identical_across_ranks": chains_identical,
+            "composition": composition,
         }
+        if rbfe:
+            nb0 = find_all_pairs(ctxts[0].get_potentials()) if ctxts else None
+            if nb0 is not None:
+                fields["merged_evaluations_replica0"] = nb0.get_merged_stats()[0]
+            fields["energy_memo_matrix_potential"] = dict(zip(("evaluations", "all_pairs_launch_skipped"), find_all_pairs_of(unbound).get_memo_stats()))
+            movers0 = ctxts[0].get_movers() if ctxts else []
+            if movers0:
+                fields["barostat_attempt_paths_replica0"] = dict(zip(("attempts", "on_current_list"), movers0[0].get_attempt_paths()))
         return fields, per_rank
 
     n_frames = max(args.steps // steps_per_frame, 1)
@@ -1316,9 +1356,10 @@ def run_hrex(args, rank, local_rank, world, backend):
     main_fields, per_rank = measure(args.precision, args.barostat_interval, n_frames, warm_frames)
     # the reference's PRODUCTION shape as a leg of the default line: f32 potentials, a Monte Carlo barostat every 25 steps in every
     # window (examples/run_rbfe_legs.py -> fe/rbfe.py:113-121,191-192; fe/free_energy.py:695-708), fewer frames
-    production = None
+    production = production_single = None
     if args.precision == "f64" and args.barostat_interval == 0 and not args.no_npt:
-        production, _ = measure("f32", 25, max(n_frames // 2, 1), 1)
+        production, _ = measure("f32", 25, max(n_frames // 2, 1), 1, composition="rbfe")
+        production_single, _ = measure("f32", 25, max(n_frames // 2, 1), 1)
     if rank != 0:
         return
     record = {
@@ -1356,9 +1397,15 @@ def run_hrex(args, rank, local_rank, world, backend):
         record["share_gpu_note"] = (f"REHEARSAL: all {world} ranks drive device 0 (gloo collectives); `value` is ONE GPU's aggregate over {world} concurrently "
                                     "working processes -- compare it with the one-process hrex line, not with an N-GPU figure")
     if production is not None:
-        production["note"] = ("the reference's production shape (examples/run_rbfe_legs.py: fe/rbfe.py:113-121,191-192, fe/free_energy.py:695-708): f32 potentials, a Monte "
-                              "Carlo barostat every 25 steps in every window, replicas stepped together; same windows, half the frames")
+        production["note"] = ("the reference's production shape (examples/run_rbfe_legs.py: fe/rbfe.py:113-121,191-192, fe/free_energy.py:695-708): every window a "
+                              "HostGuestSystem (fe/system.py:133-146: bonded terms, chiral restraints, ligand-ligand precomputed pairs, host-host "
+                              "Nonbonded(atom_idxs=host), ligand-environment NonbondedInteractionGroup), f32 potentials, a Monte Carlo barostat every 25 steps "
+                              "in every window, replicas stepped together; same windows, half the frames; the energy matrix evaluates the two tile producers "
+                              "of the state under the neighbouring windows' parameters (the host-host part once per frame: energy memo)")
         record["production_shape"] = production
+    if production_single is not None:
+        production_single["note"] = "the same ensemble on the BENCHMARK states' composition (one all-atom Nonbonded per window): rounds 4-5's production_shape"
+        record["production_shape_single_nonbonded"] = production_single
     emit_json(record)
 
 

@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     dd2b = FLAT ? fma_real(ez, ez, fma_real(ey, ey, ex * ex)) : pair_d2(ex, ey, ez, ddw);
                     if (dd2b < cutoff2) {
                         PairOut<Real> o2;
-                        nb_pair<true>(static_cast<Real>(1), static_cast<Real>(1), ri[4], cj[4], ri[5], cj[5], ri[6], cj[6], dd2b, beta, o2, es_tab);
+                        nb_pair<true, false>(static_cast<Real>(1), static_cast<Real>(1), ri[4], cj[4], ri[5], cj[5], ri[6], cj[6], dd2b, beta, o2, es_tab);
                         energy2 += float_to_fixed_energy_hot<Real>(o2.u);
                     }
                 }
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     TM_TB(5); // six LDS atomics issued and acknowledged
                 } else {
                 PairOut<Real> o;
-                nb_pair<COMPUTE_U || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
+                nb_pair<COMPUTE_U || COMPUTE_DU_DP, COMPUTE_DU_DX || COMPUTE_DU_DP>(static_cast<Real>(1), static_cast<Real>(1), qi, qj, sig_i, sig_j, eps_i, eps_j, dd2, beta, o, es_tab);
 #ifdef TM_TIMING_BATCH
                 asm volatile("" : "+v"(o.prefactor));
                 TM_TB(3); // (f32: analytic erfc / exp / switch, Lennard-Jones, prefactor)

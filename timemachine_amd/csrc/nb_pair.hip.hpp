@@ -336,12 +336,18 @@ __device__ __attribute__((noinline, cold)) double nb_pair_prefactor_below_table(
 //   prefactor = s_q q_i q_j F(d2) - s_lj eps_ij sig6 (48 sig6 - 24) / d2,   sig6 = (sig_ij^2 / d2)^3
 // WANT_U_DP = true adds, on top of the SAME prefactor arithmetic (so du/dx has the same bits whichever outputs are asked
 // for), the tabulated energy factor G(d2) for the energy and du/dq, and the LJ parameter derivatives.
-template <bool WANT_U_DP, typename Tab>
+// WANT_PREFACTOR = false (energy-only launches: barostat attempts, energy matrices): the force factor is not formed at all -- its
+// table fetch sits behind a wave-wide ballot and a call (the below-the-table escape), which the compiler must keep even when
+// nobody reads the result; o.prefactor is then 0.  The energy's own arithmetic is untouched: the same bits.
+template <bool WANT_U_DP, bool WANT_PREFACTOR = true, typename Tab>
 __device__ __forceinline__ void nb_pair(
     double charge_scale, double lj_scale, double qi, double qj, double sig_i, double sig_j, double eps_i, double eps_j, double d2ij,
     double beta, PairOut<double> &o, const Tab &tab) {
     const double qij = qi * qj;
-    const double es_prefactor = charge_scale * qij * es_force_factor(beta, d2ij, tab);
+    double es_prefactor = 0;
+    if constexpr (WANT_PREFACTOR) {
+        es_prefactor = charge_scale * qij * es_force_factor(beta, d2ij, tab);
+    }
     const double inv_d2ij = tm_rcp_f64(d2ij);
     double prefactor = es_prefactor;
     double u = 0;
@@ -356,8 +362,10 @@ __device__ __forceinline__ void nb_pair(
         const double sig2 = (sig_ij * sig_ij) * inv_d2ij;
         const double sig4 = sig2 * sig2;
         const double sig6 = sig4 * sig2;
-        const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24);
-        prefactor -= lj_prefactor;
+        if constexpr (WANT_PREFACTOR) {
+            const double lj_prefactor = lj_scale * eps_ij * (sig6 * inv_d2ij) * (sig6 * 48 - 24);
+            prefactor -= lj_prefactor;
+        }
         if constexpr (WANT_U_DP) {
             u = lj_scale * 4 * eps_ij * (sig6 - 1) * sig6;
             o.sig_grad = lj_scale * 24 * eps_ij * (sig_ij * sig4 * inv_d2ij) * (2 * sig6 - 1);
@@ -375,7 +383,7 @@ __device__ __forceinline__ void nb_pair(
     o.u = u;
 }
 // f32: the analytic pair function above, whatever is asked for (the table argument is an empty tag)
-template <bool WANT_U_DP, typename AnyTab>
+template <bool WANT_U_DP, bool WANT_PREFACTOR = true, typename AnyTab>
 __device__ __forceinline__ void nb_pair(
     float charge_scale, float lj_scale, float qi, float qj, float sig_i, float sig_j, float eps_i, float eps_j, float d2ij, float beta,
     PairOut<float> &o, const AnyTab &) {
