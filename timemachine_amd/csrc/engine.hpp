@@ -130,6 +130,10 @@ struct DeferredForces {
 };
 class ForcePlan {
 public:
+    ForcePlan() {}
+    ~ForcePlan();
+    ForcePlan(const ForcePlan &) = delete;
+    ForcePlan &operator=(const ForcePlan &) = delete;
     struct Rest {
         Potential *pot;
         int P;
@@ -171,6 +175,14 @@ private:
     FusedTable uploaded_[2];              // what d_table_ currently holds
     bool uploaded_valid_[2] = {false, false};
     DeviceBuffer<FusedTable> d_table_[2];
+    // Uploads leave the host through a ring of pinned copies (one per upload, an event behind each): a table changes whenever a
+    // caller walks parameter sets (execute_batch: every set is another d_p), and an upload that waited for the stream drained the
+    // launch queue once per evaluation (round 6: 63 -> see EXPERIMENTS.md us per further parameter set)
+    static const int TABLE_RING = 32;
+    FusedTable *h_ring_ = nullptr;
+    hipEvent_t ring_ev_[TABLE_RING];
+    bool ring_used_[TABLE_RING];
+    int ring_pos_ = 0;
     std::vector<Rest> rest_;
     bool cm_written_ = true;
     DeviceBuffer<i128> d_e_partials_[2]; // run_energy: per-wave sums of the table launches

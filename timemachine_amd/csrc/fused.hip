@@ -59,6 +59,15 @@ __global__ __launch_bounds__(256) void k_reduce_i128_sources(const EnergySources
     }
 }
 
+ForcePlan::~ForcePlan() {
+    if (h_ring_ != nullptr) {
+        for (int k = 0; k < TABLE_RING; k++) {
+            (void)hipEventDestroy(ring_ev_[k]);
+        }
+        (void)hipHostFree(h_ring_);
+    }
+}
+
 void ForcePlan::clear() {
     static const int window = std::getenv("TM_AMD_NO_FUSED_WINDOW") == nullptr ? 1 : 0;
     host_[0].n = 0;
@@ -99,12 +108,26 @@ void ForcePlan::upload_tables(bool pending[2], hipStream_t stream) {
         }
         if (!uploaded_valid_[prec] || std::memcmp(&uploaded_[prec], &t, sizeof(FusedTable)) != 0) {
             d_table_[prec].reserve(1);
-            // uploads happen only when the table changed (potentials added / re-bound), never on a plain MD step: copy
-            // from the snapshot, in stream order, and wait -- host_ is rewritten by the next clear()/add_segment, and
-            // whether an async copy from pageable memory has been staged by the time the call returns is not guaranteed
+            // never on a plain MD step (the table is the last step's); on every evaluation of a batch over parameter sets.  The copy
+            // leaves from a pinned slot of its own, in stream order, and nobody waits: host_ is rewritten by the next
+            // clear()/add_segment, the slot only when the ring comes round (its event says when the copy has been made)
+            if (h_ring_ == nullptr) {
+                HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_ring_), TABLE_RING * sizeof(FusedTable), hipHostMallocDefault));
+                for (int k = 0; k < TABLE_RING; k++) {
+                    HIP_CHECK(hipEventCreateWithFlags(&ring_ev_[k], hipEventDisableTiming));
+                    ring_used_[k] = false;
+                }
+            }
+            const int slot = ring_pos_;
+            ring_pos_ = (ring_pos_ + 1) % TABLE_RING;
+            if (ring_used_[slot]) {
+                HIP_CHECK(hipEventSynchronize(ring_ev_[slot]));
+            }
             std::memcpy(&uploaded_[prec], &t, sizeof(FusedTable));
-            HIP_CHECK(hipMemcpyAsync(d_table_[prec].data, &uploaded_[prec], sizeof(FusedTable), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            std::memcpy(&h_ring_[slot], &t, sizeof(FusedTable));
+            HIP_CHECK(hipMemcpyAsync(d_table_[prec].data, &h_ring_[slot], sizeof(FusedTable), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipEventRecord(ring_ev_[slot], stream));
+            ring_used_[slot] = true;
             uploaded_valid_[prec] = true;
         }
     }
