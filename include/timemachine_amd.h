@@ -148,6 +148,11 @@ int tm_nonbonded_all_pairs_get_merged_stats(tm_potential_t pot, long long *calls
  * kernel prologue (csrc/engine.hpp: EnergyMemo; tm_debug_set_energy_memo).  *evaluations = such evaluations since construction (the
  * potential's own and its merged carrier's), *skipped = those whose all-pairs launch was empty. */
 int tm_nonbonded_all_pairs_get_memo_stats(tm_potential_t pot, long long *evaluations, long long *skipped);
+/* diagnostic: evaluations (of the potential and of its merged carrier) that launched no neighbor-list kernel because the batch entry
+ * point vouched that coordinates and box were the previous evaluation's (tm_potential_execute_batch* walking the parameter sets of one
+ * frame; the reference orders its loops the same way, wrap_kernels.cpp:997-1001) -- csrc/engine.hpp: Potential::hint_same_frame;
+ * tm_debug_set_same_frame_hint is the A/B switch. */
+int tm_nonbonded_all_pairs_get_same_frame_skips(tm_potential_t pot, long long *skips);
 /* per-wave cycle counters of the last tile-kernel launch: [waves][8] = {setup, phase1, phase2, flush, items, batches, total, 0};
  * all zero unless the library was built with -DTM_TIMING (development aid, see scripts/ablate.py) */
 int tm_nonbonded_all_pairs_debug_timing(tm_potential_t pot, long long *out, int cap, int *n);
@@ -343,6 +348,9 @@ int tm_debug_last_host_call_device_ms(double *ms);
 /* debugging / A-B aid: the energy memo (tm_nonbonded_all_pairs_get_memo_stats) on / off; process-wide (TM_AMD_NO_ENERGY_MEMO in the
  * environment sets the initial value to 0); *previous (may be NULL) receives the old value.  Energies are bit-identical either way. */
 int tm_debug_set_energy_memo(int enabled, int *previous);
+/* debugging / A-B aid: the same-frame hint of the batch entry points (tm_nonbonded_all_pairs_get_same_frame_skips) on / off;
+ * process-wide; *previous (may be NULL) receives the old value.  Results are bit-identical either way. */
+int tm_debug_set_same_frame_hint(int enabled, int *previous);
 /* debugging / A-B aid: forces-only and energy-only plans (MD steps, barostat attempts, Summed / Fanout energy calls) run an all-pairs
  * potential and an interaction group whose columns are exactly its atoms as ONE pipeline (see tm_nonbonded_all_pairs_get_merged_stats);
  * 0 = each keeps its own list, launch and hand-over (rounds 1-5).  Process-wide (TM_AMD_NO_MERGE in the environment sets the initial

@@ -1,4 +1,2 @@
 set -u
-R=$GRAFT_REPO_ROOT
-for a in "dhfr f64 same" "dhfr f32 same" "config5 f64 same" "config5 f64 windows" "config5 f32 windows"; do python scripts/further_sets_probe.py $a 2>&1 | grep -v amdgpu.ids; done
-bash scripts/gpu_stats_cmd.sh s2fs1 12 python $R/scripts/further_sets_probe.py dhfr f64 same
+(time timeout 900 python -m pytest tests/test_gpu_rbfe_composition.py tests/test_gpu_potentials_surface.py tests/test_gpu_second_binding.py -m gpu -x -q) 2>&1 | tail -15

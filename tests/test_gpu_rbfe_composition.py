@@ -549,3 +549,63 @@ def test_hrex_energy_rows_with_the_memo_equal_rows_without(co, P):
             co.debug_set_energy_memo(before)
     np.testing.assert_array_equal(rows[True], rows[False])
     assert evals == np.isfinite(rows[True]).sum() and skipped == evals - n_states, (evals, skipped)  # one all-pairs launch per frame
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("which,static_k", [("config2", 4608), ("config2", 0), ("config4", 0)])
+def test_batches_over_parameter_sets_skip_the_list_kernels_and_keep_their_bits(co, P, which, static_k, precision):
+    """execute_batch / execute_batch_sparse walk the parameter sets of one frame back to back (the reference orders its loops the same
+    way, wrap_kernels.cpp:997-1001) and say so to their stateful children (csrc/engine.hpp: Potential::hint_same_frame): from a frame's
+    second evaluation on no neighbor-list kernel is launched -- in every output form, whether or not the frame before needed a
+    rebuild.  Frames far enough apart that every new frame rebuilds, parameter sets that differ in the ligand and in the host: the
+    batch's integers equal those of the same batch with the hint ignored, entry by entry, and the skips are counted."""
+    from timemachine_amd import testsystems as ts
+
+    s, n_lig = _system(which)
+    N = s.num_atoms
+    state = ts.rbfe_shaped_state(s, n_lig, env_charge_scale=0.9)
+    rng = np.random.default_rng(21)
+    # (every frame a rigid 0.1 nm further along x than the one before: beyond padding / 2 for every atom, so every new frame rebuilds)
+    frames = np.stack([s.coords + rng.normal(0.0, 0.002, s.coords.shape) + np.array([0.1 * k, 0.0, 0.0]) for k in range(4)])
+    boxes = np.stack([s.box, s.box, s.box * 1.002, s.box])
+    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
+    off_group = flat.size - 4 * N
+    sets = np.stack([flat] * 4)
+    for k in range(4):
+        g = sets[k][off_group:].reshape(-1, 4)
+        g[N - n_lig :, 0] *= 1.0 - 0.1 * k
+        g[N - n_lig :, 3] = 0.1 * k * s.cutoff
+    sets[3][off_group - 4 * N : off_group].reshape(-1, 4)[:, 0] *= 0.98  # the host's charges too
+    ci = np.array([2, 0, 0, 1, 3, 3, 1, 0], dtype=np.uint32)
+    pi = np.array([0, 1, 2, 3, 0, 1, 2, 3], dtype=np.uint32)
+    summed = P.SummedPotential([p for p, _ in state], [q for _, q in state])
+    forms = [(False, False, True), (True, False, False), (True, True, True)]
+
+    def run(hint):
+        before = co.debug_set_same_frame_hint(hint)
+        try:
+            impl = summed.to_gpu(precision).unbound_impl
+            out = []
+            for f in forms:
+                out.append(impl.execute_batch(frames, sets, boxes, *f))
+                out.append(impl.execute_batch_sparse(frames, sets, boxes, ci, pi, *f))
+            return out, _all_pairs_of(impl).get_same_frame_skips()
+        finally:
+            co.debug_set_same_frame_hint(before)
+
+    with _Switches(co, merge=True, static_k=static_k):
+        with_hint, skips = run(True)
+        without, skips_off = run(False)
+    for a, b in zip(with_hint, without):
+        for x, y in zip(a, b):
+            if x is None:
+                assert y is None
+            else:
+                np.testing.assert_array_equal(x, y)
+    assert skips_off == 0
+    if static_k == 0:  # (a static complete list launches no list kernel in the first place)
+        # dense: 3 of 4 sets per frame x 4 frames; sparse: entries that share their frame with the entry before (sorted by frame): 4 of 8;
+        # in the energy-only and the forces-only form the host-host potential's carrier is what is evaluated; the full form evaluates the two potentials
+        assert skips >= 2 * (12 + 4), skips
+    energies = with_hint[0][2]
+    assert len(np.unique(energies)) == energies.size  # every (frame, set) pair is a different evaluation

@@ -417,6 +417,12 @@ int tm_nonbonded_all_pairs_get_memo_stats(tm_potential_t pot, long long *evaluat
     TM_CATCH
 }
 
+int tm_nonbonded_all_pairs_get_same_frame_skips(tm_potential_t pot, long long *skips) {
+    TM_TRY
+    with_all_pairs(pot, [&](auto &p) { *skips = p.same_frame_skips(); });
+    TM_CATCH
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int tm_potential_execute(
     tm_potential_t pot, int N, int P, const double *coords, const double *params, const double *box, uint64_t *du_dx, uint64_t *du_dp,
@@ -990,6 +996,14 @@ int tm_debug_hold_api_lock(int milliseconds, int *max_concurrent) {
 int tm_debug_last_host_call_device_ms(double *ms) {
     TM_TRY
     *ms = g_last_host_call_device_ms;
+    TM_CATCH
+}
+int tm_debug_set_same_frame_hint(int enabled, int *previous) {
+    TM_TRY
+    if (previous) {
+        *previous = g_same_frame_hint ? 1 : 0;
+    }
+    g_same_frame_hint = enabled != 0;
     TM_CATCH
 }
 int tm_debug_set_energy_memo(int enabled, int *previous) {

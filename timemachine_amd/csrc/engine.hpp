@@ -54,14 +54,14 @@ static const int NB_NUM_COUNTERS = NB_COUNTER_GUEST + 1;
 struct EnergyMemo {
     int changed_main; // a record that the all-pairs items read was rewritten with other values since the cached sum was made
     int valid;        // cached_main belongs to the records as they are (but for changed_main)
-    int ran_main;     // this evaluation's decision (k_memo_select)
-    int reserved_;
+    int reserved_[2];
     double box[9];    // the box of the cached sum
     long long evaluations, skipped; // diagnostics: memo evaluations since construction, of which the all-pairs launch was empty
     i128 cached_main;
-    unsigned int main_counts[NB_SHARDS * NB_CLASSES];  // what the main launch reads as its item counts: the list's own, or zeros
-    unsigned int second_counts[NB_SHARDS * NB_CLASSES]; // ... and the second launch (the guest rows' items, all in bucket 0)
 };
+// words of zeros kept behind a list's counters: the second launch of a memo evaluation reads its 64 "bucket counts" from
+// counters + NB_COUNTER_GUEST on (bucket 0 = the guest rows' list, every other bucket empty)
+static const int NB_COUNTERS_ALLOC = NB_NUM_COUNTERS + NB_SHARDS * NB_CLASSES;
 struct FusedSegment {
     int kind;
     int count;            // terms
@@ -247,11 +247,17 @@ public:
     virtual void drop_piggybacks() {}
     // Energy-only evaluation that leaves per-wave partial sums (to be added up by the caller) in a buffer of the potential's
     // own instead of reducing them into a d_u -- saves a launch per evaluation.  false = not supported (nothing was run).
+    // d_final != nullptr: the caller has nothing else to add -- an implementation that ends in a launch of its own anyway may put the
+    // TOTAL straight into d_final[0] and report count == -1 (no partials, no reduction by the caller).
     virtual bool execute_energy_partials(
         const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials,
-        int &count) {
+        int &count, i128 *d_final = nullptr) {
         return false;
     }
+    // The caller vouches that the coordinates and the box behind the pointers of the NEXT call hold what they held at the last one
+    // (execute_batch walking the parameter sets of one frame): stateful children may skip what only coordinates can invalidate.
+    // One call only; any other use clears it.
+    virtual void hint_same_frame() {}
 
     // The consumer of DeferredForces has enqueued (on the same stream) a kernel that filled `next` for the coordinates
     // in d_x / d_box: the following execute_forces_deferred call with the same pointers may skip its gather.
@@ -367,6 +373,11 @@ public:
             pot->expect_box_scaling();
         }
     }
+    void hint_same_frame() override {
+        for (auto &pot : potentials_) {
+            pot->hint_same_frame();
+        }
+    }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
     void du_dp_fixed_to_float(const int N, const int P, const u64 *du_dp, double *du_dp_float) override;
     void du_dp_nonbonded_spans(const int N, const int P, const int offset, std::vector<DuDpSpan> &out) const override {
@@ -401,6 +412,11 @@ public:
     void expect_box_scaling() override {
         for (auto &pot : potentials_) {
             pot->expect_box_scaling();
+        }
+    }
+    void hint_same_frame() override {
+        for (auto &pot : potentials_) {
+            pot->hint_same_frame();
         }
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
@@ -599,6 +615,7 @@ private:
 void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool allow_empty = false);
 
 extern double g_last_host_call_device_ms; // potential.hip: device time of the evaluations of the last execute_host_f64 call
+extern bool g_same_frame_hint; // the batch entry points' hint_same_frame() is honoured (tm_debug_set_same_frame_hint)
 extern bool g_energy_memo;     // energy-only evaluations are remembered on the device (EnergyMemo; tm_debug_set_energy_memo)
 extern bool g_merge_producers; // ForcePlan::merge_producers runs all-pairs + interaction group as one pipeline (tm_debug_set_merge_producers)
 extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)
@@ -692,7 +709,8 @@ public:
         piggyback_energy_blocks_ = 0;
     }
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
-    bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count) override;
+    bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count, i128 *d_final = nullptr) override;
+    void hint_same_frame() override { same_frame_hint_ = true; }
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     bool probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) override;
     ProbeTarget probe_begin() override;
@@ -701,6 +719,7 @@ public:
     void probe_list_launch(hipStream_t stream);
     void invalidate_cached_inputs() override {
         pre_valid_ = false;
+        last_x_ = last_box_ = nullptr;
         inputs_epoch_++;
         if (merged_) {
             merged_->invalidate_cached_inputs();
@@ -718,6 +737,7 @@ public:
     // diagnostics (tests assert which path ran): force / energy evaluations this potential made as a merged carrier's host
     // diagnostic: {memo evaluations made, of which the device skipped the all-pairs launch} -- reads the device
     void memo_stats(long long *evaluations, long long *skipped);
+    long long same_frame_skips() const { return same_frame_skips_ + (merged_ ? merged_->same_frame_skips_ : 0); }
     void merged_stats(long long *calls, unsigned int *tiles, unsigned int *builds) {
         *calls = merged_ ? merged_->pipeline_calls_ : 0;
         *tiles = merged_ ? merged_->num_tile_ixns() : 0;
@@ -766,6 +786,11 @@ protected:
     DeviceBuffer<EnergyMemo> d_memo_;
     DeviceBuffer<i128> d_u_partials_b_; // the second launch of a memo evaluation (guest rows' items + the plan's table)
     bool memo_chain_ = false;           // the last pipeline call was a memo evaluation: the device's memo describes the records
+    i128 *memo_final_ = nullptr;        // execute_energy_partials: where the coming memo evaluation may leave its total
+    bool same_frame_hint_ = false;      // hint_same_frame(): taken by the next evaluation entry point ...
+    bool same_frame_now_ = false;       // ... for its run_pipeline
+    long long same_frame_skips_ = 0;    // diagnostic: evaluations that launched no list kernel on the strength of the hint
+    const double *last_x_ = nullptr, *last_box_ = nullptr; // the last run_pipeline's coordinate / box pointers (nullptr: its state was touched since)
     long long memo_skips_ = 0;          // (host-side count of memo evaluations; what the device decided is in d_memo_)
     const char *name_ = "NonbondedAllPairs"; // class name used in error messages
     int steps_per_sort_;

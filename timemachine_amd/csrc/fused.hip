@@ -239,7 +239,12 @@ void ForcePlan::run_energy(const int N, const double *d_x, const double *d_box, 
         if (carrier) {
             carriers_left--;
         }
-        if (!shared && room && r.pot->execute_energy_partials(N, r.P, d_x, r.d_p, d_box, stream, partials, count)) {
+        // the only contributor (every table rode along with it): it may leave the total in d_u itself
+        i128 *d_final = (n_rest == 1 && src.n == 0 && !pending[0] && !pending[1]) ? d_u : nullptr;
+        if (!shared && room && r.pot->execute_energy_partials(N, r.P, d_x, r.d_p, d_box, stream, partials, count, d_final)) {
+            if (count == -1) {
+                return; // (d_u[0] is written: nothing to add up)
+            }
             if (count > 0) {
                 src.p[src.n] = partials;
                 src.count[src.n] = count;

@@ -674,29 +674,25 @@ __device__ __forceinline__ void rebase_snapshot_box(const double *__restrict__ b
 }
 
 // ---- energy-only evaluations remembered (EnergyMemo, engine.hpp) ---------------------------------------------
-// After the check + gather kernel (which noted whether an all-pairs operand changed) and the list kernels (which may have rebuilt):
-// decide whether the all-pairs launch of this evaluation has work, and hand both launches their item counts.  One wave.
-static __global__ __launch_bounds__(64) void k_memo_select(EnergyMemo *__restrict__ memo, const int trust, const double *__restrict__ box, const unsigned int *__restrict__ counters) {
-    const int lane = threadIdx.x;
+// After the check + gather kernel (which noted whether an all-pairs operand changed): does the all-pairs launch of this evaluation have
+// the operands, the box and the order of the remembered sum?  `trust`: the host's word that the memo describes the records (the
+// previous call into the pipeline was a memo evaluation too).  Asked by every wave of that launch (which then leaves at once) and,
+// with the same answer -- nothing writes the memo in between -- by k_memo_finish.
+__device__ __forceinline__ bool memo_skips_main(const EnergyMemo *__restrict__ memo, const int trust, const double *__restrict__ box) {
     bool same_box = true;
     for (int k = 0; k < 9; k++) {
         same_box = same_box && memo->box[k] == box[k];
     }
-    const bool run_main = !(trust && memo->valid && !memo->changed_main && same_box);
-    memo->main_counts[lane] = run_main ? counters[NB_COUNTER_CLASS0 + lane] : 0u;
-    memo->second_counts[lane] = lane == 0 ? counters[NB_COUNTER_GUEST] : 0u; // bucket (shard 0, class 0) = position 0 of the guest list
-    if (lane == 0) {
-        memo->ran_main = run_main ? 1 : 0;
-    }
+    return trust && memo->valid && !memo->changed_main && same_box;
 }
-// ... and afterwards: the evaluation's total = (this launch's sum, or the remembered one) + the second launch's sum; the memo takes the
-// all-pairs sum over.  One workgroup.
+// ... and afterwards: the evaluation's total = (the all-pairs launch's sum, or the remembered one) + the second launch's sum; the memo
+// takes the all-pairs sum over.  One workgroup.
 static __global__ __launch_bounds__(256) void k_memo_finish(
-    EnergyMemo *__restrict__ memo, const double *__restrict__ box, const i128 *__restrict__ partials_main, const int n_main, const i128 *__restrict__ partials_second,
-    const int n_second, i128 *__restrict__ out) {
+    EnergyMemo *__restrict__ memo, const int trust, const double *__restrict__ box, const i128 *__restrict__ partials_main, const int n_main,
+    const i128 *__restrict__ partials_second, const int n_second, i128 *__restrict__ out) {
     __shared__ i128 s_part[2][4];
     i128 a = 0, b = 0;
-    const bool ran = memo->ran_main != 0;
+    const bool ran = !memo_skips_main(memo, trust, box);
     if (ran) {
         for (int i = threadIdx.x; i < n_main; i += 256) {
             a += partials_main[i];
@@ -711,7 +707,7 @@ static __global__ __launch_bounds__(256) void k_memo_finish(
         s_part[0][threadIdx.x >> 6] = a;
         s_part[1][threadIdx.x >> 6] = b;
     }
-    __syncthreads();
+    __syncthreads(); // (every thread has read the memo by now: thread 0 may rewrite it)
     if (threadIdx.x == 0) {
         const i128 main_sum = ran ? s_part[0][0] + s_part[0][1] + s_part[0][2] + s_part[0][3] : memo->cached_main;
         out[0] = main_sum + s_part[1][0] + s_part[1][1] + s_part[1][2] + s_part[1][3];
@@ -814,8 +810,15 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
     // DUAL launches only (nullptr / 0 otherwise): the second geometry's sorted records, box, atom-order coordinates (for the
     // piggy-backed table) and partial sums; per-block maxima of |atom - own centroid|^2 from the kernel that made the proposal
     const Real *__restrict__ gathered2 = nullptr, const double *__restrict__ box2 = nullptr, const double *__restrict__ coords2 = nullptr,
-    i128 *__restrict__ u_partials2 = nullptr, const float *__restrict__ r2_blocks = nullptr, const int n_r2_blocks = 0) {
+    i128 *__restrict__ u_partials2 = nullptr, const float *__restrict__ r2_blocks = nullptr, const int n_r2_blocks = 0,
+    // energy-only launches of a remembered evaluation (EnergyMemo; nullptr otherwise): the launch has no work if memo_skips_main says so
+    const EnergyMemo *__restrict__ gate = nullptr, const int gate_trust = 0) {
     static_assert(!DUAL || (COMPUTE_U && !COMPUTE_DU_DX && !COMPUTE_DU_DP), "DUAL is an energy-only form");
+    if constexpr (COMPUTE_U && !COMPUTE_DU_DX && !COMPUTE_DU_DP && !DUAL) {
+        if (gate != nullptr && memo_skips_main(gate, gate_trust, box)) {
+            return; // (grid-uniform; k_memo_finish takes the remembered sum and does not read this launch's partials)
+        }
+    }
 
     constexpr int WAVES = TileShape<Real, tile_wide<Real, COMPUTE_U, COMPUTE_DU_DX, COMPUTE_DU_DP, DUAL>()>::waves;
     struct WaveLds { // one wave's private scratch

@@ -298,8 +298,8 @@ Neighborlist<Real>::Neighborlist(const int N) : max_size_(N), N_(N), NC_(N), NR_
     d_row_ext_.realloc(nb * 3);
     d_row_idxs_.realloc(N);
     d_col_idxs_.realloc(N);
-    d_counters_.realloc(NB_NUM_COUNTERS);
-    HIP_CHECK(hipMemset(d_counters_.data, 0, NB_NUM_COUNTERS * sizeof(unsigned int)));
+    d_counters_.realloc(NB_COUNTERS_ALLOC); // (the words behind NB_NUM_COUNTERS stay zero for good: engine.hpp)
+    HIP_CHECK(hipMemset(d_counters_.data, 0, NB_COUNTERS_ALLOC * sizeof(unsigned int)));
     // Pool sized for the worst case: every block pair interacting.  Row subsets need rows x cols <= (nb/2)^2 block
     // pairs, always below the upper-triangular count used by the reference (neighborlist.cu:368-376).
     const size_t max_block_pairs = static_cast<size_t>(nb) * (nb + 1) / 2;
@@ -656,6 +656,7 @@ template <typename Real> void NonbondedAllPairs<Real>::set_atom_idxs(const std::
     idxs_version_++;
     calls_since_sort_ = 0; // next call sorts (and therefore rebuilds)
     force_rebuild_ = true;
+    last_x_ = last_box_ = nullptr;
 }
 
 template <typename Real>
@@ -686,6 +687,9 @@ template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const Fu
     piggyback_energy_blocks_ = blocks;
     return true;
 }
+
+// process-wide A/B switch (tm_debug_set_same_frame_hint): Potential::hint_same_frame is honoured
+bool g_same_frame_hint = true;
 
 // process-wide A/B switch (tm_debug_set_energy_memo, TM_AMD_NO_ENERGY_MEMO): energy-only evaluations are remembered on the device
 bool g_energy_memo = std::getenv("TM_AMD_NO_ENERGY_MEMO") == nullptr;
@@ -745,6 +749,10 @@ Potential *NonbondedAllPairs<Real>::merged_carrier(NonbondedAllPairsBase *group,
         merged_group_epoch_ = group->inputs_epoch();
     }
     merged_->guest_p_ = d_p_group;
+    if (same_frame_hint_) { // (the plan evaluates the carrier in this potential's place)
+        merged_->hint_same_frame();
+        same_frame_hint_ = false;
+    }
     merged_->box_scales_ = box_scales_ || group->expects_box_scaling();
     return merged_.get();
 }
@@ -776,6 +784,8 @@ template <typename Real>
 bool NonbondedAllPairs<Real>::execute_forces_deferred(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream,
     DeferredForces &out) {
+    same_frame_now_ = false; // (MD steps move the atoms)
+    same_frame_hint_ = false;
     this->check_sizes(N, P);
     if (empty_) {
         return false; // nothing to hand over; the caller falls back to execute_device (a no-op)
@@ -818,6 +828,7 @@ bool NonbondedAllPairs<Real>::execute_forces_deferred(
 template <typename Real> void NonbondedAllPairs<Real>::pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) {
     pre_valid_ = true;
     memo_chain_ = false; // (the consumer rewrote records: the device's energy memo no longer describes them)
+    last_x_ = last_box_ = nullptr;
     pre_sorted_ = sorted_bounds_done;
     pre_x_ = d_x;
     pre_box_ = d_box;
@@ -829,6 +840,8 @@ template <typename Real>
 void NonbondedAllPairs<Real>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
+    same_frame_now_ = same_frame_hint_; // (taken before anything can throw: a hint never outlives the call it was given for)
+    same_frame_hint_ = false;
     this->check_sizes(N, P);
     if (empty_) {
         return; // reference: nonbonded_interaction_group.cu:171-174 (outputs untouched, d_u left as the caller set it)
@@ -846,7 +859,9 @@ void NonbondedAllPairs<Real>::execute_device(
 template <typename Real>
 bool NonbondedAllPairs<Real>::execute_energy_partials(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials,
-    int &count) {
+    int &count, i128 *d_final) {
+    same_frame_now_ = same_frame_hint_;
+    same_frame_hint_ = false;
     this->check_sizes(N, P);
     if (empty_) {
         partials = d_u_partials_.data; // an interaction group without interactions: nothing to add
@@ -857,14 +872,20 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
     const bool pregathered = pre_valid_ && d_x == pre_x_ && d_p == pre_p_ && guest_p_ == pre_guest_p_ && d_box == pre_box_ && !force_rebuild_ &&
                              calls_since_sort_ % steps_per_sort_ != 0;
     defer_u_reduce_ = true;
+    memo_final_ = d_final;
     try {
         this->run_pipeline(d_x, d_p, d_box, nullptr, nullptr, d_u_partials_.data, true, stream, pregathered);
     } catch (...) {
         defer_u_reduce_ = false;
+        memo_final_ = nullptr;
         throw;
     }
     defer_u_reduce_ = false;
-    if (u_partials_count_ < 0) { // a memo evaluation: its total, one value (run_pipeline)
+    memo_final_ = nullptr;
+    if (u_partials_count_ < 0 && d_final != nullptr) { // a memo evaluation that left its total where the caller wants it
+        partials = nullptr;
+        count = -1;
+    } else if (u_partials_count_ < 0) { // a memo evaluation: its total, one value (run_pipeline)
         partials = d_u_partials_.data + grid_ - 1;
         count = 1;
     } else {
@@ -926,6 +947,7 @@ template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
     t.blk_ext = nblist_.d_col_ext();
     t.second_records = merged_mode_ ? K_ + 1 : 0;
     memo_chain_ = false; // (a commit rewrites records)
+    last_x_ = last_box_ = nullptr;
     probe_d_box_ = pre_box_;
     return t; // pre_valid_ / pre_sorted_ stay: the sorted records still describe (x, box), or -- after the commit -- (x', box')
 }
@@ -1039,6 +1061,11 @@ void NonbondedAllPairs<Real>::run_pipeline(
         d_u_partials_b_.realloc(grid_);
     }
     EnergyMemo *memo = memo_mode ? d_memo_.data : nullptr;
+    // the caller's word (hint_same_frame) that coordinates and box are the last call's, and this pipeline's own that nothing has touched
+    // its state since: whatever the list kernels could do they did a call ago
+    const bool same_frame = g_same_frame_hint && same_frame_now_ && last_x_ != nullptr && last_x_ == d_x && last_box_ == d_box && !pregathered;
+    same_frame_now_ = false;
+    last_x_ = last_box_ = nullptr; // (set again where this call ends)
     pre_valid_ = false; // consumed by this call or stale after it
     // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker
     // does that whenever it raises the rebuild flag, and the host cannot know): the list has to be rebuilt whatever the
@@ -1094,6 +1121,10 @@ void NonbondedAllPairs<Real>::run_pipeline(
     // (c) K2 + K3: rebuild iff forced or flagged (kernels exit immediately otherwise)
     if (static_list() && static_list_built_ && !force) {
         // the complete list of this order exists and nothing can invalidate it: no list kernel on this call
+    } else if (same_frame && !force) {
+        // the last call's coordinates in the last call's box: the check kernel cannot have raised the flag (either that call rebuilt --
+        // the snapshot is these coordinates -- or its test passed and passes again), bounds and counters stand: no list kernel either
+        same_frame_skips_++;
     } else {
         const bool bounds_done = pregathered && sorted_pending && !force; // (a forced build computes its own bounds and counters)
         const int prof_list = Profiler::get().begin("nblist_build", stream); // rebuilds AND the launches that only read the flag
@@ -1138,35 +1169,37 @@ void NonbondedAllPairs<Real>::run_pipeline(
     piggyback_table_ = nullptr;
     piggyback_blocks_ = 0;
     if (memo_mode) {
-        // (a) which launch has work: decided on the device; (b) the all-pairs items (guest rows' items emptied: bit 1 of the order flag);
-        // (c) the guest rows' items from their own list, with the plan's table riding -- skipped when there is neither; (d) the total
-        k_memo_select<<<1, 64, 0, stream>>>(memo, memo_trust ? 1 : 0, d_box, nblist_.d_counters());
-        HIP_CHECK(hipGetLastError());
+        // (a) the all-pairs items (guest rows' items emptied: bit 1 of the order flag) -- every wave of that launch decides for itself
+        // whether there is work (memo_skips_main) and leaves at once if not; (b) the guest rows' items from their own list (its "bucket
+        // counts": the guest counter and the zeros behind it), with the plan's table riding -- skipped when there is neither; (c) the total
         const int split_m = K_ <= TM_SPLIT4_MAX_K ? 4 : (K_ <= (sizeof(Real) == 8 ? TM_SPLIT2_MAX_K_F64 : TM_SPLIT2_MAX_K_F32) ? 2 : 1);
         using MemoShape = TileShape<Real, tile_wide<Real, true, false, false, false>()>;
         const int n_wg = n_cus * MemoShape::wgs_per_cu;
-#define TM_LAUNCH_MEMO(COUNTS, CAP, ITEMS, ORDER, OUT, TABLE, TBLOCKS, ...)                                            \
+#define TM_LAUNCH_MEMO(COUNTS, CAP, ITEMS, ORDER, OUT, TABLE, TBLOCKS, GATE, ...)                                      \
     k_nonbonded_tiles<Real, true, false, false, ##__VA_ARGS__><<<n_wg, 64 * MemoShape::waves, 0, stream>>>(               \
         K_, nblist_.get_num_row_idxs(), ORDER, nullptr, COUNTS, CAP, ITEMS, nblist_.d_col_atoms(), d_gathered_.data, d_box, beta_, cutoff_, \
-        d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, OUT, TABLE, TBLOCKS, d_x, nullptr, 3, 1, nullptr, d_timing_.data)
+        d_es_table_, d_g_du_dx_.data, d_g_du_dp_.data, acc_stride_, OUT, TABLE, TBLOCKS, d_x, nullptr, 3, 1, nullptr, d_timing_.data, \
+        nullptr, nullptr, nullptr, nullptr, nullptr, 0, GATE, memo_trust ? 1 : 0)
         const int prof_m = Profiler::get().begin("nonbonded_tiles", stream);
         const int order_main = (nblist_.upper_triangular() ? 1 : 0) | (merged_mode_ ? 2 : 0);
+        const unsigned int *main_counts = nblist_.d_counters() + NB_COUNTER_CLASS0;
         if (split_m == 4) {
-            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, false, 4);
+            TM_LAUNCH_MEMO(main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, memo, false, 4);
         } else if (split_m == 2) {
-            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, false, 2);
+            TM_LAUNCH_MEMO(main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, memo, false, 2);
         } else {
-            TM_LAUNCH_MEMO(memo->main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0);
+            TM_LAUNCH_MEMO(main_counts, nblist_.items_cap(), nblist_.d_items(), order_main, d_u_partials_.data, nullptr, 0, memo);
         }
         const bool second = merged_mode_ || pig_table != nullptr;
         if (second) {
-            TM_LAUNCH_MEMO(memo->second_counts, nblist_.guest_items_cap(), nblist_.d_guest_items(), 1, d_u_partials_b_.data, pig_table, pig_blocks);
+            TM_LAUNCH_MEMO(nblist_.d_counters() + NB_COUNTER_GUEST, nblist_.guest_items_cap(), nblist_.d_guest_items(), 1, d_u_partials_b_.data, pig_table, pig_blocks, nullptr);
         }
 #undef TM_LAUNCH_MEMO
         Profiler::get().end("nonbonded_tiles", prof_m, stream);
         HIP_CHECK(hipGetLastError());
-        i128 *total = defer_u_reduce_ ? d_u_partials_.data + grid_ - 1 : d_u; // (deferred: the caller reads ONE value from the end of the partials)
-        k_memo_finish<<<1, 256, 0, stream>>>(memo, d_box, d_u_partials_.data, n_wg, d_u_partials_b_.data, second ? n_wg : 0, total);
+        // (deferred: the caller reads ONE value -- from the end of the partials, or where it asked for the total)
+        i128 *total = defer_u_reduce_ ? (memo_final_ != nullptr ? memo_final_ : d_u_partials_.data + grid_ - 1) : d_u;
+        k_memo_finish<<<1, 256, 0, stream>>>(memo, memo_trust ? 1 : 0, d_box, d_u_partials_.data, n_wg, d_u_partials_b_.data, second ? n_wg : 0, total);
         HIP_CHECK(hipGetLastError());
         if (defer_u_reduce_) {
             u_partials_count_ = -1; // marks "one value at d_u_partials_ + grid_ - 1" for execute_energy_partials
@@ -1176,6 +1209,8 @@ void NonbondedAllPairs<Real>::run_pipeline(
         force_rebuild_ = false;
         memo_chain_ = true;
         memo_skips_++;
+        last_x_ = d_x;
+        last_box_ = d_box;
         return;
     }
     const int prof = Profiler::get().begin("nonbonded_tiles", stream);
@@ -1272,6 +1307,8 @@ void NonbondedAllPairs<Real>::run_pipeline(
     calls_since_sort_++;
     parity_ ^= 1;
     force_rebuild_ = false;
+    last_x_ = d_x;
+    last_box_ = d_box;
 }
 
 template <typename Real>

@@ -268,6 +268,9 @@ void Potential::execute_batch_device(
     for (int i = 0; i < coord_batch_size; i++) {
         for (int j = 0; j < param_batch_size; j++) {
             const size_t k = static_cast<size_t>(i) * param_batch_size + j;
+            if (j > 0) {
+                this->hint_same_frame(); // (the frame's coordinates and box sit where they sat a call ago, untouched)
+            }
             this->execute_device(
                 N, P, d_x + static_cast<size_t>(i) * N * D, P > 0 ? d_p + static_cast<size_t>(j) * P : nullptr, d_box + i * D * D,
                 d_du_dx ? d_du_dx + k * N * D : nullptr, d_du_dp ? d_du_dp + k * P : nullptr, d_u ? d_u + k : nullptr, stream);
@@ -284,8 +287,13 @@ void Potential::execute_batch_sparse_device(
     std::vector<int> order(batch_size);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return coords_batch_idxs[a] < coords_batch_idxs[b]; });
+    long long ic_last = -1;
     for (const int i : order) {
         const size_t ic = coords_batch_idxs[i], ip = params_batch_idxs[i];
+        if (static_cast<long long>(ic) == ic_last) {
+            this->hint_same_frame();
+        }
+        ic_last = static_cast<long long>(ic);
         this->execute_device(
             N, P, d_x + ic * N * D, P > 0 ? d_p + ip * P : nullptr, d_box + ic * D * D,
             d_du_dx ? d_du_dx + static_cast<size_t>(i) * N * D : nullptr, d_du_dp ? d_du_dp + static_cast<size_t>(i) * P : nullptr,

@@ -500,6 +500,11 @@ template <int PREC> void declare_potentials(py::module &m) {
                  check(tm_nonbonded_all_pairs_get_build_count(p.h, &n));
                  return n;
              })
+        .def("get_same_frame_skips", [](AllPairs &p) { // diagnostic: evaluations that launched no list kernel on the batch entry point's word
+            long long skips = 0;
+            check(tm_nonbonded_all_pairs_get_same_frame_skips(p.h, &skips));
+            return skips;
+        })
         .def("get_memo_stats", [](AllPairs &p) { // diagnostic: (energy-only evaluations remembered on the device, of which the all-pairs launch was empty)
             long long evals = 0, skipped = 0;
             check(tm_nonbonded_all_pairs_get_memo_stats(p.h, &evals, &skipped));
@@ -1112,6 +1117,14 @@ void declare_functions(py::module &m) {
         check(tm_debug_last_host_call_device_ms(&ms));
         return ms;
     });
+    m.def(
+        "debug_set_same_frame_hint",
+        [](const bool enabled) {
+            int previous = 0;
+            check(tm_debug_set_same_frame_hint(enabled ? 1 : 0, &previous));
+            return previous != 0;
+        },
+        py::arg("enabled"));
     m.def(
         "debug_set_energy_memo",
         [](const bool enabled) {

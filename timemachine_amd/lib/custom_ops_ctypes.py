@@ -495,6 +495,13 @@ def _all_pairs_get_build_count(self):
     return n.value
 
 
+def _all_pairs_get_same_frame_skips(self):
+    """diagnostic: evaluations that launched no list kernel on the batch entry point's word (same frame as the call before)"""
+    a = ctypes.c_longlong(0)
+    _check(_lib.tm_nonbonded_all_pairs_get_same_frame_skips(self._h, ctypes.byref(a)))
+    return a.value
+
+
 def _all_pairs_get_memo_stats(self):
     """diagnostic: (energy-only evaluations remembered on the device, of which the all-pairs launch was empty)"""
     a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
@@ -512,6 +519,7 @@ def _all_pairs_get_merged_stats(self):
 for _k in (NonbondedAllPairs_f32, NonbondedAllPairs_f64):
     _k.get_merged_stats = _all_pairs_get_merged_stats  # diagnostic (not in the reference surface)
     _k.get_memo_stats = _all_pairs_get_memo_stats  # diagnostic (not in the reference surface)
+    _k.get_same_frame_skips = _all_pairs_get_same_frame_skips
     _k.get_build_count = _all_pairs_get_build_count  # diagnostic (not in the reference surface)
     _k.debug_timing = _all_pairs_debug_timing
     _k.set_atom_idxs = _all_pairs_set_atom_idxs
@@ -1096,6 +1104,13 @@ def debug_last_host_call_device_ms():
     ms = ctypes.c_double(0.0)
     _check(_lib.tm_debug_last_host_call_device_ms(ctypes.byref(ms)))
     return ms.value
+
+
+def debug_set_same_frame_hint(enabled):
+    """A/B aid: the batch entry points' same-frame hint honoured (True) or ignored (False); -> the old value.  Bit-identical either way."""
+    prev = _c_int(0)
+    _check(_lib.tm_debug_set_same_frame_hint(_c_int(1 if enabled else 0), ctypes.byref(prev)))
+    return bool(prev.value)
 
 
 def debug_set_energy_memo(enabled):
