@@ -1,2 +1,2 @@
 set -u
-(time timeout 900 python -m pytest tests/test_gpu_rbfe_composition.py tests/test_gpu_potentials_surface.py tests/test_gpu_second_binding.py -m gpu -x -q) 2>&1 | tail -15
+(time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pregather_with_atom_subset") 2>&1 | tail -30

@@ -1067,13 +1067,18 @@ def test_pregathered_steps_are_bitwise_the_full_path(co, P, precision):
     assert not np.array_equal(changed.get_x_t(), ref2.get_x_t())
 
 
-def test_pregather_with_atom_subset_and_interaction_group(co, P):
+@pytest.mark.parametrize("precision", [np.float32, np.float64])
+@pytest.mark.parametrize("static_k,barostat,merge", [(None, False, True), (0, False, True), (0, True, True), (0, True, False), (None, True, True)])
+def test_pregather_with_atom_subset_and_interaction_group(co, P, precision, static_k, barostat, merge):
     """The integrator's hand-over with potentials that own only part of the atoms: an all-pairs potential over a subset
     (atoms outside it have no slot) next to an interaction group (rows | columns sorted separately) -- two producers of
-    deferred forces in one context.  Stepping in one go and re-setting the coordinates before every step (always the
-    full gather path) must agree bit for bit across two Hilbert re-sorts."""
+    deferred forces in one context, or, merged, one carrier that does not cover every atom (the update kernel's atom-order
+    form).  Stepping in one go and re-setting the coordinates before every step (always the full gather path) must agree
+    bit for bit across two Hilbert re-sorts: in both precisions, on the static complete list (the default at this size) and
+    on the listed pipeline, with a Monte Carlo barostat every 5 steps (reference-shaped attempts: the carrier does not
+    cover every atom, so its list cannot vouch for a proposal), producers merged and not."""
     from timemachine_amd import testsystems as ts
-    from timemachine_amd.lib import LangevinIntegrator
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
 
     s = _md_system()
     N = s.num_atoms
@@ -1084,6 +1089,7 @@ def test_pregather_with_atom_subset_and_interaction_group(co, P):
     subset = env[: (len(env) // 9) * 6]  # two thirds of the solvent (whole waters): the rest has no nonbonded partner at all
     in_subset = np.isin(s.exclusion_idxs, subset).all(axis=1)
     excl_idxs, excl_scales = s.exclusion_idxs[in_subset], s.scale_factors[in_subset]
+    groups = [list(range(3 * k, 3 * k + 3)) for k in range((N - 16) // 3)] + [list(range(N - 16, N))]
 
     def make():
         pots = [
@@ -1093,20 +1099,33 @@ def test_pregather_with_atom_subset_and_interaction_group(co, P):
             P.NonbondedInteractionGroup(N, ligand, s.beta, s.cutoff, col_atom_idxs=subset).bind(s.nb_params),
             P.NonbondedExclusions(excl_idxs, excl_scales, s.beta, s.cutoff).bind(s.nb_params),
         ]
-        bps = [bp.to_gpu(np.float32).bound_impl for bp in pots]
-        return co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 2.0e-4, 5.0, s.masses, 17).impl(), bps)
+        bps = [bp.to_gpu(precision).bound_impl for bp in pots]
+        movers = [MonteCarloBarostat(N, 1.0, 300.0, groups, 5, 23).impl(bps)] if barostat else []
+        return co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 2.0e-4, 5.0, s.masses, 17).impl(), bps, movers=movers), movers
 
     n_steps = 210
-    ref = make()
-    xs_ref, _ = ref.multiple_steps(n_steps, 15)
-    assert np.all(np.isfinite(xs_ref))
-    full = make()
-    for k in range(n_steps):
-        full.set_x_t(full.get_x_t())
-        full.step()
-        if (k + 1) % 15 == 0:
-            np.testing.assert_array_equal(full.get_x_t(), xs_ref[(k + 1) // 15 - 1])
-    np.testing.assert_array_equal(full.get_v_t(), ref.get_v_t())
+    m0 = co.debug_set_merge_producers(merge)
+    k0 = co.debug_set_static_list_max_k(static_k) if static_k is not None else None
+    try:
+        ref, ref_movers = make()
+        xs_ref, boxes_ref = ref.multiple_steps(n_steps, 15)
+        assert np.all(np.isfinite(xs_ref))
+        full, _ = make()
+        for k in range(n_steps):
+            full.set_x_t(full.get_x_t())
+            full.step()
+            if (k + 1) % 15 == 0:
+                np.testing.assert_array_equal(full.get_x_t(), xs_ref[(k + 1) // 15 - 1])
+                np.testing.assert_array_equal(full.get_box(), boxes_ref[(k + 1) // 15 - 1])
+        np.testing.assert_array_equal(full.get_v_t(), ref.get_v_t())
+        if barostat:
+            attempts, fast = ref_movers[0].get_attempt_paths()
+            assert (attempts, fast) == (n_steps // 5, 0)  # partial coverage: never the fast path
+            assert ref_movers[0].get_counters()[0] > 0 and not np.array_equal(ref.get_box(), s.box)
+    finally:
+        co.debug_set_merge_producers(m0)
+        if k0 is not None:
+            co.debug_set_static_list_max_k(k0)
 
 
 def test_langevin_thermostat_statistics(co, P):
