@@ -1,2 +1,2 @@
 set -u
-(time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pregather_with_atom_subset") 2>&1 | tail -30
+(time timeout 1700 python scripts/soak_rbfe.py 200000) > gpurun_out/s2_soak_rbfe.txt 2>&1; echo "exit $?"; grep -v amdgpu.ids gpurun_out/s2_soak_rbfe.txt | tail -50

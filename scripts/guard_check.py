@@ -79,5 +79,33 @@ group = [co.Context(mid.coords, np.zeros_like(mid.coords), mid.box, LangevinInte
                     [bp.to_gpu(np.float64 if k else np.float32).bound_impl for bp in ts.bound_potentials(mid)]) for k in range(3)]
 co.multiple_steps_group(group, 300)
 total += check("group stepping")
+# round 6: the reference's RBFE composition on the merged carrier (two record sets, guest rows' items, the holes of the merged order):
+# MD and NPT in both precisions on the listed pipeline and on the static list, grouped; energy batches over frames x parameter sets
+# (the energy memo, the same-frame hint, the f64 host entry points with device-side conversion)
+for sysm, n_lig in ((ts.small_solvated_ligand(lamb=0.3), 20), (mid, 30)):
+    Nm = sysm.num_atoms
+    for prec in (np.float32, np.float64):
+        for static_k in (0, 4608):
+            k0 = co.debug_set_static_list_max_k(static_k)
+            bps = [bp.to_gpu(prec).bound_impl for bp in ts.rbfe_bound_potentials(sysm, n_lig)]
+            baro = MonteCarloBarostat(Nm, 1.0, 300.0, ts.molecule_groups(sysm), 5, 11).impl(bps)
+            ctxt = co.Context(sysm.coords, np.zeros_like(sysm.coords), sysm.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, sysm.masses, 2).impl(), bps, movers=[baro])
+            ctxt.multiple_steps(250, 0)
+            co.debug_set_static_list_max_k(k0)
+        state = ts.rbfe_shaped_state(sysm, n_lig)
+        flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
+        sets = np.stack([flat, flat, flat * 1.0])
+        sets[1][flat.size - 4 * n_lig :].reshape(-1, 4)[:, 0] *= 0.9
+        summed = P.SummedPotential([p for p, _ in state], [q for _, q in state]).to_gpu(prec).unbound_impl
+        xs = np.stack([sysm.coords, ctxt.get_x_t()])
+        bxs = np.stack([sysm.box, ctxt.get_box()])
+        for flags in ((False, False, True), (True, False, False), (True, True, True)):
+            summed.execute_batch(xs, sets, bxs, *flags)
+            summed.execute_batch_sparse(xs, sets, bxs, np.array([1, 0, 1, 1], dtype=np.uint32), np.array([0, 1, 2, 1], dtype=np.uint32), *flags)
+    total += check(f"rbfe composition, {Nm} atoms")
+group = [co.Context(mid.coords, np.zeros_like(mid.coords), mid.box, LangevinIntegrator(300.0, 1.0e-3, 10.0, mid.masses, 30 + k).impl(),
+                    [bp.to_gpu(np.float32).bound_impl for bp in ts.rbfe_bound_potentials(mid, 30)]) for k in range(3)]
+co.multiple_steps_group(group, 300)
+total += check("group stepping, rbfe composition")
 print("TOTAL", total)
 sys.exit(1 if total else 0)
