@@ -1,2 +1,2 @@
 set -u
-(time timeout 1700 python scripts/soak_rbfe.py 200000) > gpurun_out/s2_soak_rbfe.txt 2>&1; echo "exit $?"; grep -v amdgpu.ids gpurun_out/s2_soak_rbfe.txt | tail -50
+(time timeout 900 python -m pytest tests/test_gpu_barostat_cases.py tests/test_gpu_rbfe_composition.py -m gpu -x -q) 2>&1 | tail -15

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 PREC=${PMC_PREC:-f64}
 PMC=$ROOT/gpurun_out/pmc_md_$PREC
 mkdir -p $PMC
-CMD="python $ROOT/bench.py --steps ${PMC_STEPS:-200} --warmup 10 --no-cpu-baseline --no-npt --no-rc10 --profile-steps 0 --equil-scale 0.2 --equil-precision ${PMC_PREC:-f64} --precision ${PMC_PREC:-f64} ${BENCH_ARGS:-}"
+CMD="python $ROOT/bench.py --steps ${PMC_STEPS:-200} --warmup 10 --no-cpu-baseline --no-npt --no-rc10 --no-rbfe-shape --profile-steps 0 --equil-scale 0.2 --equil-precision ${PMC_PREC:-f64} --precision ${PMC_PREC:-f64} ${BENCH_ARGS:-}"
 cd /tmp
 pass() { # name, counters...
   name=$1; shift

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python $ROOT/bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-npt --no-rc10 --profile-steps 0 "$@" > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python $ROOT/bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-npt --no-rc10 --no-rbfe-shape --profile-steps 0 "$@" > $OUT/run.log 2>&1
 cd $ROOT
 python - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections

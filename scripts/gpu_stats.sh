@@ -4,7 +4,7 @@ set -u
 tag=$1; shift
 mkdir -p gpurun_out/$tag
 export TMPDIR=/tmp
-cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-npt --profile-steps 0 "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag/bench.log 2>&1
+cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-npt --no-rbfe-shape --profile-steps 0 "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag/bench.log 2>&1
 echo "rocprof $tag exit $?"
 cd $GRAFT_REPO_ROOT
 tail -1 gpurun_out/$tag/bench.log | cut -c1-200

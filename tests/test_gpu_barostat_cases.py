@@ -298,3 +298,40 @@ def test_attempts_on_the_current_list_are_bitwise_the_reference_shaped_attempts(
     assert attempts == (n_steps + 7) // interval and fast >= 0.9 * attempts, a[7]  # all but the attempts that meet a Hilbert re-sort
     assert b[7] == (attempts, 0)
     assert not np.array_equal(a[4], s.box)  # moves were accepted
+
+
+def test_a_proposal_beyond_the_lists_reach_is_reported_not_decided_in_silence(co):
+    """The fast path evaluates a proposal on the nonbonded potential's CURRENT list (rebuilt from the current geometry if the proposal
+    fails the list's validity test).  A proposal that scales the box by several per cent can hold pairs inside the cutoff that even
+    that fresh list does not (it reaches cutoff + padding in the current geometry): `k_barostat_propose_probe` notes the first such
+    attempt in host-visible memory and the stepping call ends with an error instead of a trajectory decided on wrong energies.  With
+    the reference-shaped attempts (two full evaluations, each listing its own geometry) the same barostat runs; and moves of ordinary
+    size never trip the check (every other fast-path test of this suite steps through `after_wait`)."""
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s = ts.config4_solvated_ligand()  # 6 318 atoms: the listed pipeline (a static complete list holds every pair and has no reach to exceed)
+    N = s.num_atoms
+    groups = ts.molecule_groups(s)
+
+    def make(volume_scale):
+        bps = [bp.to_gpu(np.float32).bound_impl for bp in ts.bound_potentials(s)]
+        baro = MonteCarloBarostat(N, 1.0, 300.0, groups, 5, 3, adaptive_scaling_enabled=False, initial_volume_scale_factor=volume_scale).impl(bps)
+        ctxt = co.Context(s.coords, np.zeros_like(s.coords), s.box, LangevinIntegrator(300.0, 1.0e-3, 1.0, s.masses, 2).impl(), bps, movers=[baro])
+        return ctxt, baro
+
+    volume = float(np.prod(np.diag(s.box)))
+    ctxt, baro = make(0.6 * volume)  # |s - 1| up to 17 %: (1.2 + ...) / 0.83 is far beyond cutoff + padding = 1.3
+    with pytest.raises(RuntimeError, match="scaled further than the nonbonded potential's neighbor list reaches"):
+        for _ in range(20):
+            ctxt.multiple_steps(5, 0)
+    before = co.debug_set_barostat_fast_path(False)
+    try:
+        ctxt, baro = make(0.6 * volume)
+        ctxt.multiple_steps(40, 0)
+        assert baro.get_attempt_paths() == (8, 0) and np.all(np.isfinite(ctxt.get_x_t()))
+    finally:
+        co.debug_set_barostat_fast_path(before)
+    ctxt, baro = make(0.01 * volume)  # an ordinary move size: |s - 1| <= 0.33 %
+    ctxt.multiple_steps(100, 0)
+    assert baro.get_attempt_paths() == (20, 20)

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     const int *__restrict__ atom_idxs,
     const u64 *__restrict__ centroids, // sums of the molecules larger than BAROSTAT_INLINE_MOL (k_barostat_centroids ran first), else unused
     float *__restrict__ r2_blocks,     // [gridDim.x]: this block's largest |atom - own molecule's centroid|^2 (the DUAL tile launch's filter margin)
+    unsigned int *__restrict__ overreach, // host-visible: set to attempt + 1 by the first proposal the list cannot vouch for however fresh
     const ProbeTarget t) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float s_r2[4];
@@ -355,7 +356,20 @@ __global__ __launch_bounds__(256) void k_barostat_propose_probe(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        r2_blocks[blockIdx.x] = fmaxf(fmaxf(s_r2[0], s_r2[1]), fmaxf(s_r2[2], s_r2[3]));
+        const float r2 = fmaxf(fmaxf(s_r2[0], s_r2[1]), fmaxf(s_r2[2], s_r2[3]));
+        r2_blocks[blockIdx.x] = r2;
+        // A pair inside the cutoff in the proposal is at most (rc + 2 R |s - 1|) / (1 - |s - 1|) apart in the current geometry (the DUAL
+        // launch's filter cutoff, with this block's R: the bound grows with R, so some block sees the violation iff the largest R does).
+        // Beyond cutoff + padding even the list the probe has just rebuilt from the current geometry does not hold it: this attempt's
+        // proposal energy may miss pairs.  Said out loud (MonteCarloBarostat::after_wait throws) instead of deciding on a wrong energy
+        // in silence: only moves of several per cent of the box length get here (|s - 1| > padding / (rc + padding + 2 R), roughly).
+        if (t.list_reach > 0.0) {
+            const double ds = fabs(static_cast<double>(p.scale) - 1.0);
+            const double need = ds < 0.5 ? (t.cutoff + 2.0 * sqrt(static_cast<double>(r2)) * ds * 1.001) / (1.0 - ds) + 1e-6 : 1e30;
+            if (need > t.list_reach && *overreach == 0u) {
+                *overreach = static_cast<unsigned int>(attempt) + 1u;
+            }
+        }
     }
 }
 
@@ -584,6 +598,26 @@ MonteCarloBarostat<Real>::MonteCarloBarostat(
     if (N_ > 0) {
         d_mol_of_atom_.copy_from(mol_of_atom.data());
     }
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_overreach_), sizeof(unsigned int), hipHostMallocDefault));
+    *h_overreach_ = 0u;
+}
+
+template <typename Real> MonteCarloBarostat<Real>::~MonteCarloBarostat() {
+    if (h_overreach_ != nullptr) {
+        (void)hipHostFree(h_overreach_);
+    }
+}
+
+// (the Context has waited for the stream: what the proposal kernels wrote is visible)
+template <typename Real> void MonteCarloBarostat<Real>::after_wait() {
+    if (h_overreach_ != nullptr && *h_overreach_ != 0u) {
+        const unsigned int first = *h_overreach_ - 1u;
+        *h_overreach_ = 0u;
+        throw std::runtime_error(
+            "MonteCarloBarostat: attempt " + std::to_string(first) + " proposed a box scaled further than the nonbonded potential's neighbor list reaches "
+            "(cutoff + padding), so its energy -- and every decision since -- may be wrong.  Moves this large need the reference-shaped attempt: "
+            "tm_debug_set_barostat_fast_path(0) / TM_AMD_BAROSTAT_SLOW_PATH=1, a larger nblist_padding, or a smaller volume scale factor");
+    }
 }
 
 // One attempt on the nonbonded potential's current list (see the comment above k_barostat_propose_probe).  false: the state is
@@ -640,7 +674,7 @@ template <typename Real> bool MonteCarloBarostat<Real>::move_on_current_list(dou
 #define TM_BAROSTAT_FAST(GREAL)                                                                                        \
     k_barostat_propose_probe<Real, GREAL><<<n_prop_blocks, 256, 0, stream>>>(                                            \
         N_, adaptive_ ? 1 : 0, seed_, attempt_, d_box, d_volume_scale_.data, d_move_.data, d_box_proposed_.data, d_x, d_x_proposed_.data, \
-        d_mol_of_atom_.data, d_atom_idxs_.data, d_centroids_.data, d_r2_blocks_.data, t);                                \
+        d_mol_of_atom_.data, d_atom_idxs_.data, d_centroids_.data, d_r2_blocks_.data, h_overreach_, t);                  \
     HIP_CHECK(hipGetLastError());                                                                                      \
     if (g_barostat_dual_launch) {                                                                                      \
         nb->probe_energy_dual(d_box_proposed_.data, tables[prec], blocks[prec], d_x, d_x_proposed_.data, d_r2_blocks_.data, n_prop_blocks, stream, p0, p1, n0); \
@@ -671,6 +705,7 @@ template <typename Real> void MonteCarloBarostat<Real>::get_counters(int *accept
     int h[2];
     HIP_CHECK(hipDeviceSynchronize());
     d_counters_.copy_to(h);
+    this->after_wait();
     *accepted = h[0];
     *attempted = h[1];
 }

@@ -644,6 +644,10 @@ struct ProbeTarget {
     unsigned int *nbl_counters = nullptr; // reset by whoever raises a flag (sorted hand-over: no bounds kernel does it)
     void *blk_ctr = nullptr, *blk_ext = nullptr; // Real[ceil(n / 32)][3]: block bounds, recomputed by the commit
     int second_records = 0; // merged producers (PregatherTarget::second_records): a commit writes the positions there as well
+    // how far the CURRENT list reaches even when it has just been rebuilt (cutoff + padding; 0: a static complete list -- every pair),
+    // and the cutoff: a proposal whose pairs inside the cutoff can lie beyond that reach in the current geometry is one the list
+    // cannot vouch for however fresh it is (the mover checks: k_barostat_propose_probe)
+    double list_reach = 0, cutoff = 0;
 };
 
 // reference: cpp/src/nonbonded_all_pairs.{hpp,cu}
@@ -1022,6 +1026,9 @@ public:
     // result (the barostat's fast path commits an accepted proposal into them): the Context then only drops the integrator's
     // slot-ordered copies of x / v
     bool kept_potential_inputs() const { return kept_inputs_; }
+    // called by the Context after it has waited for the stream its movers work on (end of a stepping call): a mover that leaves
+    // itself notes from the device in host-visible memory checks them here -- and throws if the device reported a failure
+    virtual void after_wait() {}
     // the bound potentials this mover evaluates on its own (a barostat's energy evaluations run in THEIR neighbor lists and
     // accumulators): Context::multiple_steps_group counts them as device state of the mover's context
     virtual std::vector<std::shared_ptr<BoundPotential>> held_potentials() const { return {}; }
@@ -1054,6 +1061,8 @@ public:
         *attempts = static_cast<long long>(attempt_);
         *fast = fast_attempts_;
     }
+    ~MonteCarloBarostat();
+    void after_wait() override;
 private:
     const int N_;
     bool adaptive_;
@@ -1075,6 +1084,8 @@ private:
     int max_mol_size_ = 0;
     long long fast_attempts_ = 0;
     bool centroids_clean_ = false; // d_centroids_ is all zero (left so by the last fast-path attempt)
+    // pinned host word: 1 + the number of the first fast-path attempt whose proposal lay beyond the list's reach (0: none so far)
+    unsigned int *h_overreach_ = nullptr;
     bool move_on_current_list(double *d_x, double *d_box, hipStream_t stream);
 };
 

@@ -766,6 +766,9 @@ void Context::multiple_steps(const int n_steps, const int n_samples, double *h_x
     }
     intg_->finalize(bps_, d_x_t_.data, d_v_t_.data, d_box_t_.data, nullptr, stream);
     wait_for_stream(stream);
+    for (auto &mover : movers_) {
+        mover->after_wait(); // (what the movers' kernels reported in host-visible memory: throws on a reported failure)
+    }
 }
 
 // The streams a group of contexts is stepped on: created once, one after the other, so that the runtime hands them distinct
@@ -947,6 +950,11 @@ void Context::multiple_steps_group(const std::vector<Context *> &ctxts, const in
     for (hipStream_t q : st) {
         wait_for_stream(q);
     }
+    for (Context *c : ctxts) {
+        for (auto &mover : c->movers_) {
+            mover->after_wait();
+        }
+    }
 }
 
 double Context::_get_temperature() const {
@@ -1063,6 +1071,9 @@ void Context::multiple_steps_local_selection(
 void Context::step() {
     this->_step(stream_);
     HIP_CHECK(hipStreamSynchronize(stream_));
+    for (auto &mover : movers_) {
+        mover->after_wait();
+    }
 }
 
 void Context::initialize() {

@@ -946,6 +946,8 @@ template <typename Real> ProbeTarget NonbondedAllPairs<Real>::probe_begin() {
     t.blk_ctr = nblist_.d_col_ctr();
     t.blk_ext = nblist_.d_col_ext();
     t.second_records = merged_mode_ ? K_ + 1 : 0;
+    t.cutoff = cutoff_;
+    t.list_reach = static_list() ? 0.0 : cutoff_ + list_padding();
     memo_chain_ = false; // (a commit rewrites records)
     last_x_ = last_box_ = nullptr;
     probe_d_box_ = pre_box_;
