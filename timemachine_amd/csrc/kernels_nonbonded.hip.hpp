@@ -1471,18 +1471,49 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                     TM_TB(5);
                 }
                 if constexpr (COMPUTE_DU_DP) {
-                    lds_add(&s_pi[0][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qj * o.inv_dij * o.ebd));
-                    lds_add(&s_pj[0][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DCHARGE>(qi * o.inv_dij * o.ebd));
-                    if (o.has_lj) {
-                        const u64 sg = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DSIG>(o.sig_grad);
-                        lds_add(&s_pi[1][pi], sg);
-                        lds_add(&s_pj[1][pj], sg);
-                        lds_add(&s_pi[2][pi], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_j));
-                        lds_add(&s_pj[2][pj], float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DEPS>(o.eps_grad * eps_i));
+                    // The integers of float_to_fixed_exp() value by value (fixed_point.hip.hpp: scale in Real, widen, round half even),
+                    // with ONE range test and one wave-uniform escape for all of them instead of one per value (round 6: six ballots
+                    // and branch pairs per batch fewer); lanes without a Lennard-Jones term carry zeros through it.
+                    const double x_qi = static_cast<double>((qj * o.inv_dij * o.ebd) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DCHARGE));
+                    const double x_qj = static_cast<double>((qi * o.inv_dij * o.ebd) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DCHARGE));
+                    const double x_sg = o.has_lj ? static_cast<double>(o.sig_grad * static_cast<Real>(TM_FIXED_EXPONENT_DU_DSIG)) : 0.0;
+                    const double x_ei = o.has_lj ? static_cast<double>((o.eps_grad * eps_j) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DEPS)) : 0.0;
+                    const double x_ej = o.has_lj ? static_cast<double>((o.eps_grad * eps_i) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DEPS)) : 0.0;
+                    // flat items: w_i - w_j == +0, so the w gradient is an exact zero for every finite prefactor (and adding zero is
+                    // no operation) -- only a non-finite prefactor (0 * inf) keeps the general form, behind the same escape
+                    const double x_w = FLAT ? (static_cast<double>(o.prefactor) - static_cast<double>(o.prefactor)) // 0, or NaN for inf / NaN
+                                            : static_cast<double>((o.prefactor * ddw) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DW));
+                    long long r_qi = real_to_int64_fast(x_qi), r_qj = real_to_int64_fast(x_qj), r_sg = real_to_int64_fast(x_sg);
+                    long long r_ei = real_to_int64_fast(x_ei), r_ej = real_to_int64_fast(x_ej), r_w = real_to_int64_fast(x_w);
+                    const double lim = TM_FIXED_FAST_LIMIT;
+                    const bool big = !(__builtin_fabs(x_qi) < lim && __builtin_fabs(x_qj) < lim && __builtin_fabs(x_sg) < lim && __builtin_fabs(x_ei) < lim &&
+                                       __builtin_fabs(x_ej) < lim && __builtin_fabs(x_w) < lim); // (true for NaN)
+                    bool w_general = !FLAT;
+                    if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+                        if (big) {
+                            r_qi = llrint(x_qi);
+                            r_qj = llrint(x_qj);
+                            r_sg = llrint(x_sg);
+                            r_ei = llrint(x_ei);
+                            r_ej = llrint(x_ej);
+                            r_w = llrint(FLAT ? static_cast<double>((o.prefactor * ddw) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DW)) : x_w);
+                        } else if (FLAT) {
+                            r_w = 0;
+                        }
+                        w_general = true;
                     }
-                    const u64 gw = float_to_fixed_exp<Real, TM_FIXED_EXPONENT_DU_DW>(o.prefactor * ddw);
-                    lds_add(&s_pi[3][pi], gw);
-                    lds_sub(&s_pj[3][pj], gw);
+                    lds_add(&s_pi[0][pi], static_cast<u64>(r_qi));
+                    lds_add(&s_pj[0][pj], static_cast<u64>(r_qj));
+                    if (o.has_lj) {
+                        lds_add(&s_pi[1][pi], static_cast<u64>(r_sg));
+                        lds_add(&s_pj[1][pj], static_cast<u64>(r_sg));
+                        lds_add(&s_pi[2][pi], static_cast<u64>(r_ei));
+                        lds_add(&s_pj[2][pj], static_cast<u64>(r_ej));
+                    }
+                    if (w_general) { // (wave-uniform: not a flat item, or the rare escape)
+                        lds_add(&s_pi[3][pi], static_cast<u64>(r_w));
+                        lds_sub(&s_pj[3][pj], static_cast<u64>(r_w));
+                    }
                 }
                 if constexpr (COMPUTE_U) {
                     energy += float_to_fixed_energy_hot<Real>(o.u);
