@@ -21,6 +21,7 @@ bash scripts/gpu_stats_cmd.sh ${TAG}_pot5 60 python $R/bench.py --mode potential
 ( for a in "dhfr f64 same" "dhfr f32 same" "config5 f64 same" "config5 f64 windows" "config5 f32 windows"; do python scripts/further_sets_probe.py $a 2>&1 | grep -v amdgpu.ids; done
   echo "-- the same with the same-frame hint and the energy memo switched off"
   for a in "dhfr f64 same" "config5 f64 windows"; do TM_AMD_NO_ENERGY_MEMO=1 python scripts/further_sets_probe.py $a 2>&1 | grep -v amdgpu.ids; done ) > $A/further_sets.txt 2>&1
+( for pr in f64 f32; do bash scripts/gpu_stats_cmd.sh ${TAG}_form_$pr 8 python $R/scripts/pp_launch_probe.py $pr | cut -c1-220; grep "device us" gpurun_out/prof_${TAG}_form_$pr/run.log; done ) > $A/tile_launch_by_form.txt 2>&1
 ( timeout 600 python scripts/matrix_probe.py 2>&1 | grep -v amdgpu.ids ) > $A/matrix_probe.txt 2>&1
 # the 8-rank launch rehearsed on one GPU
 timeout 900 python bench.py --gpus 8 --share-gpu > $A/bench_share_gpu_md.json 2> $A/bench_share_gpu_md.err
