@@ -18,6 +18,18 @@
 
 namespace tmamd {
 
+// A value every lane of the wave holds alike, moved to scalar registers (the compiler keeps the result of a vector instruction
+// -- an LDS read, a division, a shuffle -- in vector registers even when it is uniform; the list kernel's budget is 64).
+__device__ __forceinline__ float wave_uniform(const float v) {
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
+__device__ __forceinline__ double wave_uniform(const double v) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+    const unsigned int lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(b));
+    const unsigned int hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(b >> 32));
+    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
 // K2: block bounds (one wave per 32-atom block), coordinate snapshot and counter reset.
 // REFERENCE_FOLD = true reproduces the reference's boxes (what Neighborlist.compute_block_bounds reports): its running
 // min/max fold is inherently sequential (each atom is re-imaged around the CURRENT centre), so every lane of the wave
@@ -135,30 +147,27 @@ __global__ __launch_bounds__(256) void k_block_bounds(
 // K3: per row block, find interacting column atoms.  One NBL_THREADS-thread workgroup (16 waves) per row block.
 //   pass 1  per chunk of NBL_CHUNK column blocks: compact the passing block ids into an LDS list (ballot + popcount)
 //   pass 2  the waves stride over the list two column blocks at a time (lanes 0-31 / 32-63 = one column atom
-//           each).  As in the reference, row atoms are first filtered against the column block's box
-//           (k_neighborlist.cuh:349-365), here with one (row atom, column block) test per lane and two 32-bit row masks;
-//           every lane then walks only the set bits of its half's mask, and the wave leaves as soon as all of its
-//           lanes have found a partner.
-#ifndef TM_NBL_TRIP
-#define TM_NBL_TRIP 4
-#endif
-static const int NBL_TRIP = TM_NBL_TRIP; // rows tested per trip of the fine pass
+//           each); every lane tests its atom against all 32 rows without a branch (f32, origin-relative, Gram form) and
+//           counts the rows inside the cost cutoff on the way; see the comment at the loop.
 #ifndef TM_NBL_COST_STRIDE
 #define TM_NBL_COST_STRIDE 4
 #endif
-static const int NBL_COST_STRIDE = TM_NBL_COST_STRIDE; // cost estimates sample every 4th row (lane-staggered start)
+static const int NBL_COST_STRIDE = TM_NBL_COST_STRIDE; // cost estimates count every 4th row
 static const int NBL_CHUNK = 2048;   // column blocks per LDS list chunk (8 KB of LDS)
 #ifndef TM_NBL_CAND_CAP
-#define TM_NBL_CAND_CAP 3072
+#define TM_NBL_CAND_CAP 8192
 #endif
-static const int NBL_CAND_CAP = TM_NBL_CAND_CAP; // accepted column atoms per row block staged in LDS (48 KB; a 1.3 nm list at water density holds ~2100)
+static const int NBL_CAND_CAP = TM_NBL_CAND_CAP; // accepted column atoms per row block whose pair counts are staged in LDS (16 KB; a 1.3 nm list at water density holds ~2100)
 #ifndef TM_NBL_THREADS
 #define TM_NBL_THREADS 1024
 #endif
 static const int NBL_THREADS = TM_NBL_THREADS; // 16 waves per row block: the per-row-block critical path is what bounds this kernel
+#ifndef TM_NBL_WAVES_PER_SIMD
+#define TM_NBL_WAVES_PER_SIMD 8
+#endif
 
 template <typename Real, bool UPPER_TRIANGULAR>
-__global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SIMD = 2 workgroups per CU: the register budget is 64
+__global__ __launch_bounds__(NBL_THREADS, TM_NBL_WAVES_PER_SIMD) void k_find_ixns( // 8 waves per SIMD = 2 workgroups per CU: the register budget is 64
     const int K, const int NC, const int NR, const unsigned int *__restrict__ col_idxs, const unsigned int *__restrict__ row_idxs,
     const Real *__restrict__ col_ctr, const Real *__restrict__ col_ext, const Real *__restrict__ row_ctr,
     const Real *__restrict__ row_ext, const Real *__restrict__ gathered, const double *__restrict__ box, const double cutoff_d,
@@ -199,9 +208,12 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     __shared__ unsigned int s_nlist, s_count;
     __shared__ unsigned int s_hist[NB_CLASSES], s_base[NB_CLASSES];
     __shared__ float s_rf[3][TILE];
-    // accepted column atoms (origin-relative f32 position, atom index in .w) in list order: the cost estimate below
-    // reads them back from here instead of through two dependent global round trips (col_atoms, then gathered)
-    __shared__ float4 s_cand[NBL_CAND_CAP];
+    // the rows once more in the form the fine pass multiplies with: (-2 x, -2 y, -2 z, |r|^2) of the origin-relative f32
+    // position, so that |r - c|^2 - |c|^2 is three FMAs on a broadcast 16-byte read; rows past the block's end hold |r|^2 = 1e30
+    __shared__ float4 s_rg[TILE];
+    // per accepted column atom, in list order: how many of the block's rows it has inside the cost cutoff (the fine pass
+    // counts them while it is there); the items' cost estimates are sums over 64 consecutive entries
+    __shared__ unsigned short s_cnt[NBL_CAND_CAP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -216,16 +228,36 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
 #endif
     TM_NBL_STAMP();
     const int n_col_blocks = (NC + TILE - 1) / TILE;
-    const NbBox<Real> bx = load_box<Real>(box);
-    const Real cutoff = static_cast<Real>(cutoff_d);
-    const Real cutoff2 = cutoff * cutoff;
     const bool guest = UPPER_TRIANGULAR && rb < guest_blocks;
     const int row_limit = guest ? guest_rows : NR;
     const int nrow = (row_limit - rb * TILE) < TILE ? (row_limit - rb * TILE) : TILE;
     const int guest_bit = guest ? static_cast<int>(0x80000000u) : 0;
+    const int cb_first = UPPER_TRIANGULAR ? (guest ? guest_blocks : rb) : 0;
+
+    // Everything the kernel needs from memory before its first barrier is requested in one go -- this thread's first column
+    // box, the row block's own box, the row atoms: a dependent global load costs 1-3 us right behind a kernel boundary (the
+    // inputs were written by another XCD), and the workgroup's life is a chain of such hops.
+    Real pc[6] = {0, 0, 0, 0, 0, 0};
+    const int cb_pre = cb_first + tid;
+    if (cb_pre < n_col_blocks) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            pc[d] = col_ctr[cb_pre * 3 + d];
+            pc[3 + d] = col_ext[cb_pre * 3 + d];
+        }
+    }
+    const Real rcx = row_ctr[rb * 3 + 0], rcy = row_ctr[rb * 3 + 1], rcz = row_ctr[rb * 3 + 2];
+    const Real rex = row_ext[rb * 3 + 0], rey = row_ext[rb * 3 + 1], rez = row_ext[rb * 3 + 2];
+    NbBox<Real> bx = load_box<Real>(box);
+    bx.inv_x = wave_uniform(bx.inv_x); // (the divisions ran on the vector unit)
+    bx.inv_y = wave_uniform(bx.inv_y);
+    bx.inv_z = wave_uniform(bx.inv_z);
+    const Real cutoff = static_cast<Real>(cutoff_d);
+    const Real cutoff2 = cutoff * cutoff;
 
     if (tid == 0) {
         s_count = 0;
+        s_nlist = 0;
     }
     if (tid < TILE) {
         const int ridx = rb * TILE + tid;
@@ -240,21 +272,14 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     }
     __syncthreads();
 
-    const Real rcx = row_ctr[rb * 3 + 0], rcy = row_ctr[rb * 3 + 1], rcz = row_ctr[rb * 3 + 2];
-    const Real rex = row_ext[rb * 3 + 0], rey = row_ext[rb * 3 + 1], rez = row_ext[rb * 3 + 2];
-    const int cb_first = UPPER_TRIANGULAR ? (guest ? guest_blocks : rb) : 0;
-
     // row bbox vs column bbox (k_neighborlist.cuh:296-329)
-    auto coarse = [&](int cb) -> bool {
-        if (cb >= n_col_blocks) {
-            return false;
-        }
-        Real ddx = min_image(rcx - col_ctr[cb * 3 + 0], bx.x, bx.inv_x);
-        Real ddy = min_image(rcy - col_ctr[cb * 3 + 1], bx.y, bx.inv_y);
-        Real ddz = min_image(rcz - col_ctr[cb * 3 + 2], bx.z, bx.inv_z);
-        ddx = max(static_cast<Real>(0), fabs(ddx) - rex - col_ext[cb * 3 + 0]);
-        ddy = max(static_cast<Real>(0), fabs(ddy) - rey - col_ext[cb * 3 + 1]);
-        ddz = max(static_cast<Real>(0), fabs(ddz) - rez - col_ext[cb * 3 + 2]);
+    auto coarse_box = [&](Real ccx, Real ccy, Real ccz, Real cex, Real cey, Real cez) -> bool {
+        Real ddx = min_image(rcx - ccx, bx.x, bx.inv_x);
+        Real ddy = min_image(rcy - ccy, bx.y, bx.inv_y);
+        Real ddz = min_image(rcz - ccz, bx.z, bx.inv_z);
+        ddx = max(static_cast<Real>(0), fabs(ddx) - rex - cex);
+        ddy = max(static_cast<Real>(0), fabs(ddy) - rey - cey);
+        ddz = max(static_cast<Real>(0), fabs(ddz) - rez - cez);
         return (ddx * ddx + ddy * ddy + ddz * ddz) < cutoff2;
     };
 
@@ -269,13 +294,18 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     // f32 copies of the row atoms relative to the first one (resolution independent of coordinate drift): the fine pass
     // and the cost estimate run on these; only distances within rounding reach of the cutoff are re-tested in Real
     const float fbx = static_cast<float>(bx.x), fby = static_cast<float>(bx.y), fbz = static_cast<float>(bx.z);
-    const float fibx = 1.0f / fbx, fiby = 1.0f / fby, fibz = 1.0f / fbz;
-    const Real ox = s_rx[0], oy = s_ry[0], oz = s_rz[0];
+    const float fibx = wave_uniform(1.0f / fbx), fiby = wave_uniform(1.0f / fby), fibz = wave_uniform(1.0f / fbz);
+    const Real ox = wave_uniform(s_rx[0]), oy = wave_uniform(s_ry[0]), oz = wave_uniform(s_rz[0]);
     if (tid < TILE) {
         const bool valid = tid < nrow;
-        s_rf[0][tid] = valid ? static_cast<float>(min_image(s_rx[tid] - ox, bx.x, bx.inv_x)) : 0.0f;
-        s_rf[1][tid] = valid ? static_cast<float>(min_image(s_ry[tid] - oy, bx.y, bx.inv_y)) : 0.0f;
-        s_rf[2][tid] = valid ? static_cast<float>(min_image(s_rz[tid] - oz, bx.z, bx.inv_z)) : 0.0f;
+        const float fx = valid ? static_cast<float>(min_image(s_rx[tid] - ox, bx.x, bx.inv_x)) : 0.0f;
+        const float fy = valid ? static_cast<float>(min_image(s_ry[tid] - oy, bx.y, bx.inv_y)) : 0.0f;
+        const float fz = valid ? static_cast<float>(min_image(s_rz[tid] - oz, bx.z, bx.inv_z)) : 0.0f;
+        s_rf[0][tid] = fx;
+        s_rf[1][tid] = fy;
+        s_rf[2][tid] = fz;
+        s_rg[tid] = valid ? make_float4(-2.0f * fx, -2.0f * fy, -2.0f * fz, __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx)))
+                          : make_float4(0.0f, 0.0f, 0.0f, 1e30f);
     }
     __syncthreads();
     // largest |row - origin| per dimension (every wave computes it for itself)
@@ -287,19 +317,29 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         rmy = fmaxf(rmy, __shfl_xor(rmy, o, 64));
         rmz = fmaxf(rmz, __shfl_xor(rmz, o, 64));
     }
+    rmx = wave_uniform(rmx);
+    rmy = wave_uniform(rmy);
+    rmz = wave_uniform(rmz);
+    const float rm2 = wave_uniform(__builtin_fmaf(rmz, rmz, __builtin_fmaf(rmy, rmy, rmx * rmx)));
+    const float fcut = static_cast<float>(cutoff_d);
     const float fcut2 = static_cast<float>(cutoff_d * cutoff_d);
     const float fmargin = 2e-5f * (1.0f + fcut2); // >> the f32 rounding error of a squared distance of this size
+    const float cost_cutoff2 = static_cast<float>(cost_cutoff_d * cost_cutoff_d);
+    const Real cost_cutoff2_real = static_cast<Real>(cost_cutoff_d * cost_cutoff_d);
     TM_NBL_STAMP(); // rows loaded
     for (int chunk0 = cb_first; chunk0 < n_col_blocks; chunk0 += NBL_CHUNK) {
-        // ---- pass 1: compact the passing column blocks of this chunk into s_list
-        if (tid == 0) {
-            s_nlist = 0;
-        }
-        __syncthreads();
+        // ---- pass 1: compact the passing column blocks of this chunk into s_list (s_nlist is zero here)
         const int chunk_end = (chunk0 + NBL_CHUNK) < n_col_blocks ? (chunk0 + NBL_CHUNK) : n_col_blocks;
         for (int cb0 = chunk0; cb0 < chunk_end; cb0 += NBL_THREADS) {
             const int cb = cb0 + tid;
-            const bool pass = cb < chunk_end && coarse(cb);
+            bool pass = false;
+            if (cb < chunk_end) {
+                if (cb0 == cb_first) { // the box requested at the top
+                    pass = coarse_box(pc[0], pc[1], pc[2], pc[3], pc[4], pc[5]);
+                } else {
+                    pass = coarse_box(col_ctr[cb * 3 + 0], col_ctr[cb * 3 + 1], col_ctr[cb * 3 + 2], col_ext[cb * 3 + 0], col_ext[cb * 3 + 1], col_ext[cb * 3 + 2]);
+                }
+            }
             const u64 m = __ballot(pass);
             if (m) {
                 unsigned int base = 0;
@@ -315,19 +355,22 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         __syncthreads();
         const int nlist = s_nlist;
 
-#if defined(TM_NBL_ABL) && TM_NBL_ABL == 4
-        if (nlist >= 0) { continue; } // ablation: coarse passes only
-#endif
         TM_NBL_STAMP(); // coarse list ready
-        // ---- pass 2: two column blocks per wave iteration
+        // ---- pass 2: two column blocks per wave iteration (lanes 0-31 / 32-63 = one column atom each).  Every lane tests its
+        // atom against ALL rows, branch-free, in f32 on origin-relative coordinates: per row one broadcast read of s_rg and
+        // three FMAs give |r - c|^2 - |c|^2; the minimum decides, the (sampled) count inside the cost cutoff is the atom's share
+        // of its item's cost estimate.  (The reference filters rows against the column block's box first, k_neighborlist.cuh:349-365,
+        // and walks the survivors; on a wave that walk is a chain of ballots and branches that costs more than the 32 rows.)
+        // Only distances within rounding reach of the cutoff, and atoms so far from the origin that row - column could need
+        // re-imaging, take the exact test in Real -- so the listed set equals the brute-force Real set (tests/test_nblist.py:180-186).
         const int half_id = lane >> 5; // 0: lanes 0-31, 1: lanes 32-63
         const int sub = lane & 31;
-        for (int k = wave * 2; k < nlist; k += 2 * (NBL_THREADS / 64)) {
+        const int kstride = 2 * (NBL_THREADS / 64);
+        auto fetch = [&](const int k, int &cb, unsigned int &ja, Real &xj, Real &yj, Real &zj) {
             const int my_entry = k + half_id;
-            const int cb = my_entry < nlist ? s_list[my_entry] : -1;
-            unsigned int ja = K;
-            Real xj = 0, yj = 0, zj = 0;
-            bool row_near = false; // is row atom `sub` within the cutoff of column block cb's box?
+            cb = my_entry < nlist ? s_list[my_entry] : -1;
+            ja = K;
+            xj = yj = zj = 0;
             if (cb >= 0) {
                 const int jpos = cb * TILE + sub;
                 if (jpos < NC) {
@@ -336,87 +379,69 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                     yj = gathered[static_cast<size_t>(ja) * 8 + 1];
                     zj = gathered[static_cast<size_t>(ja) * 8 + 2];
                 }
-                if (sub < nrow) {
-                    Real ax = min_image(s_rx[sub] - col_ctr[cb * 3 + 0], bx.x, bx.inv_x);
-                    Real ay = min_image(s_ry[sub] - col_ctr[cb * 3 + 1], bx.y, bx.inv_y);
-                    Real az = min_image(s_rz[sub] - col_ctr[cb * 3 + 2], bx.z, bx.inv_z);
-                    ax = max(static_cast<Real>(0), fabs(ax) - col_ext[cb * 3 + 0]);
-                    ay = max(static_cast<Real>(0), fabs(ay) - col_ext[cb * 3 + 1]);
-                    az = max(static_cast<Real>(0), fabs(az) - col_ext[cb * 3 + 2]);
-                    row_near = (ax * ax + ay * ay + az * az) < cutoff2;
+            }
+        };
+        int cb_n = -1;
+        unsigned int ja_n = K;
+        Real xn = 0, yn = 0, zn = 0;
+        if (wave * 2 < nlist) {
+            fetch(wave * 2, cb_n, ja_n, xn, yn, zn);
+        }
+        for (int k = wave * 2; k < nlist; k += kstride) {
+            const int cb = cb_n;
+            const unsigned int ja = ja_n;
+            const bool valid = ja < static_cast<unsigned int>(K);
+            const float cfx = static_cast<float>(min_image(xn - ox, bx.x, bx.inv_x));
+            const float cfy = static_cast<float>(min_image(yn - oy, bx.y, bx.inv_y));
+            const float cfz = static_cast<float>(min_image(zn - oz, bx.z, bx.inv_z));
+            if (k + kstride < nlist) { // the next trip's atoms are on their way while this trip computes
+                fetch(k + kstride, cb_n, ja_n, xn, yn, zn);
+            }
+            const float acx = fabsf(cfx), acy = fabsf(cfy), acz = fabsf(cfz);
+            const bool no_wrap = (acx + rmx) * fibx < 0.49f && (acy + rmy) * fiby < 0.49f && (acz + rmz) * fibz < 0.49f;
+            // farther than the cutoff from every row in one dimension alone (true under any re-imaging: |c| <= L/2)
+            const bool far = fmaxf(fmaxf(acx - rmx, acy - rmy), acz - rmz) > fcut + 1e-4f;
+            const float c2 = __builtin_fmaf(cfz, cfz, __builtin_fmaf(cfy, cfy, cfx * cfx));
+            const float thr_cost = cost_cutoff2 - c2;
+            float gmin = 1e30f;
+            unsigned int cnt = 0;
+            // (the rows are the same on every trip: without an address the compiler cannot see through it reads all 32 once,
+            // in front of the loop, and spills them)
+            int opaque0 = 0;
+            asm volatile("" : "+s"(opaque0));
+            const float4 *rg = s_rg + opaque0;
+#pragma unroll 8
+            for (int r = 0; r < TILE; r++) { // eight rows' reads in flight: 32 registers (the budget is 64)
+                const float4 g = rg[r];
+                const float acc = __builtin_fmaf(cfz, g.z, __builtin_fmaf(cfy, g.y, __builtin_fmaf(cfx, g.x, g.w)));
+                gmin = fminf(gmin, acc);
+                if ((r % NBL_COST_STRIDE) == 0) { // the count samples every fourth row (three instructions per counted row)
+                    cnt += acc < thr_cost ? static_cast<unsigned int>(NBL_COST_STRIDE) : 0u;
                 }
             }
-            const u64 near = __ballot(row_near);
-            unsigned int rows = half_id ? static_cast<unsigned int>(near >> 32) : static_cast<unsigned int>(near);
-            bool live = ja < static_cast<unsigned int>(K);
-            if (live) {
-                // the mirror-image filter: a column atom farther than the cutoff from the row block's BOX has no partner,
-                // and would otherwise walk every set bit of the row mask to find that out (the wave waits for it)
-                Real ax = min_image(xj - rcx, bx.x, bx.inv_x);
-                Real ay = min_image(yj - rcy, bx.y, bx.inv_y);
-                Real az = min_image(zj - rcz, bx.z, bx.inv_z);
-                ax = max(static_cast<Real>(0), fabs(ax) - rex);
-                ay = max(static_cast<Real>(0), fabs(ay) - rey);
-                az = max(static_cast<Real>(0), fabs(az) - rez);
-                live = (ax * ax + ay * ay + az * az) < cutoff2;
-            }
-            bool interacts = false;
-            // all lanes of a half share `rows`; the loop is uniform across the wave (max of the two popcounts)
-#if defined(TM_NBL_ABL) && TM_NBL_ABL == 2
-            interacts = live; // ablation: no fine pass (every atom of a passing column block is listed)
-#endif
-            // f32 distances on origin-relative coordinates decide everything that is not within rounding reach of the
-            // cutoff; those few, and column atoms so far from the origin that row - col could need re-imaging, take the
-            // exact test in Real (so the listed set equals the brute-force Real set, tests/test_nblist.py:180-186)
-            const float cfx = static_cast<float>(min_image(xj - ox, bx.x, bx.inv_x));
-            const float cfy = static_cast<float>(min_image(yj - oy, bx.y, bx.inv_y));
-            const float cfz = static_cast<float>(min_image(zj - oz, bx.z, bx.inv_z));
-            const bool no_wrap = (fabsf(cfx) + rmx) * fibx < 0.49f && (fabsf(cfy) + rmy) * fiby < 0.49f && (fabsf(cfz) + rmz) * fibz < 0.49f;
-            {
-                // NBL_TRIP rows per trip: the trip itself is a latency chain (LDS read -> distance -> compare -> ballot -> branch,
-                // ~200 cycles) and the whole wave waits for its slowest lane, so the number of trips is what costs.
-                while (__ballot(rows != 0 && live && !interacts)) {
-                    bool exact_needed = false;
-                    int ix[NBL_TRIP];
-                    bool have[NBL_TRIP];
-#pragma unroll
-                    for (int q = 0; q < NBL_TRIP; q++) {
-                        ix[q] = 0;
-                        have[q] = false;
+            const float dmin = c2 + gmin;
+            const float marg = __builtin_fmaf(2e-6f, c2 + rm2, fmargin); // + the Gram form's own rounding
+            bool interacts = valid && !far && no_wrap && dmin < fcut2 - marg;
+            const bool exact_needed = valid && !far && !interacts && (!no_wrap || dmin < fcut2 + marg);
+            if (__ballot(exact_needed)) {
+                if (exact_needed) {
+                    // (the atom's Real position is not kept across the row loop for this: registers)
+                    const Real xj = gathered[static_cast<size_t>(ja) * 8 + 0], yj = gathered[static_cast<size_t>(ja) * 8 + 1],
+                               zj = gathered[static_cast<size_t>(ja) * 8 + 2];
+                    unsigned int c = 0; // (every row: this path is rare)
+                    for (int r = 0; r < nrow; r++) {
+                        const Real dx = min_image(s_rx[r] - xj, bx.x, bx.inv_x);
+                        const Real dy = min_image(s_ry[r] - yj, bx.y, bx.inv_y);
+                        const Real dz = min_image(s_rz[r] - zj, bx.z, bx.inv_z);
+                        const Real d2 = dx * dx + dy * dy + dz * dz;
+                        interacts = interacts || d2 < cutoff2;
+                        c += d2 < cost_cutoff2_real ? 1u : 0u;
                     }
-                    if (rows != 0 && live && !interacts) {
-#pragma unroll
-                        for (int q = 0; q < NBL_TRIP; q++) {
-                            have[q] = rows != 0;
-                            ix[q] = have[q] ? __builtin_ctz(rows) : 0;
-                            rows = have[q] ? (rows & (rows - 1)) : 0u;
-                        }
-                        float dmin = 1e30f; // smallest f32 squared distance among this trip's rows
-#pragma unroll
-                        for (int q = 0; q < NBL_TRIP; q++) {
-                            const float dx = s_rf[0][ix[q]] - cfx, dy = s_rf[1][ix[q]] - cfy, dz = s_rf[2][ix[q]] - cfz;
-                            const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                            dmin = fminf(dmin, have[q] ? d2 : 1e30f);
-                        }
-                        interacts = no_wrap && dmin < fcut2 - fmargin;
-                        // nothing decided yet and something within rounding reach of the cutoff (or re-imaging possible):
-                        // the trip's rows take the exact test
-                        exact_needed = !interacts && (!no_wrap || dmin < fcut2 + fmargin);
-                    }
-                    if (__ballot(exact_needed)) {
-                        if (exact_needed) {
-#pragma unroll
-                            for (int q = 0; q < NBL_TRIP; q++) {
-                                if (have[q]) {
-                                    const Real dx = min_image(s_rx[ix[q]] - xj, bx.x, bx.inv_x);
-                                    const Real dy = min_image(s_ry[ix[q]] - yj, bx.y, bx.inv_y);
-                                    const Real dz = min_image(s_rz[ix[q]] - zj, bx.z, bx.inv_z);
-                                    interacts = interacts || (dx * dx + dy * dy + dz * dz) < cutoff2;
-                                }
-                            }
-                        }
-                    }
+                    cnt = c;
                 }
+            }
+            if (UPPER_TRIANGULAR && cb == rb) {
+                cnt >>= 1; // the diagonal tile evaluates row < column only
             }
             const u64 hits = __ballot(interacts);
             if (hits) {
@@ -429,17 +454,20 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
                     const unsigned int pos = base + __popcll(hits & ((1ull << lane) - 1ull));
                     col_atoms[seg_start + pos] = ja;
                     if (pos < static_cast<unsigned int>(NBL_CAND_CAP)) {
-                        s_cand[pos] = make_float4(cfx, cfy, cfz, __uint_as_float(ja));
+                        s_cnt[pos] = static_cast<unsigned short>(cnt);
                     }
                 }
             }
         }
         __syncthreads();
+        if (chunk0 + NBL_CHUNK < n_col_blocks) { // (uniform) another chunk follows
+            if (tid == 0) {
+                s_nlist = 0;
+            }
+            __syncthreads();
+        }
     }
 
-#if defined(TM_NBL_ABL) && TM_NBL_ABL >= 3
-    if (tid >= 0) { return; } // ablation: nothing published
-#endif
     TM_NBL_STAMP(); // pass 2 done
     // ---- publish the segment and its work items
     // Every item gets a cost estimate -- the number of (row, column) pairs inside `cost_cutoff` -- and is filed into
@@ -468,43 +496,30 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
     // uninitialised LDS, and the item went to a wild address (intermittent GPU memory faults once the cost estimate
     // stopped waiting on global loads).
     __syncthreads();
-    // the estimate runs in f32 on coordinates relative to the first row atom
-    const float cost_cutoff2 = static_cast<float>(cost_cutoff_d * cost_cutoff_d);
     for (unsigned int c = wave; c < n_chunks; c += NBL_THREADS / 64) {
         const unsigned int off = c * NB_CHUNK;
         const unsigned int len = (count - off) < NB_CHUNK ? (count - off) : NB_CHUNK;
-        unsigned int ja = K;
-        float xj = 0.0f, yj = 0.0f, zj = 0.0f;
         const bool staged = off + len <= static_cast<unsigned int>(NBL_CAND_CAP); // wave-uniform
-        if (static_cast<unsigned int>(lane) < len) {
-            if (staged) {
-                const float4 cand = s_cand[off + lane];
-                xj = cand.x;
-                yj = cand.y;
-                zj = cand.z;
-                ja = __float_as_uint(cand.w);
-            } else {
-                // written by other waves of this workgroup a barrier ago: read past the (non-coherent) vector L1
-                ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
-                yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
-                zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
-            }
-        }
         unsigned int mine = 0;
-#if defined(TM_NBL_ABL) && TM_NBL_ABL == 1
-        if (false) { // ablation: no cost estimate
-#else
-        if (ja < static_cast<unsigned int>(K)) {
-#endif
-            // every NBL_COST_STRIDE-th row only: the estimate feeds a 128-pair-wide cost class, a sampled count is plenty
+        if (staged) {
+            if (static_cast<unsigned int>(lane) < len) {
+                mine = s_cnt[off + lane];
+            }
+        } else if (static_cast<unsigned int>(lane) < len) {
+            // more accepted atoms than the staging area holds: a sampled count (every NBL_COST_STRIDE-th row, lane-staggered)
+            // on the atom re-read from memory -- written by other waves of this workgroup a barrier ago: read past the
+            // (non-coherent) vector L1
+            const unsigned int ja = __hip_atomic_load(col_atoms + seg_start + off + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float xj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 0] - ox, bx.x, bx.inv_x));
+            const float yj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 1] - oy, bx.y, bx.inv_y));
+            const float zj = static_cast<float>(min_image(gathered[static_cast<size_t>(ja) * 8 + 2] - oz, bx.z, bx.inv_z));
             for (int i = (lane & (NBL_COST_STRIDE - 1)); i < nrow; i += NBL_COST_STRIDE) {
                 float dx = s_rf[0][i] - xj, dy = s_rf[1][i] - yj, dz = s_rf[2][i] - zj;
                 dx = __builtin_fmaf(-fbx, __builtin_rintf(dx * fibx), dx);
                 dy = __builtin_fmaf(-fby, __builtin_rintf(dy * fiby), dy);
                 dz = __builtin_fmaf(-fbz, __builtin_rintf(dz * fibz), dz);
                 const bool order_ok = !UPPER_TRIANGULAR || static_cast<unsigned int>(rb * TILE + i) < ja;
-                mine += (order_ok && __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) < cost_cutoff2) ? 1u : 0u;
+                mine += (order_ok && __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) < cost_cutoff2) ? NBL_COST_STRIDE : 0u;
             }
         }
         unsigned int total = mine;
@@ -512,7 +527,6 @@ __global__ __launch_bounds__(NBL_THREADS, 8) void k_find_ixns( // 8 waves per SI
         for (int o = 32; o > 0; o >>= 1) {
             total += __shfl_xor(total, o, 64);
         }
-        total *= NBL_COST_STRIDE;
         total = total < 2048u ? total : 2048u;
         if (lane == 0) {
             const unsigned int heavy = total / NB_CLASS_PAIRS;
