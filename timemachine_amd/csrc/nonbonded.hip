@@ -569,8 +569,8 @@ template <typename Real>
 NonbondedAllPairs<Real>::NonbondedAllPairs(
     const int N, const double beta, const double cutoff, const bool disable_hilbert_sort, const double nblist_padding, MergedTag,
     const std::vector<unsigned int> &host_idxs, const std::vector<unsigned int> &guest_idxs)
-    : steps_per_sort_(STEPS_PER_SORT), N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding),
-      disable_hilbert_(disable_hilbert_sort), calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N + TILE), merged_mode_(true) {
+    : merged_mode_(true), steps_per_sort_(STEPS_PER_SORT), N_(N), K_(N), beta_(beta), cutoff_(cutoff), nblist_padding_(nblist_padding),
+      disable_hilbert_(disable_hilbert_sort), calls_since_sort_(0), parity_(0), force_rebuild_(true), nblist_(N + TILE) {
     this->allocate();
     const int L = static_cast<int>(guest_idxs.size()), K1 = static_cast<int>(host_idxs.size());
     guest_rows_ = L;
