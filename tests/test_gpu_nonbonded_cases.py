@@ -152,9 +152,11 @@ def test_hilbert_sort_makes_compact_blocks(co, block_size):
     assert mean_max_block_distance(coords[perm]) < 0.6 * mean_max_block_distance(coords)
 
 
-@pytest.mark.parametrize("tiles", [2, 10, 100])
+@pytest.mark.parametrize("tiles", [2, 10, 100, 300])
 def test_nblist_max_interactions(co, tiles):
-    """tests/test_nblist.py:366-383: every atom within the cutoff of every other -- the list fills its worst-case buffers exactly."""
+    """tests/test_nblist.py:366-383: every atom within the cutoff of every other -- the list fills its worst-case buffers exactly.
+    (300 tiles = 9 600 listed atoms per row block: more than the list kernel stages in LDS (NBL_CAND_CAP = 8192), so the cost
+    estimates of the chunks past the staging area take their sampled path on atoms re-read from memory.)"""
     rng = np.random.default_rng(2023)
     block_size, cutoff = 32, 10.0
     coords = rng.random(size=(block_size * tiles, 3))

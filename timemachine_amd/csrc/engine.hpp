@@ -254,10 +254,13 @@ public:
         int &count, i128 *d_final = nullptr) {
         return false;
     }
-    // The caller vouches that the coordinates and the box behind the pointers of the NEXT call hold what they held at the last one
-    // (execute_batch walking the parameter sets of one frame): stateful children may skip what only coordinates can invalidate.
-    // One call only; any other use clears it.
-    virtual void hint_same_frame() {}
+    // The caller vouches that the coordinates and the box behind the pointers of the NEXT call hold what they held at the call numbered
+    // `prev_call` (execute_batch walking the parameter sets of one frame; calls are numbered by g_eval_serial): a stateful child that
+    // last ran its pipeline IN that call may skip what only coordinates can invalidate.  A child that did not run in it -- an
+    // interaction group whose work the all-pairs potential's merged carrier did, or the reverse -- must not: its own "last call" was
+    // another frame behind what may well be the same pointers (found by tests/test_gpu_interleavings.py: a stale list, pairs near the
+    // cutoff missing).  One call only: the giver withdraws the hint (on = false) behind the call.
+    virtual void hint_same_frame(const bool on = true, const long long prev_call = 0) {}
 
     // The consumer of DeferredForces has enqueued (on the same stream) a kernel that filled `next` for the coordinates
     // in d_x / d_box: the following execute_forces_deferred call with the same pointers may skip its gather.
@@ -373,9 +376,9 @@ public:
             pot->expect_box_scaling();
         }
     }
-    void hint_same_frame() override {
+    void hint_same_frame(const bool on = true, const long long prev_call = 0) override {
         for (auto &pot : potentials_) {
-            pot->hint_same_frame();
+            pot->hint_same_frame(on, prev_call);
         }
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
@@ -414,9 +417,9 @@ public:
             pot->expect_box_scaling();
         }
     }
-    void hint_same_frame() override {
+    void hint_same_frame(const bool on = true, const long long prev_call = 0) override {
         for (auto &pot : potentials_) {
-            pot->hint_same_frame();
+            pot->hint_same_frame(on, prev_call);
         }
     }
     void execute_device(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) override;
@@ -616,6 +619,7 @@ void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool
 
 extern double g_last_host_call_device_ms; // potential.hip: device time of the evaluations of the last execute_host_f64 call
 extern bool g_same_frame_hint; // the batch entry points' hint_same_frame() is honoured (tm_debug_set_same_frame_hint)
+extern thread_local long long g_eval_serial; // number of the batch entry being evaluated on this thread (Potential::execute_batch[_sparse]_device)
 extern bool g_energy_memo;     // energy-only evaluations are remembered on the device (EnergyMemo; tm_debug_set_energy_memo)
 extern bool g_merge_producers; // ForcePlan::merge_producers runs all-pairs + interaction group as one pipeline (tm_debug_set_merge_producers)
 extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)
@@ -714,7 +718,13 @@ public:
     }
     bool execute_forces_deferred(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, hipStream_t stream, DeferredForces &out) override;
     bool execute_energy_partials(const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials, int &count, i128 *d_final = nullptr) override;
-    void hint_same_frame() override { same_frame_hint_ = true; }
+    void hint_same_frame(const bool on = true, const long long prev_call = 0) override {
+        same_frame_hint_ = on;
+        hint_call_ = prev_call;
+        if (!on && merged_) {
+            merged_->hint_same_frame(false);
+        }
+    }
     void pregather_committed(const double *d_x, const double *d_box, const bool sorted_bounds_done) override;
     bool probe_ready(const int N, const int P, const double *d_x, const double *d_p, const double *d_box) override;
     ProbeTarget probe_begin() override;
@@ -791,6 +801,8 @@ protected:
     DeviceBuffer<i128> d_u_partials_b_; // the second launch of a memo evaluation (guest rows' items + the plan's table)
     bool memo_chain_ = false;           // the last pipeline call was a memo evaluation: the device's memo describes the records
     i128 *memo_final_ = nullptr;        // execute_energy_partials: where the coming memo evaluation may leave its total
+    long long hint_call_ = 0, hint_call_now_ = 0; // ... the call the hint speaks of (g_eval_serial at the time)
+    long long last_call_ = -1;          // the call this pipeline last ran in
     bool same_frame_hint_ = false;      // hint_same_frame(): taken by the next evaluation entry point ...
     bool same_frame_now_ = false;       // ... for its run_pipeline
     long long same_frame_skips_ = 0;    // diagnostic: evaluations that launched no list kernel on the strength of the hint

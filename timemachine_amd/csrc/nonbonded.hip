@@ -690,6 +690,7 @@ template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const Fu
 
 // process-wide A/B switch (tm_debug_set_same_frame_hint): Potential::hint_same_frame is honoured
 bool g_same_frame_hint = true;
+thread_local long long g_eval_serial = 0;
 
 // process-wide A/B switch (tm_debug_set_energy_memo, TM_AMD_NO_ENERGY_MEMO): energy-only evaluations are remembered on the device
 bool g_energy_memo = std::getenv("TM_AMD_NO_ENERGY_MEMO") == nullptr;
@@ -750,7 +751,7 @@ Potential *NonbondedAllPairs<Real>::merged_carrier(NonbondedAllPairsBase *group,
     }
     merged_->guest_p_ = d_p_group;
     if (same_frame_hint_) { // (the plan evaluates the carrier in this potential's place)
-        merged_->hint_same_frame();
+        merged_->hint_same_frame(true, hint_call_);
         same_frame_hint_ = false;
     }
     merged_->box_scales_ = box_scales_ || group->expects_box_scaling();
@@ -841,6 +842,7 @@ void NonbondedAllPairs<Real>::execute_device(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u,
     hipStream_t stream) {
     same_frame_now_ = same_frame_hint_; // (taken before anything can throw: a hint never outlives the call it was given for)
+    hint_call_now_ = hint_call_;
     same_frame_hint_ = false;
     this->check_sizes(N, P);
     if (empty_) {
@@ -861,6 +863,7 @@ bool NonbondedAllPairs<Real>::execute_energy_partials(
     const int N, const int P, const double *d_x, const double *d_p, const double *d_box, hipStream_t stream, const i128 *&partials,
     int &count, i128 *d_final) {
     same_frame_now_ = same_frame_hint_;
+    hint_call_now_ = hint_call_;
     same_frame_hint_ = false;
     this->check_sizes(N, P);
     if (empty_) {
@@ -1065,8 +1068,9 @@ void NonbondedAllPairs<Real>::run_pipeline(
     EnergyMemo *memo = memo_mode ? d_memo_.data : nullptr;
     // the caller's word (hint_same_frame) that coordinates and box are the last call's, and this pipeline's own that nothing has touched
     // its state since: whatever the list kernels could do they did a call ago
-    const bool same_frame = g_same_frame_hint && same_frame_now_ && last_x_ != nullptr && last_x_ == d_x && last_box_ == d_box && !pregathered;
+    const bool same_frame = g_same_frame_hint && same_frame_now_ && hint_call_now_ == last_call_ && last_x_ != nullptr && last_x_ == d_x && last_box_ == d_box && !pregathered;
     same_frame_now_ = false;
+    last_call_ = g_eval_serial;
     last_x_ = last_box_ = nullptr; // (set again where this call ends)
     pre_valid_ = false; // consumed by this call or stale after it
     // A sorted hand-over that this call does not consume may already have reset the list counters on the device (its maker

@@ -261,6 +261,14 @@ void Potential::execute_host_f64(
     }
 }
 
+namespace {
+struct HintWithdrawn { // Potential::hint_same_frame is for ONE call
+    Potential *p;
+    explicit HintWithdrawn(Potential *q) : p(q) {}
+    ~HintWithdrawn() { p->hint_same_frame(false); }
+};
+} // namespace
+
 void Potential::execute_batch_device(
     const int coord_batch_size, const int N, const int param_batch_size, const int P, const double *d_x, const double *d_p,
     const double *d_box, u64 *d_du_dx, u64 *d_du_dp, i128 *d_u, hipStream_t stream) {
@@ -268,8 +276,10 @@ void Potential::execute_batch_device(
     for (int i = 0; i < coord_batch_size; i++) {
         for (int j = 0; j < param_batch_size; j++) {
             const size_t k = static_cast<size_t>(i) * param_batch_size + j;
+            HintWithdrawn withdrawn(this); // (after the call, thrown out of or not: whatever child did not run in it must not keep the hint)
+            const long long prev_call = g_eval_serial++;
             if (j > 0) {
-                this->hint_same_frame(); // (the frame's coordinates and box sit where they sat a call ago, untouched)
+                this->hint_same_frame(true, prev_call); // (the frame's coordinates and box sit where they sat a call ago, untouched)
             }
             this->execute_device(
                 N, P, d_x + static_cast<size_t>(i) * N * D, P > 0 ? d_p + static_cast<size_t>(j) * P : nullptr, d_box + i * D * D,
@@ -290,8 +300,10 @@ void Potential::execute_batch_sparse_device(
     long long ic_last = -1;
     for (const int i : order) {
         const size_t ic = coords_batch_idxs[i], ip = params_batch_idxs[i];
+        HintWithdrawn withdrawn(this);
+        const long long prev_call = g_eval_serial++;
         if (static_cast<long long>(ic) == ic_last) {
-            this->hint_same_frame();
+            this->hint_same_frame(true, prev_call);
         }
         ic_last = static_cast<long long>(ic);
         this->execute_device(
