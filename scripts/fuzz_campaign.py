@@ -34,3 +34,16 @@ for seed in range(200, 230):
                 nbad += 1
                 print("windows seed", seed, sk, prec.__name__, "MISMATCH" if bad else "", "NONFINITE" if not fin else "", bad[:4], len(fast), flush=True)
 print("windows campaign done", nbad, "bad of", 30 * 2 * 2)
+nbad = 0
+for seed in range(300, 340):
+    for sk, packed in ((0, False), (4608, False), (0, True)):
+        for prec in (np.float64, np.float32):
+            ops = T._make_ops(seed, 60)
+            fast, pf = T._run_single(co, prec, sk, False, ops, packed)
+            plain, pp = T._run_single(co, prec, sk, True, ops, packed)
+            bad = [k for k, (a, b) in enumerate(zip(fast, plain)) if not np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)]
+            fin = all(np.all(np.isfinite(a)) for a in fast[-5:-2])
+            if bad or not fin:
+                nbad += 1
+                print("single seed", seed, sk, packed, prec.__name__, "MISMATCH" if bad else "", "NONFINITE" if not fin else "", bad[:4], len(fast), flush=True)
+print("single-Nonbonded campaign done", nbad, "bad of", 40 * 3 * 2)

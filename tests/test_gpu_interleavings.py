@@ -227,3 +227,82 @@ def test_random_interleavings_of_windows_that_share_the_gpu(co, static_k, seed, 
         np.testing.assert_array_equal(a, b, err_msg=f"record {k} of {len(fast)}")
     assert all(np.all(np.isfinite(a)) for a in fast[-9:])
     assert stats_plain[3] == 0 and stats_fast[3] > 0 and all(f[0] == p[0] > 0 and p[1] == 0 and f[1] > 0 for f, p in zip(stats_fast[:3], stats_plain[:3])), (stats_fast, stats_plain)
+
+
+def _run_single(co, precision, static_k, plain, ops, packed):
+    """the benchmark's composition -- bonded terms + ONE all-atom Nonbonded (fe/free_energy.py:614-657), a barostat every 4 steps.
+    ``plain``: every step is a call of its own behind set_x_t / set_v_t / set_box of the values just read (which drop every hand-over
+    between the potential and the integrator: csrc/integrator.hip, Context::set_x_t), attempts reference-shaped; otherwise the calls
+    as a user makes them.  ``packed``: the state as ONE SummedPotential (how the reference's fe layer binds it)."""
+    from timemachine_amd import potentials as P
+    from timemachine_amd import testsystems as ts
+    from timemachine_amd.lib import LangevinIntegrator, MonteCarloBarostat
+
+    s = ts.small_solvated_ligand(lamb=0.3)
+    N = s.num_atoms
+    v0 = np.random.default_rng(17).normal(size=s.coords.shape) * 0.2
+    out = []
+    with _AllSwitches(co, not plain, static_k):
+        parts = ts.bound_potentials(s, nblist_padding=0.1)
+        if packed:
+            flat = np.concatenate([np.asarray(bp.params, dtype=np.float64).reshape(-1) for bp in parts])
+            bound = [P.SummedPotential([bp.potential for bp in parts], [bp.params for bp in parts]).bind(flat)]
+        else:
+            bound = parts
+        bps = [bp.to_gpu(precision).bound_impl for bp in bound]
+        baro = MonteCarloBarostat(N, 1.0, 300.0, ts.molecule_groups(s), 4, 3).impl(bps)
+        ctxt = co.Context(s.coords, v0, s.box, LangevinIntegrator(300.0, 1.5e-3, 1.0, s.masses, 5).impl(), bps, movers=[baro])
+        nb_params = np.asarray(parts[-1].params, dtype=np.float64)
+        for kind, n, op_seed in ops:
+            rng = np.random.default_rng(op_seed)
+            x, box = ctxt.get_x_t(), ctxt.get_box()
+            if kind in ("steps", "local", "bound_batch"):
+                if plain:
+                    for _ in range(n):
+                        ctxt.set_x_t(ctxt.get_x_t())
+                        ctxt.set_v_t(ctxt.get_v_t())
+                        ctxt.set_box(ctxt.get_box())
+                        ctxt.step()
+                else:
+                    ctxt.multiple_steps(n, 0)
+            elif kind in ("energy", "fixed"):
+                out += [np.float64(bp.execute(x, box, False, True)[1]) for bp in bps]
+            elif kind == "forces":
+                out += [bp.execute(x, box, True, False)[0] for bp in bps]
+            elif kind in ("elsewhere", "unbound"):
+                for bp in bps:
+                    du, u = bp.execute(x + rng.normal(0.0, 0.0003 * n, x.shape), box * (1.0 + 0.001 * n), True, True)
+                    out += [du, np.float64(u)]
+            elif kind == "set_x":
+                ctxt.set_x_t(x + rng.normal(0.0, 0.0002 * n, x.shape))
+            elif kind == "set_box":
+                ctxt.set_box(box * (1.0 + 0.0005 * (n - 3)))
+            elif kind == "velocities":
+                ctxt.set_v_t(ctxt.get_v_t() * (1.0 - 0.01 * n))
+            elif kind in ("set_params", "restore_params") and not packed:
+                scale = np.array([1.0 - 0.01 * n if kind == "set_params" else 1.0, 1.0, 1.0, 1.0])
+                bps[-1].set_params((nb_params * scale).reshape(-1))
+            elif kind in ("batch", "batch_sparse"):
+                frames = np.stack([x, x + rng.normal(0.0, 0.002, x.shape)])
+                for bp in bps[-1:]:
+                    res = bp.execute_batch(frames, np.stack([box, box * 1.001]), n % 2 == 0, True)
+                    out += [np.asarray(r) for r in res if r is not None]
+            out += [ctxt.get_x_t(), ctxt.get_v_t(), ctxt.get_box()]
+        out += [np.asarray(baro.get_counters()), np.float64(baro.get_volume_scale_factor())]
+        paths = baro.get_attempt_paths()
+    return out, paths
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("static_k,seed,packed", [(0, 7, False), (4608, 8, False), (0, 9, True)])
+def test_random_interleavings_on_the_benchmark_composition(co, static_k, seed, packed, precision):
+    """one all-atom Nonbonded: the sorted hand-over to the integrator, the slot-ordered update, bonded terms riding on the tile launch,
+    barostat attempts on the current list -- against a run in which every step is a call of its own behind setters that drop all of it"""
+    ops = _make_ops(seed, 60)
+    fast, paths_fast = _run_single(co, precision, static_k, False, ops, packed)
+    plain, paths_plain = _run_single(co, precision, static_k, True, ops, packed)
+    assert len(fast) == len(plain)
+    for k, (a, b) in enumerate(zip(fast, plain)):
+        np.testing.assert_array_equal(a, b, err_msg=f"record {k} of {len(fast)}")
+    assert all(np.all(np.isfinite(a)) for a in fast[-5:-2])
+    assert paths_fast[0] == paths_plain[0] > 0 and paths_plain[1] == 0 and paths_fast[1] > 0, (paths_fast, paths_plain)
