@@ -9,7 +9,7 @@ from timemachine_amd import potentials as P
 co.set_device(0)
 t0 = time.time()
 nbad = 0
-for seed in range(100, 140):
+for seed in range(100, 160):
     for which, sk, n in (("config2", 0, 80), ("config2", 4608, 80), ("config4", 0, 40)):
         for prec in (np.float64, np.float32):
             ops = T._make_ops(seed, n)
