@@ -619,7 +619,11 @@ void verify_atom_idxs(const int N, const std::vector<int> &atom_idxs, const bool
 
 extern double g_last_host_call_device_ms; // potential.hip: device time of the evaluations of the last execute_host_f64 call
 extern bool g_same_frame_hint; // the batch entry points' hint_same_frame() is honoured (tm_debug_set_same_frame_hint)
-extern thread_local long long g_eval_serial; // number of the batch entry being evaluated on this thread (Potential::execute_batch[_sparse]_device)
+// Numbers of the batch entries (Potential::execute_batch[_sparse]_device): drawn from one process-wide counter, so that no two entries
+// -- of whatever thread -- share one; g_eval_serial is the number of the entry being evaluated on THIS thread (children run inside
+// their caller's call), which a pipeline notes when it runs.
+long long next_eval_serial();
+extern thread_local long long g_eval_serial;
 extern bool g_energy_memo;     // energy-only evaluations are remembered on the device (EnergyMemo; tm_debug_set_energy_memo)
 extern bool g_merge_producers; // ForcePlan::merge_producers runs all-pairs + interaction group as one pipeline (tm_debug_set_merge_producers)
 extern bool g_barostat_fast_path; // MonteCarloBarostat attempts run on the potential's current list when its state allows (tm_debug_set_barostat_fast_path)

@@ -2,6 +2,7 @@
 // One translation unit on purpose: the tile kernel and the pair-list kernel must inline the same nb_pair() under
 // the same compiler flags (exact fixed-point cancellation of exclusions).
 #include "engine.hpp"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "kernels_nblist.hip.hpp"
@@ -691,6 +692,10 @@ template <typename Real> bool NonbondedAllPairs<Real>::piggyback_energy(const Fu
 // process-wide A/B switch (tm_debug_set_same_frame_hint): Potential::hint_same_frame is honoured
 bool g_same_frame_hint = true;
 thread_local long long g_eval_serial = 0;
+long long next_eval_serial() {
+    static std::atomic<long long> counter{0};
+    return ++counter;
+}
 
 // process-wide A/B switch (tm_debug_set_energy_memo, TM_AMD_NO_ENERGY_MEMO): energy-only evaluations are remembered on the device
 bool g_energy_memo = std::getenv("TM_AMD_NO_ENERGY_MEMO") == nullptr;

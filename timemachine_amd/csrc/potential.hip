@@ -277,7 +277,8 @@ void Potential::execute_batch_device(
         for (int j = 0; j < param_batch_size; j++) {
             const size_t k = static_cast<size_t>(i) * param_batch_size + j;
             HintWithdrawn withdrawn(this); // (after the call, thrown out of or not: whatever child did not run in it must not keep the hint)
-            const long long prev_call = g_eval_serial++;
+            const long long prev_call = g_eval_serial; // (the entry before this one, if this loop made one: hinted entries only)
+            g_eval_serial = next_eval_serial();
             if (j > 0) {
                 this->hint_same_frame(true, prev_call); // (the frame's coordinates and box sit where they sat a call ago, untouched)
             }
@@ -301,7 +302,8 @@ void Potential::execute_batch_sparse_device(
     for (const int i : order) {
         const size_t ic = coords_batch_idxs[i], ip = params_batch_idxs[i];
         HintWithdrawn withdrawn(this);
-        const long long prev_call = g_eval_serial++;
+        const long long prev_call = g_eval_serial;
+        g_eval_serial = next_eval_serial();
         if (static_cast<long long>(ic) == ic_last) {
             this->hint_same_frame(true, prev_call);
         }
