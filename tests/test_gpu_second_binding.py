@@ -33,6 +33,14 @@ def test_gpu_parity_subset_through_the_ctypes_binding():
     )
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout and "failed" not in r.stdout
+    # ... and the randomized tests: every entry point a window's caller has (Context with movers, local MD, setters, batches dense
+    # and sparse, set_atom_idxs, grouped stepping) and every potential class, through the ctypes marshalling
+    r = subprocess.run(
+        [sys.executable, "-m", "pytest", "tests/test_gpu_interleavings.py", "tests/test_gpu_random_parity.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+        cwd=REPO, env=env, capture_output=True, text=True, timeout=900,
+    )
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 ROWBLOCK_LIB = os.path.join(REPO, "timemachine_amd", "csrc", "libtimemachine_amd_rowblock.so")
