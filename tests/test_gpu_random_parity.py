@@ -182,7 +182,7 @@ def run_bonded_case(seed, precision):
     angles = np.stack([a, b, c], 1)[ok].astype(np.int32)
     if len(angles):
         ap = np.stack([rng.uniform(0.0, ka_max, len(angles)), rng.uniform(1.0, 3.0, len(angles)), rng.choice([0.0, 1e-3], len(angles))], 1)
-        compare("angle", P.HarmonicAngle(angles), ap, rp.harmonic_angle(x, ap, box, angles), rtol, ptol)
+        compare("angle", P.HarmonicAngle(angles), ap, rp.harmonic_angle(x, ap, box, angles), rtol if f64 else 4e-4, ptol)  # (f32: short arms, angles near pi)
     ok = (a != c) & (a != e) & (b != e)
     tors = np.stack([a, b, c, e], 1)[ok].astype(np.int32)
     if len(tors):
