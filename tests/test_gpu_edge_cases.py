@@ -716,3 +716,32 @@ def test_two_contexts_driven_from_two_host_threads():
     for c, (x, v) in zip(ctxts, ref):
         np.testing.assert_array_equal(c.get_x_t(), x)
         np.testing.assert_array_equal(c.get_v_t(), v)
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+def test_a_fully_excluded_clash_beyond_the_accumulators_range_cancels_whichever_atom_is_the_row(co, P, precision):
+    """Two fully excluded atoms 0.11 nm apart with sigma_ij = 0.36 nm push force components of 2e8 ... 6e8 kJ/mol/nm through the tile
+    kernel and the exclusion kernel: beyond the fixed-point accumulator's range (2^27 = 1.3e8; the reference's too, k_fixed_point.cuh).
+    The two contributions must still cancel to an exact zero, and with either atom as the tile's row: the pair's second atom gets the
+    two's-complement negation of the first one's integers, which equals its own conversion only if the slow conversion is odd beyond
+    the range as well (csrc/fixed_point.hip.hpp: tm_llrint_odd; the device's llrint saturates asymmetrically, which left +-2^-4
+    kJ/mol/nm on the pair depending on the neighbor list's state -- found by scripts/fuzz_campaign.py)."""
+    x = np.array([[1.0, 1.0, 1.0], [1.035, 1.03, 1.1], [2.5, 2.5, 2.5], [0.4, 2.1, 0.3]])
+    params = np.array([[2.4, 0.18, 1.0, 0.0], [-1.4, 0.18, 1.0, 0.0], [0.3, 0.15, 0.2, 0.0], [-0.3, 0.15, 0.2, 0.0]])
+    box = np.eye(3) * 4.0
+    excl, scales = np.array([[0, 1]], dtype=np.int32), np.array([[1.0, 1.0]])
+    ref = None
+    for order in ([0, 1, 2, 3], [1, 0, 2, 3]):
+        for hilbert_off in (False, True):
+            nb = P.Nonbonded(4, excl, scales, 2.0, 1.2, disable_hilbert_sort=hilbert_off).to_gpu(precision).unbound_impl
+            du_dx = nb.execute(x[order], params[order], box, True, False, False)[0]
+            parts = nb.get_potentials()
+            big = parts[0].execute(x[order], params[order], box, True, False, False)[0]
+            assert np.abs(big[:2]).max() > 1.34e8  # (the all-pairs part alone: pinned at the accumulator's range, 2^27)
+            back = np.empty_like(du_dx)
+            back[order] = du_dx
+            if ref is None:
+                ref = back
+            np.testing.assert_array_equal(back, ref)
+    # atoms 0 and 1 feel only atoms 2 and 3 (far, weak): the clash itself is gone to the last bit
+    assert np.abs(ref[:2]).max() < 10.0

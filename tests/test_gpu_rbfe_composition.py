@@ -609,38 +609,3 @@ def test_batches_over_parameter_sets_skip_the_list_kernels_and_keep_their_bits(c
         assert skips >= 2 * (12 + 4), skips
     energies = with_hint[0][2]
     assert len(np.unique(energies)) == energies.size  # every (frame, set) pair is a different evaluation
-
-
-@pytest.mark.parametrize("precision", [np.float64, np.float32])
-def test_a_same_frame_hint_does_not_outlive_the_call_it_was_given_for(co, P, precision):
-    """Found by tests/test_gpu_interleavings.py, kept here as a directed case.  A batch over parameter sets hints its children that the
-    next call's frame is the last call's (Potential::hint_same_frame).  In the energy-only form the all-pairs potential's merged
-    carrier does the interaction group's work, so the group itself never ran and never consumed its hint: the next full-form call --
-    which evaluates the group separately, on ANOTHER frame behind the same staging pointers -- must not find it (it skipped its list
-    kernels on the strength of it: a stale list, the pairs that had moved inside the cutoff missing)."""
-    from timemachine_amd import testsystems as ts
-
-    s, n_lig = _system("config2")
-    N = s.num_atoms
-    state = ts.rbfe_shaped_state(s, n_lig, env_charge_scale=0.9)
-    flat = np.concatenate([np.asarray(q, dtype=np.float64).reshape(-1) for _, q in state])
-    sets = np.stack([flat, flat])
-    sets[1][flat.size - 4 * N :].reshape(-1, 4)[N - n_lig :, 0] *= 0.9
-    rng = np.random.default_rng(8)
-    x0 = s.coords
-    x1 = s.coords + rng.normal(0.0, 0.002, s.coords.shape)
-    x2 = s.coords + rng.normal(0.0, 0.05, s.coords.shape) * (rng.random((N, 1)) < 0.3)  # a third of the atoms moved by more than the padding
-    if precision == np.float32:
-        x2 = x2.astype(np.float32).astype(np.float64)
-
-    def summed():
-        return P.SummedPotential([p for p, _ in state], [q for _, q in state]).to_gpu(precision).unbound_impl
-
-    with _Switches(co, merge=True, static_k=0):
-        impl = summed()
-        impl.execute(x0, sets[0], s.box, True, True, True)  # the group builds its own list, at x0
-        impl.execute_batch(np.stack([x1]), sets, np.stack([s.box]), False, False, True)  # merged; the second set's call is hinted
-        got = impl.execute(x2, sets[0], s.box, True, True, True)
-        ref = summed().execute(x2, sets[0], s.box, True, True, True)
-    for a, b in zip(got, ref):
-        np.testing.assert_array_equal(a, b)

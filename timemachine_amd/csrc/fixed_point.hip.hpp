@@ -25,6 +25,17 @@ namespace tmamd {
 __device__ __forceinline__ long long real_to_int64_fast(double x) {
     return __double_as_longlong(x + TM_FIXED_MAGIC) - __double_as_longlong(TM_FIXED_MAGIC);
 }
+// The slow conversion of a value whose NEGATION is applied to the pair's other atom as the two's-complement negation of the result
+// (pair_force_fixed*: FIX(-v) == -FIX(v), three conversions per pair instead of six).  llrint is odd for every value an int64
+// holds; BEYOND that range (a force component above 2^27 kJ/mol/nm: the accumulator's own range, here as in the reference) the
+// device's conversion saturates its high word to 2^31 - 1 on one side and -2^31 on the other, so FIX(-v) and -FIX(v) differed by
+// 2^32 units -- 2^-4 kJ/mol/nm -- and a pair's contribution depended on which of its atoms the tile had as its row: the list's
+// state showed in the result (found by scripts/fuzz_campaign.py on a synthetic ligand whose excluded 1-3 pairs clash that hard).
+// Odd by construction: the same integers for every in-range value, and whatever the saturation gives, mirrored.
+__device__ __forceinline__ long long tm_llrint_odd(const double x) {
+    const long long r = llrint(__builtin_fabs(x));
+    return x < 0 ? -r : r;
+}
 __device__ __forceinline__ long long real_to_int64(double x) {
     long long r = real_to_int64_fast(x);
     const bool big = !(__builtin_fabs(x) < TM_FIXED_FAST_LIMIT);

@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__((64 * TileShape<Real, tile_wide<Real, COMPUTE_U, CO
                             r_sg = llrint(x_sg);
                             r_ei = llrint(x_ei);
                             r_ej = llrint(x_ej);
-                            r_w = llrint(FLAT ? static_cast<double>((o.prefactor * ddw) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DW)) : x_w);
+                            r_w = tm_llrint_odd(FLAT ? static_cast<double>((o.prefactor * ddw) * static_cast<Real>(TM_FIXED_EXPONENT_DU_DW)) : x_w);
                         } else if (FLAT) {
                             r_w = 0;
                         }

@@ -425,9 +425,9 @@ __device__ __forceinline__ void pair_force_fixed_fast_bounded(double prefactor, 
 }
 __device__ __forceinline__ void pair_force_fixed_slow(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
     const double ps = prefactor * static_cast<double>(TM_FIXED_EXPONENT);
-    fx = static_cast<u64>(llrint(ps * dx));
-    fy = static_cast<u64>(llrint(ps * dy));
-    fz = static_cast<u64>(llrint(ps * dz));
+    fx = static_cast<u64>(tm_llrint_odd(ps * dx));
+    fy = static_cast<u64>(tm_llrint_odd(ps * dy));
+    fz = static_cast<u64>(tm_llrint_odd(ps * dz));
 }
 __device__ __forceinline__ void pair_force_fixed(double prefactor, double dx, double dy, double dz, u64 &fx, u64 &fy, u64 &fz) {
     bool big;
@@ -453,9 +453,9 @@ __device__ __forceinline__ void pair_force_fixed(float prefactor, float dx, floa
                        __builtin_fabs(c) < TM_FIXED_FAST_LIMIT);
     if (__ballot(big) != 0ull) {
         if (big) {
-            fx = static_cast<u64>(llrint(a));
-            fy = static_cast<u64>(llrint(b));
-            fz = static_cast<u64>(llrint(c));
+            fx = static_cast<u64>(tm_llrint_odd(a));
+            fy = static_cast<u64>(tm_llrint_odd(b));
+            fz = static_cast<u64>(tm_llrint_odd(c));
         }
     }
 }
@@ -471,9 +471,9 @@ __device__ __forceinline__ void pair_force_fixed_bounded(float prefactor, float 
     const bool big = !(__builtin_fabsf(prefactor) < limit); // (true for NaN)
     if (__ballot(big) != 0ull) {
         if (big) {
-            fx = static_cast<u64>(llrint(a));
-            fy = static_cast<u64>(llrint(b));
-            fz = static_cast<u64>(llrint(c));
+            fx = static_cast<u64>(tm_llrint_odd(a));
+            fy = static_cast<u64>(tm_llrint_odd(b));
+            fz = static_cast<u64>(tm_llrint_odd(c));
         }
     }
 }
