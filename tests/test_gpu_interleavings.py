@@ -260,8 +260,8 @@ def _run_single(co, precision, static_k, plain, ops, packed):
     out = []
     with _AllSwitches(co, not plain, static_k):
         parts = ts.bound_potentials(s, nblist_padding=0.1)
+        flat = np.concatenate([np.asarray(bp.params, dtype=np.float64).reshape(-1) for bp in parts])
         if packed:
-            flat = np.concatenate([np.asarray(bp.params, dtype=np.float64).reshape(-1) for bp in parts])
             bound = [P.SummedPotential([bp.potential for bp in parts], [bp.params for bp in parts]).bind(flat)]
         else:
             bound = parts
@@ -295,9 +295,12 @@ def _run_single(co, precision, static_k, plain, ops, packed):
                 ctxt.set_box(box * (1.0 + 0.0005 * (n - 3)))
             elif kind == "velocities":
                 ctxt.set_v_t(ctxt.get_v_t() * (1.0 - 0.01 * n))
-            elif kind in ("set_params", "restore_params") and not packed:
+            elif kind in ("set_params", "restore_params"):
                 scale = np.array([1.0 - 0.01 * n if kind == "set_params" else 1.0, 1.0, 1.0, 1.0])
-                bps[-1].set_params((nb_params * scale).reshape(-1))
+                if packed:  # the whole state's parameters replaced behind the one bound potential (an HREX state move)
+                    bps[0].set_params(np.concatenate([flat[: flat.size - nb_params.size], (nb_params * scale).reshape(-1)]))
+                else:
+                    bps[-1].set_params((nb_params * scale).reshape(-1))
             elif kind in ("batch", "batch_sparse"):
                 frames = np.stack([x, x + rng.normal(0.0, 0.002, x.shape)])
                 for bp in bps[-1:]:
