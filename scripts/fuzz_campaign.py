@@ -20,7 +20,7 @@ for seed in range(100, 160):
             if bad or not fin:
                 nbad += 1
                 print("seed", seed, which, sk, prec.__name__, "MISMATCH" if bad else "", "NONFINITE" if not fin else "", [(k, labels[k]) for k in bad[:3]], flush=True)
-print("campaign done", nbad, "bad of", 40 * 3 * 2, f"{time.time()-t0:.0f}s")
+print("campaign done", nbad, "bad of", 60 * 3 * 2, f"{time.time()-t0:.0f}s")
 nbad = 0
 for seed in range(200, 230):
     for sk in (0, 4608):
