@@ -609,3 +609,37 @@ def test_batches_over_parameter_sets_skip_the_list_kernels_and_keep_their_bits(c
         assert skips >= 2 * (12 + 4), skips
     energies = with_hint[0][2]
     assert len(np.unique(energies)) == energies.size  # every (frame, set) pair is a different evaluation
+
+
+@pytest.mark.parametrize("precision", [np.float64, np.float32])
+@pytest.mark.parametrize("barostat", [None, (4, 1.0, 3)])
+def test_separate_producers_after_a_merged_stretch_do_not_find_their_old_pre_gather(co, P, barostat, precision):
+    """A window whose interaction group loses and regains columns at run time (set_atom_idxs: what the reference's water-sampling and
+    local moves do to their groups) steps  separate producers -> merged carrier -> separate producers.  While the carrier evaluates in
+    their place the two potentials keep what an update kernel pre-gathered for them before the merged stretch -- behind the same
+    coordinate pointers -- and must not use it when they become producers again (csrc/engine.hpp: carrier_took_over; found by
+    tests/test_gpu_interleavings.py at config-5 size: attempts on the current list, unlike reference-shaped ones, do not happen to
+    invalidate it).  Against the same calls with merging off; with and without a barostat."""
+    s, n_lig = _system("config2")
+    N = s.num_atoms
+    host = np.arange(N - n_lig, dtype=np.int32)
+    lig = np.arange(N - n_lig, N, dtype=np.int32)
+    v0 = np.random.default_rng(4).normal(size=s.coords.shape) * 0.2
+
+    def run(merge):
+        with _Switches(co, merge=merge, static_k=0, fast=True):
+            ctxt, bps, baro = _context(co, s, n_lig, precision, 0.1, v0, env_scale=0.9, barostat=barostat)
+            group = bps[-1].get_potential()
+            out = []
+            for cols, n in ((host[:-9], 3), (host, 6), (host[:-12], 2), (host[:-9], 4), (host, 5)):
+                group.set_atom_idxs(lig, cols)
+                ctxt.multiple_steps(n, 0)
+                out += [ctxt.get_x_t(), ctxt.get_v_t(), ctxt.get_box()]
+            return out, _host_all_pairs(bps).get_merged_stats()[0]
+
+    merged, n_merged = run(True)
+    plain, n_plain = run(False)
+    assert n_plain == 0 and n_merged > 0
+    for a, b in zip(merged, plain):
+        np.testing.assert_array_equal(a, b)
+    assert np.all(np.isfinite(merged[-3]))

@@ -686,6 +686,13 @@ public:
     // to the group's parameters for the coming call -- or nullptr when the two do not fit (different precision / beta / cutoff,
     // the group's columns are not exactly this potential's atoms, an empty side, du/dp wanted ...)
     virtual Potential *merged_carrier(NonbondedAllPairsBase *group, const int P_group, const double *d_p_group) { return nullptr; }
+    // The carrier is about to evaluate in this potential's place: whatever this potential remembers about its own inputs -- positions
+    // an update kernel pre-gathered for it while it was a producer of its own -- describes a call it will not make.  Without this a
+    // window that went  separate producers -> merged (restore of the group's atom set) -> separate again  found its all-pairs potential
+    // holding a "valid" pre-gather from before the merged stretch behind the same pointers, and stepped on coordinates that many steps
+    // old (tests/test_gpu_interleavings.py at config-5 size; every reference-shaped barostat attempt happened to clear it, attempts on
+    // the current list do not).  The carrier's own state is not touched.
+    virtual void carrier_took_over() {}
     // what the all-pairs side needs to know about a candidate group
     virtual const std::vector<unsigned int> &host_atom_idxs() const = 0; // group: rows (ascending) then columns; all-pairs: its atoms (ascending)
     virtual int num_group_rows() const { return 0; }
@@ -744,6 +751,10 @@ public:
         }
     }
     void expect_box_scaling() override { box_scales_ = true; }
+    void carrier_took_over() override {
+        pre_valid_ = false;
+        last_x_ = last_box_ = nullptr;
+    }
     Potential *merged_carrier(NonbondedAllPairsBase *group, const int P_group, const double *d_p_group) override;
     const std::vector<unsigned int> &host_atom_idxs() const override { return h_atom_idxs_; }
     int num_group_rows() const override { return group_rows_; }

@@ -760,6 +760,8 @@ Potential *NonbondedAllPairs<Real>::merged_carrier(NonbondedAllPairsBase *group,
         same_frame_hint_ = false;
     }
     merged_->box_scales_ = box_scales_ || group->expects_box_scaling();
+    this->carrier_took_over();
+    group->carrier_took_over();
     return merged_.get();
 }
 
