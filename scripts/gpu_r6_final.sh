@@ -28,7 +28,9 @@ timeout 900 python bench.py --gpus 8 --share-gpu > $A/bench_share_gpu_md.json 2>
 timeout 900 python bench.py --gpus 8 --share-gpu --mode hrex > $A/bench_share_gpu_hrex.json 2> $A/bench_share_gpu_hrex.err
 ( timeout 1500 python scripts/soak_rbfe.py 200000 2>&1 | grep -v amdgpu.ids ) > $A/soak_rbfe.txt 2>&1
 # random interleavings (every fast path on = off) and random systems against the oracle, over many seeds
-( timeout 900 python scripts/fuzz_campaign.py 2>&1 | grep -v amdgpu.ids; timeout 900 python scripts/fuzz_parity.py 100 300 2>&1 | grep -v amdgpu.ids ) > $A/fuzz.txt 2>&1
+( timeout 900 python scripts/fuzz_campaign.py 2>&1 | grep -v amdgpu.ids; timeout 900 python scripts/fuzz_parity.py 100 300 2>&1 | grep -v amdgpu.ids
+  echo "-- scripts/fuzz_campaign_long.py 100 9000"; timeout 900 python scripts/fuzz_campaign_long.py 100 9000 2>&1 | grep -v amdgpu.ids
+  echo "-- scripts/fuzz_campaign_config5.py 300 9000 (single windows at config-5 size)"; timeout 900 python scripts/fuzz_campaign_config5.py 300 9000 600 2>&1 | grep -v amdgpu.ids ) > $A/fuzz.txt 2>&1
 ( bash scripts/gpu_nbl_probe.sh f64 product; bash scripts/gpu_nbl_probe.sh f32 product ) > $A/nbl_probe.txt 2>&1
 tail -30 gpurun_out/art_$TAG.log
 for f in gpu_tests gpu_tests_guard npt_trace_f64 further_sets matrix_probe soak_rbfe fuzz nbl_probe; do echo "== $f"; tail -12 $A/$f.txt | cut -c1-300; done
