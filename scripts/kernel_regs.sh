@@ -3,7 +3,7 @@
 src=$1; filt=${2:-.}; shift; shift
 cd "$(dirname "$0")/../timemachine_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" -I../../include \
-  -Rpass-analysis=kernel-resource-usage -x hip -c $src -o /tmp/_regs.o 2>&1 | python3 -c "
+  -Rpass-analysis=kernel-resource-usage -x hip -c $src -o /tmp/_regs_$$.o 2>&1 | python3 -c "
 import re,sys,subprocess
 cur=None; rows=[]
 for l in sys.stdin:
