@@ -100,6 +100,18 @@ def pair_force_sums(x, prm, box, cutoff, beta, ex=None, scales=None, rows=None, 
     return g.sum(1)
 
 
+def cutoff_off_straddling_pairs(x, prm, box, cutoff):
+    """the cutoff, moved up in steps of 3e-4 nm until no pair's d^2 (4D, minimum image) lies within 2e-6 nm^2 of cutoff^2 as an f32
+    kernel reads it"""
+    L = np.diagonal(box)
+    d = x[:, None, :] - x[None, :, :]
+    d -= L * np.rint(d / L)
+    d2 = (d ** 2).sum(-1) + (prm[:, 3][:, None] - prm[None, :, 3]) ** 2
+    while np.any(np.abs(d2 - np.float64(np.float32(cutoff)) ** 2) < 2e-6):
+        cutoff += 3e-4
+    return cutoff
+
+
 def check(tag, got, ref, precision, pair_sums):
     du_dx, du_dp, u = got
     ref_u, ref_dx, ref_dp = ref
@@ -127,12 +139,7 @@ def run_case(seed, precision):
         # the cutoff is a step in the force (the electrostatic part is not switched off at it): a pair whose d^2 lies within f32
         # rounding of cutoff^2 is inside for one precision and outside for the other, and the comparison measures that pair's whole
         # force (scripts/fuzz_parity.py, seed 21355: d^2 - cutoff^2 = -8.8e-8 in f64, +1.8e-7 in f32).  Move the cutoff off such pairs.
-        L = np.diagonal(box)
-        d = x[:, None, :] - x[None, :, :]
-        d -= L * np.rint(d / L)
-        d2 = (d ** 2).sum(-1) + (prm[:, 3][:, None] - prm[None, :, 3]) ** 2
-        while np.any(np.abs(d2 - np.float64(np.float32(cutoff)) ** 2) < 2e-6):
-            cutoff += 3e-4
+        cutoff = cutoff_off_straddling_pairs(x, prm, box, cutoff)
     tag = f"seed {seed} N {N} cutoff {cutoff} box {np.diagonal(box).round(2)}"
     nb = P.Nonbonded(N, s["ex"], s["scales"], beta, cutoff).to_gpu(precision).unbound_impl
     sums = pair_force_sums(x, prm, box, cutoff, beta, s["ex"], s["scales"])
